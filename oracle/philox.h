@@ -1,0 +1,104 @@
+/*
+ * oracle/philox.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * CPU statement of the counter-based generator the HIP kernels use
+ * (bboptpy_amd/csrc/bbo_rng.hpp holds the device twin): Philox4x32-10
+ * (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the
+ * Random123 known-answer vectors are checked in tests/test_rng.py) plus the
+ * bit -> double conversions and the Box-Muller transform.  The reference has
+ * no counterpart: it consumes one process-global std::mt19937
+ * (/root/reference/src/random.hpp:677-680), which a device generator cannot
+ * reproduce (hard part 2) -- the oracle therefore carries
+ * BOTH generators (mt19937 replay in bbo_oracle.cpp, this one here).
+ *
+ * Counter layout (shared with the device code):
+ *   c0 = row (candidate / individual / particle index)
+ *   c1 = column block (pair index for normals, word index for uniforms)
+ *   c2 = generation (or draw sequence number)
+ *   c3 = (stream << 24) | sub-stream
+ * key  = 64-bit seed of the optimizer handle.
+ */
+#ifndef BBO_ORACLE_PHILOX_H_
+#define BBO_ORACLE_PHILOX_H_
+
+#include <math.h>
+#include <stdint.h>
+
+enum {
+    BBO_STREAM_CMA_NORMAL = 1,   /* CMA-ES sampling normals             */
+    BBO_STREAM_INIT = 2,         /* uniform initial populations         */
+    BBO_STREAM_DE_PARAM = 3,     /* DE per-individual parameter draws   */
+    BBO_STREAM_DE_CROSS = 4,     /* DE per-coordinate crossover draws   */
+    BBO_STREAM_PSO_R = 5,        /* PSO r1/r2 per coordinate            */
+    BBO_STREAM_PSO_CTRL = 6,     /* APSO delta1/delta2/elitist draws    */
+    BBO_STREAM_RESTART = 7,      /* IPOP/BIPOP restart points, u, u'    */
+    BBO_STREAM_DE_ARCH = 8       /* DE archive slot draws               */
+};
+
+static inline void bbo_philox4x32_10(const uint32_t key_in[2],
+        const uint32_t ctr_in[4], uint32_t out[4])
+{
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t) 0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t) 0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t) (p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t) p1;
+        const uint32_t n2 = (uint32_t) (p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t) p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline void bbo_philox(uint64_t seed, uint32_t c0, uint32_t c1,
+        uint32_t c2, uint32_t c3, uint32_t out[4])
+{
+    const uint32_t key[2] = { (uint32_t) seed, (uint32_t) (seed >> 32) };
+    const uint32_t ctr[4] = { c0, c1, c2, c3 };
+    bbo_philox4x32_10(key, ctr, out);
+}
+
+static inline uint32_t bbo_stream(int stream, uint32_t sub)
+{
+    return ((uint32_t) stream << 24) | (sub & 0x00FFFFFFu);
+}
+
+/* 53 random bits -> [0,1) */
+static inline double bbo_u01(uint32_t lo, uint32_t hi)
+{
+    const uint64_t b = (((uint64_t) hi << 32) | lo) >> 11;
+    return (double) b * 0x1.0p-53;
+}
+
+/* 53 random bits -> (0,1] (safe for log) */
+static inline double bbo_u01_open0(uint32_t lo, uint32_t hi)
+{
+    const uint64_t b = (((uint64_t) hi << 32) | lo) >> 11;
+    return (double) (b + 1) * 0x1.0p-53;
+}
+
+/* uniform integer in [0, range): multiply-shift (bias <= range / 2^32) */
+static inline int bbo_uint_below(uint32_t w, int range)
+{
+    return (int) (((uint64_t) w * (uint64_t) (uint32_t) range) >> 32);
+}
+
+/* one Philox call -> two standard normals (Box-Muller) */
+static inline void bbo_normal_pair(uint64_t seed, uint32_t c0, uint32_t c1,
+        uint32_t c2, uint32_t c3, double *z0, double *z1)
+{
+    uint32_t w[4];
+    bbo_philox(seed, c0, c1, c2, c3, w);
+    const double u1 = bbo_u01_open0(w[0], w[1]);
+    const double u2 = bbo_u01(w[2], w[3]);
+    const double r = sqrt(-2. * log(u1));
+    const double a = 6.283185307179586476925286766559 * u2;
+    *z0 = r * cos(a);
+    *z1 = r * sin(a);
+}
+
+#endif /* BBO_ORACLE_PHILOX_H_ */
