@@ -1,0 +1,749 @@
+// bbo_cma.hip -- host side of the CMA-ES / active CMA-ES engine: strategy constants,
+// HBM state, and the kernel sequence of one generation.
+//
+// Reference behaviour restated on the host: BaseCmaes::init (base_cmaes.cpp:54-134),
+// Cmaes::init (cmaes.cpp:44-63), ActiveCmaes::init (active_cmaes.cpp:42-69),
+// BaseCmaes::setParams (:136-148), optimize (:162-174), solution (:158-160).
+#include "bbo_cma_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace bbo {
+
+namespace {
+
+int pick_maxt(int ld)
+{
+    const int per_wave = ((ld >> 4) + 3) / 4;
+    if (per_wave <= 1) return 1;
+    if (per_wave <= 2) return 2;
+    if (per_wave <= 4) return 4;
+    return 8;
+}
+
+int gram_ldy(int ld)
+{
+    // rows k, k+1 of the slab must land 32 banks apart for the k-major fragment reads
+    return (ld % 32 == 0) ? ld + 16 : ld;
+}
+
+} // namespace
+
+CmaEngine::CmaEngine(const bbo_params &p) :
+        params_(p)
+{
+    BBO_REQUIRE(p.algo == BBO_ALGO_CMAES || p.algo == BBO_ALGO_ACTIVE_CMAES,
+            "CmaEngine: algo must be CMAES or ACTIVE_CMAES");
+    BBO_REQUIRE(p.np >= 4, "CMA-ES needs np >= 4 (mu >= 2, best/worst pairs)");
+    BBO_REQUIRE(p.populations >= 1, "populations must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(BBO_ERR_NO_DEVICE, "no HIP device visible: libbbopt_hip has no CPU path");
+    BBO_REQUIRE(p.device >= 0 && p.device < ndev, "device ordinal out of range");
+    BBO_HIP(hipSetDevice(p.device));
+    BBO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    BBO_HIP(hipHostMalloc((void**) &stop_host_, sizeof(int) * p.populations));
+}
+
+CmaEngine::~CmaEngine()
+{
+    if (stream_) (void) hipStreamDestroy(stream_);
+    if (stop_host_) (void) hipHostFree(stop_host_);
+}
+
+void CmaEngine::set_params(int np, double sigma, int mfev)
+{
+    params_.np = np;
+    params_.sigma0 = sigma;
+    params_.mfev = mfev;
+    if (params_.bound) {
+        params_.bound = 0;
+        fprintf(stderr, "Warning [CMA]: box bounding is no longer enabled.\n");
+    }
+}
+
+void CmaEngine::init(int n, const double *lower, const double *upper, const double *guess,
+        const ObjectiveSpec &obj)
+{
+    BBO_REQUIRE(n >= 1 && n <= EIG_NMAX, "dimension must be in [1, 512]");
+    BBO_HIP(hipSetDevice(params_.device));
+    obj_ = obj;
+    const int P = params_.populations;
+    const int lambda = params_.np;
+    CmaConst &c = c_;
+    c = CmaConst {};
+    c.n = n;
+    c.ld = round_up(n, 16);
+    c.lambda = lambda;
+    c.lambda_pad = round_up(lambda, 16);
+    c.mu = lambda / 2;
+    c.mu_pad = round_up(c.mu, 16);
+    c.variant = params_.algo == BBO_ALGO_ACTIVE_CMAES ? 1 : 0;
+    c.bound = params_.bound ? 1 : 0;
+    c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
+    c.mfev = params_.mfev;
+    c.mit = params_.mfev / lambda;
+    c.npop = P;
+    c.seed = params_.seed;
+    c.tol = params_.tol;
+    c.sigma0 = params_.sigma0;
+
+    // recombination weights, base_cmaes.cpp:92-105
+    std::vector<double> w(c.mu);
+    double sum = 0.;
+    for (int i = 0; i < c.mu; i++) {
+        w[i] = std::log(0.5 * (lambda + 1.)) - std::log(i + 1.);
+        sum += w[i];
+    }
+    const double inv = 1. / sum;
+    for (int i = 0; i < c.mu; i++) w[i] *= inv;
+    double lenw = 0.;
+    for (int i = 0; i < c.mu; i++) lenw = lenw + w[i] * w[i];
+    c.mueff = 1. / lenw;
+
+    // base_cmaes.cpp:108-117
+    c.chi = std::sqrt(n) * (1. - 1. / (4. * n) + 1. / (21. * n * n));
+    c.cc = (4. + c.mueff / n) / (n + 4. + 2. * c.mueff / n);
+    c.cs = (c.mueff + 2.) / (5. + n + c.mueff);
+    c.c1 = 2. / ((1.3 + n) * (1.3 + n) + c.mueff);
+    c.cmu = std::min(1. - c.c1,
+            2. * (c.mueff - 2. + 1. / c.mueff) / ((2. + n) * (2. + n) + c.mueff));
+    c.damps = 1. + c.cs + 2. * std::max(0., std::sqrt((c.mueff - 1.) / (n + 1.)) - 1.);
+    c.hlen = 10 + (int) std::ceil((30. * n) / lambda);
+    c.ik = (int) std::ceil(0.1 + lambda / 4.);
+    // cmaes.cpp:48
+    c.eigenfreq = params_.eigenrate * lambda / (c.c1 + c.cmu) / n;
+    c.cm = 1.;
+    c.alphaold = 0.5;
+    c.cneg = 0.;
+    if (c.variant == 1) {
+        // active_cmaes.cpp:48-64
+        const double ac = params_.alphacov;
+        c.cc = (4. + 0. * c.mueff / n) / (n + 4. + 0. * 2. * c.mueff / n);
+        c.cs = (c.mueff + 2.) / (3. + n + c.mueff);
+        c.c1 = ac * std::min(1., lambda / 6.) / ((n + 1.3) * (n + 1.3) + c.mueff);
+        c.cmu = 1. - c.c1;
+        c.cmu = std::min(c.cmu,
+                ac * (c.mueff - 2. + 1. / c.mueff) / ((2. + n) * (2. + n) + ac * c.mueff / 2.));
+        c.cneg = (1. - c.cmu) * (ac / 8.) * c.mueff / (std::pow(n + 2., 1.5) + 2. * c.mueff);
+        c.damps = 1. + c.cs + 2. * std::max(0., std::sqrt((c.mueff - 1.) / (n + 1.)) - 1.);
+        c.eigenfreq = params_.eigenrate * (1. / (c.c1 + c.cmu + c.cneg)) / n;
+    }
+
+    // Gram split-K geometry
+    c.rps = 64;
+    c.splits = (c.lambda_pad + c.rps - 1) / c.rps;
+
+    // ---- HBM state ------------------------------------------------------------
+    const size_t ld = c.ld, ld2 = ld * ld;
+    const bool same_shape = keep_bc_ && last_n_ == n && C_.count == P * ld2;
+    X_.alloc((size_t) P * c.lambda_pad * ld);
+    f_.alloc((size_t) P * c.lambda_pad);
+    rank_.alloc((size_t) P * c.lambda_pad);
+    order_.alloc((size_t) P * c.lambda_pad);
+    xmean_.alloc(P * ld);
+    xold_.alloc(P * ld);
+    pc_.alloc(P * ld);
+    ps_.alloc(P * ld);
+    D_.alloc(P * ld);
+    isc_.alloc(P * ld2);
+    BDp_.alloc(P * ld2);
+    ISp_.alloc(P * ld2);
+    S_.alloc((size_t) P * c.mu_pad);
+    gram_part_.alloc((size_t) P * c.splits * ld2);
+    mean_part_.alloc((size_t) P * c.splits * ld);
+    hist_best_.alloc((size_t) P * c.hlen);
+    hist_kth_.alloc((size_t) P * c.hlen);
+    weights_.alloc(c.mu);
+    weights_.upload(w.data(), c.mu);
+    lower_.alloc(ld);
+    upper_.alloc(ld);
+    aux_.alloc(ld);
+    scal_.alloc(P);
+    zinject_.release();
+    zrecord_.release();
+
+    lower_h_.assign(ld, 0.);
+    upper_h_.assign(ld, 0.);
+    aux_h_.assign(ld, 0.);
+    std::copy(lower, lower + n, lower_h_.begin());
+    std::copy(upper, upper + n, upper_h_.begin());
+    fill_objective_aux(obj.on_device() ? obj.builtin : -1, n, aux_h_.data());
+    lower_.upload(lower_h_.data(), ld);
+    upper_.upload(upper_h_.data(), ld);
+    aux_.upload(aux_h_.data(), ld);
+
+    // B = C = C^-1/2 = I, D = 1.  The reference resize()s _b/_c, so on a re-init of the
+    // SAME object with the same n the old off-diagonals survive and only the diagonals are
+    // reset (cmaes.cpp:53-59); restart drivers depend on that, so it is kept.
+    std::vector<double> eye(P * ld2, 0.), ones(P * ld, 1.);
+    for (int p = 0; p < P; p++)
+        for (int i = 0; i < n; i++) eye[p * ld2 + (size_t) i * ld + i] = 1.;
+    if (same_shape) {
+        std::vector<double> bm(P * ld2), cm(P * ld2);
+        B_.download(bm.data(), P * ld2);
+        C_.download(cm.data(), P * ld2);
+        for (int p = 0; p < P; p++)
+            for (int i = 0; i < n; i++) {
+                bm[p * ld2 + (size_t) i * ld + i] = 1.;
+                cm[p * ld2 + (size_t) i * ld + i] = 1.;
+            }
+        B_.upload(bm.data(), P * ld2);
+        C_.upload(cm.data(), P * ld2);
+    } else {
+        B_.alloc(P * ld2);
+        C_.alloc(P * ld2);
+        B_.upload(eye.data(), P * ld2);
+        C_.upload(eye.data(), P * ld2);
+    }
+    isc_.upload(eye.data(), P * ld2);
+    D_.upload(ones.data(), P * ld);
+    keep_bc_ = true;
+    last_n_ = n;
+
+    std::vector<double> xm(P * ld, 0.);
+    for (int p = 0; p < P; p++) std::copy(guess + (size_t) p * n, guess + (size_t) (p + 1) * n,
+            xm.begin() + p * ld);
+    xmean_.upload(xm.data(), P * ld);
+
+    std::vector<CmaScal> sc(P);
+    for (auto &s : sc) {
+        std::memset(&s, 0, sizeof(s));
+        s.sigma = params_.sigma0;
+        s.fbest = -std::numeric_limits<double>::infinity();
+        s.fworst = std::numeric_limits<double>::infinity();
+        s.hist_head = -1;
+    }
+    scal_.upload(sc.data(), P);
+
+    // the eigensolver keeps its matrix in LDS when it fits
+    const int lda = n | 1;
+    const size_t eig_lds = (size_t) (4 * EIG_NMAX + 1024 + (size_t) n * lda) * sizeof(double);
+    if (eig_lds > 160 * 1024 - 256) eig_work_.alloc((size_t) P * ld * (ld + 1));
+    else eig_work_.release();
+
+    CmaDev &d = d_;
+    d = CmaDev {};
+    d.X = X_.p; d.f = f_.p; d.rank = rank_.p; d.order = order_.p;
+    d.xmean = xmean_.p; d.xold = xold_.p; d.pc = pc_.p; d.ps = ps_.p;
+    d.C = C_.p; d.B = B_.p; d.D = D_.p; d.isc = isc_.p; d.BDp = BDp_.p; d.ISp = ISp_.p;
+    d.S = S_.p; d.gram_part = gram_part_.p; d.mean_part = mean_part_.p;
+    d.hist_best = hist_best_.p; d.hist_kth = hist_kth_.p; d.eig_work = eig_work_.p;
+    d.weights = weights_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
+    d.zinject = nullptr; d.zrecord = nullptr; d.scal = scal_.p;
+
+    // packed operands of the initial B, D, C^-1/2
+    c.honor_stop = 0;
+    inited_ = true;
+    {
+        dim3 grid(c.ld / 16, c.ld / 16, P);
+        hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 2);
+        BBO_HIP(hipGetLastError());
+        BBO_HIP(hipStreamSynchronize(stream_));
+    }
+}
+
+// ---- kernel launches ---------------------------------------------------------------
+void CmaEngine::launch_sample_eval()
+{
+    const CmaConst &c = c_;
+    dim3 grid(c.lambda_pad / 16, c.npop);
+    const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
+    switch (pick_maxt(c.ld)) {
+    case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
+    case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;
+    case 4: hipLaunchKernelGGL(cma_sample_eval<4>, grid, dim3(256), lds, stream_, d_, c_); break;
+    default: hipLaunchKernelGGL(cma_sample_eval<8>, grid, dim3(256), lds, stream_, d_, c_); break;
+    }
+    BBO_HIP(hipGetLastError());
+}
+
+void CmaEngine::launch_rank()
+{
+    const CmaConst &c = c_;
+    dim3 grid((c.lambda + 31) / 32, c.npop);
+    hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
+    BBO_HIP(hipGetLastError());
+}
+
+void CmaEngine::launch_update()
+{
+    const CmaConst &c = c_;
+    if (c.variant == 1) {
+        dim3 grid(c.mu_pad / 16, c.npop);
+        const size_t lds = (size_t) (16 * (c.ld + 2) + 64) * sizeof(double);
+        switch (pick_maxt(c.ld)) {
+        case 1: hipLaunchKernelGGL(cma_whiten<1>, grid, dim3(256), lds, stream_, d_, c_); break;
+        case 2: hipLaunchKernelGGL(cma_whiten<2>, grid, dim3(256), lds, stream_, d_, c_); break;
+        case 4: hipLaunchKernelGGL(cma_whiten<4>, grid, dim3(256), lds, stream_, d_, c_); break;
+        default: hipLaunchKernelGGL(cma_whiten<8>, grid, dim3(256), lds, stream_, d_, c_); break;
+        }
+        BBO_HIP(hipGetLastError());
+    }
+    {
+        const int NT = c.ld / 16, LT = NT * (NT + 1) / 2;
+        const int ldy = gram_ldy(c.ld);
+        dim3 grid(c.splits, (LT + 31) / 32, c.npop);
+        const size_t lds = (size_t) (c.rps * ldy + 2 * c.rps) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_gram,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(cma_gram, grid, dim3(256), lds, stream_, d_, c_, ldy);
+        BBO_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(cma_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
+    BBO_HIP(hipGetLastError());
+    {
+        const int total = c.n * (c.n + 1) / 2;
+        dim3 grid((total + 255) / 256, c.npop);
+        hipLaunchKernelGGL(cma_cov, grid, dim3(256), 0, stream_, d_, c_);
+        BBO_HIP(hipGetLastError());
+    }
+}
+
+void CmaEngine::launch_eigen()
+{
+    const CmaConst &c = c_;
+    const int lda_lds = c.n | 1;
+    const size_t base = (size_t) (4 * EIG_NMAX + 1024) * sizeof(double);
+    const size_t with_mat = base + (size_t) c.n * lda_lds * sizeof(double);
+    const bool use_lds = with_mat <= 160 * 1024 - 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        BBO_HIP(hipFuncSetAttribute((const void*) cma_eigen,
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), use_lds ? with_mat : base,
+            stream_, d_, c_, use_lds ? 1 : 0, use_lds ? lda_lds : c.ld + 1, 0);
+    BBO_HIP(hipGetLastError());
+    dim3 grid(c.ld / 16, c.ld / 16, c.npop);
+    hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 0);
+    BBO_HIP(hipGetLastError());
+}
+
+void CmaEngine::launch_history_stop()
+{
+    hipLaunchKernelGGL(cma_history_stop, dim3(c_.npop), dim3(64), 0, stream_, d_, c_);
+    BBO_HIP(hipGetLastError());
+}
+
+// the compatibility path for arbitrary host objectives: X leaves HBM once per generation
+void CmaEngine::host_evaluate()
+{
+    const CmaConst &c = c_;
+    const size_t rows = (size_t) c.npop * c.lambda_pad;
+    std::vector<double> xh(rows * c.ld), fh(rows, std::numeric_limits<double>::infinity());
+    BBO_HIP(hipStreamSynchronize(stream_));
+    X_.download(xh.data(), xh.size());
+    std::vector<CmaScal> sc;
+    fetch_scal(sc);
+    for (int p = 0; p < c.npop; p++) {
+        if (c.honor_stop && sc[p].stop) continue;
+        const size_t r0 = (size_t) p * c.lambda_pad;
+        obj_.eval_host(xh.data() + r0 * c.ld, c.lambda, c.n, c.ld, fh.data() + r0);
+        for (int r = 0; r < c.lambda; r++)
+            if (fh[r0 + r] != fh[r0 + r]) fh[r0 + r] = std::numeric_limits<double>::infinity();
+    }
+    f_.upload(fh.data(), rows);
+}
+
+void CmaEngine::generation(bool honor_stop)
+{
+    c_.honor_stop = honor_stop ? 1 : 0;
+    launch_sample_eval();
+    if (!obj_.on_device()) host_evaluate();
+    launch_rank();
+    launch_update();
+    launch_eigen();
+    launch_history_stop();
+}
+
+void CmaEngine::phase(int which)
+{
+    BBO_REQUIRE(inited_, "phase before init");
+    BBO_HIP(hipSetDevice(params_.device));
+    c_.honor_stop = 0;
+    switch (which) {
+    case BBO_PHASE_SAMPLE_EVALUATE:
+        launch_sample_eval();
+        if (!obj_.on_device()) host_evaluate();
+        break;
+    case BBO_PHASE_RANK: launch_rank(); break;
+    case BBO_PHASE_UPDATE: launch_update(); break;
+    case BBO_PHASE_EIGEN: launch_eigen(); break;
+    case BBO_PHASE_HISTORY_STOP: launch_history_stop(); break;
+    default: throw Error(BBO_ERR_ARG, "unknown CMA phase");
+    }
+    BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+void CmaEngine::inject_normals(const double *z, int count)
+{
+    BBO_REQUIRE(inited_, "inject_normals before init");
+    if (!z) {
+        d_.zinject = nullptr;
+        return;
+    }
+    const size_t want = (size_t) c_.npop * c_.lambda * c_.n;
+    BBO_REQUIRE((size_t) count == want, "inject_normals: count must be populations*lambda*n");
+    if (zinject_.count != want) zinject_.alloc(want);
+    zinject_.upload(z, want);
+    d_.zinject = zinject_.p;
+}
+
+void CmaEngine::iterate()
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "iterate() before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    generation(false);
+    BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+void CmaEngine::fetch_scal(std::vector<CmaScal> &out)
+{
+    out.resize(c_.npop);
+    scal_.download(out.data(), c_.npop);
+}
+
+bool CmaEngine::all_stopped()
+{
+    std::vector<CmaScal> sc;
+    fetch_scal(sc);
+    for (const auto &s : sc)
+        if (!s.stop) return false;
+    return true;
+}
+
+int CmaEngine::run(int max_generations)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "run() before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    const int poll = params_.poll_every > 0 ? params_.poll_every : 8;
+    int done = 0;
+    // a population whose budget is already spent must not take another generation
+    // (the reference's loop is `while (_fev < _mfev)`, base_cmaes.cpp:166)
+    {
+        std::vector<CmaScal> sc;
+        fetch_scal(sc);
+        bool touched = false;
+        for (auto &s : sc)
+            if (!s.stop && s.fev >= c_.mfev) {
+                s.stop = 2;
+                touched = true;
+            }
+        if (touched) scal_.upload(sc.data(), c_.npop);
+    }
+    while (done < max_generations) {
+        if (all_stopped()) break;
+        const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
+        for (int g = 0; g < chunk; g++) generation(true);
+        BBO_HIP(hipStreamSynchronize(stream_));
+        done += chunk;
+    }
+    return done;
+}
+
+void CmaEngine::solution(int population, double *x_out, int *n_evals, int *converged)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "solution() before initialize()");
+    BBO_REQUIRE(population >= 0 && population < c_.npop, "population index out of range");
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    CmaScal s;
+    scal_.download(&s, 1, population);
+    std::vector<double> x(c_.ld);
+    // bestSolution(), base_cmaes.cpp:232-238: the mean before the first generation, else
+    // the best candidate of the LAST generation
+    if (s.it <= 0) xmean_.download(x.data(), c_.ld, (size_t) population * c_.ld);
+    else X_.download(x.data(), c_.ld, ((size_t) population * c_.lambda_pad + s.ibw[0]) * c_.ld);
+    std::copy(x.begin(), x.begin() + c_.n, x_out);
+    *n_evals = s.fev;
+    // solution() re-runs converged() (base_cmaes.cpp:158-160); before any generation the
+    // tests see it = 0 and the initial state
+    if (s.it <= 0) {
+        *converged = (0 >= c_.mit) ? 1 : 0;
+    } else {
+        *converged = s.flag != 0 ? 1 : 0;
+    }
+}
+
+void CmaEngine::optimize(int n, const double *lower, const double *upper, const double *guess,
+        const ObjectiveSpec &obj, double *x_out, int *n_evals, int *converged)
+{
+    init(n, lower, upper, guess, obj);
+    // while (_fev < _mfev) { iterate(); if (converged()) break; }   base_cmaes.cpp:166-172
+    const int max_gen = c_.mfev / c_.lambda + 2;
+    run(max_gen);
+    CmaScal s;
+    scal_.download(&s, 1, 0);
+    std::vector<double> x(c_.ld);
+    if (s.it <= 0) xmean_.download(x.data(), c_.ld, 0);
+    else X_.download(x.data(), c_.ld, (size_t) s.ibw[0] * c_.ld);
+    std::copy(x.begin(), x.begin() + c_.n, x_out);
+    *n_evals = s.fev;
+    *converged = (s.stop == 1) ? 1 : 0;
+}
+
+double CmaEngine::evaluate_point(const double *x)
+{
+    if (!obj_.on_device()) {
+        double f = 0.;
+        obj_.eval_host(x, 1, c_.n, c_.n, &f);
+        return f;
+    }
+    // restart drivers re-evaluate one point per restart (bipop_cmaes.cpp:86): host
+    // arithmetic with the same definition and the same per-coordinate table
+    const int obj = obj_.builtin, n = c_.n;
+    const double *aux = aux_h_.data();
+    double s = 0.;
+    switch (obj) {
+    case BBO_OBJ_SPHERE:
+        for (int i = 0; i < n; i++) s += x[i] * x[i];
+        return s;
+    case BBO_OBJ_ROSENBROCK:
+        for (int i = 0; i + 1 < n; i++) {
+            const double a = x[i + 1] - x[i] * x[i], b = 1. - x[i];
+            s += 100. * (a * a) + b * b;
+        }
+        return s;
+    case BBO_OBJ_RASTRIGIN:
+        for (int i = 0; i < n; i++) s += x[i] * x[i] - 10. * std::cos(TWO_PI * x[i]);
+        return 10. * n + s;
+    case BBO_OBJ_ELLIPSOID:
+        for (int i = 0; i < n; i++) s += aux[i] * (x[i] * x[i]);
+        return s;
+    case BBO_OBJ_ACKLEY: {
+        double cs = 0.;
+        for (int i = 0; i < n; i++) {
+            s += x[i] * x[i];
+            cs += std::cos(TWO_PI * x[i]);
+        }
+        return -20. * std::exp(-0.2 * std::sqrt(s / n)) - std::exp(cs / n) + 20. + EULER_E;
+    }
+    case BBO_OBJ_GRIEWANK: {
+        double pr = 1.;
+        for (int i = 0; i < n; i++) {
+            s += x[i] * x[i];
+            pr *= std::cos(x[i] * aux[i]);
+        }
+        return 1. + s / 4000. - pr;
+    }
+    case BBO_OBJ_CIGAR:
+        for (int i = 1; i < n; i++) s += x[i] * x[i];
+        return x[0] * x[0] + 1.0e6 * s;
+    case BBO_OBJ_DISCUS:
+        for (int i = 1; i < n; i++) s += x[i] * x[i];
+        return 1.0e6 * (x[0] * x[0]) + s;
+    case BBO_OBJ_DIFFPOW:
+        for (int i = 0; i < n; i++) s += std::pow(std::fabs(x[i]), aux[i]);
+        return s;
+    case BBO_OBJ_SCHWEFEL12: {
+        double run = 0.;
+        for (int i = 0; i < n; i++) {
+            run += x[i];
+            s += run * run;
+        }
+        return s;
+    }
+    default:
+        throw Error(BBO_ERR_ARG, "unknown builtin objective");
+    }
+}
+
+// ---- named state access ---------------------------------------------------------------
+int CmaEngine::get(const std::string &k, int p, double *out, int cap)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "get() before initialize()");
+    BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    const CmaConst &c = c_;
+    const size_t ld = c.ld, n = c.n;
+    auto vec = [&](const DevBuf<double> &b) {   // [P][ld] -> n
+        if (out && cap >= (int) n) b.download(out, n, p * ld);
+        return (int) n;
+    };
+    auto mat = [&](const DevBuf<double> &b, size_t rows, size_t rstride, size_t cols,
+            size_t base) {
+        if (out && cap >= (int) (rows * cols)) {
+            std::vector<double> tmp(rows * rstride);
+            b.download(tmp.data(), rows * rstride, base);
+            for (size_t i = 0; i < rows; i++)
+                std::copy(tmp.begin() + i * rstride, tmp.begin() + i * rstride + cols,
+                        out + i * cols);
+        }
+        return (int) (rows * cols);
+    };
+    auto one = [&](double v) {
+        if (out && cap >= 1) out[0] = v;
+        return 1;
+    };
+    if (k == "xmean") return vec(xmean_);
+    if (k == "xold") return vec(xold_);
+    if (k == "pc") return vec(pc_);
+    if (k == "ps") return vec(ps_);
+    if (k == "D") return vec(D_);
+    if (k == "B") return mat(B_, n, ld, n, p * ld * ld);
+    if (k == "C") return mat(C_, n, ld, n, p * ld * ld);
+    if (k == "invsqrtC") return mat(isc_, n, ld, n, p * ld * ld);
+    if (k == "arx") return mat(X_, c.lambda, ld, n, (size_t) p * c.lambda_pad * ld);
+    if (k == "weights") {
+        if (out && cap >= c.mu) weights_.download(out, c.mu);
+        return c.mu;
+    }
+    if (k == "fitness") {
+        if (out && cap >= c.lambda) f_.download(out, c.lambda, (size_t) p * c.lambda_pad);
+        return c.lambda;
+    }
+    if (k == "fit_idx" || k == "fit_val" || k == "rank") {
+        if (out && cap >= c.lambda) {
+            std::vector<int> ord(c.lambda);
+            (k == "rank" ? rank_ : order_).download(ord.data(), c.lambda,
+                    (size_t) p * c.lambda_pad);
+            if (k == "fit_val") {
+                std::vector<double> f(c.lambda);
+                f_.download(f.data(), c.lambda, (size_t) p * c.lambda_pad);
+                for (int i = 0; i < c.lambda; i++) out[i] = f[ord[i]];
+            } else {
+                for (int i = 0; i < c.lambda; i++) out[i] = ord[i];
+            }
+        }
+        return c.lambda;
+    }
+    if (k == "ycoeff") {
+        if (out && cap >= c.mu) {
+            std::vector<double> S(c.mu_pad);
+            S_.download(S.data(), c.mu_pad, (size_t) p * c.mu_pad);
+            for (int i = 0; i < c.mu; i++) out[i] = S[i] / std::max(S[c.mu - 1 - i], 1e-8);
+        }
+        return c.mu;
+    }
+    if (k == "zlast") {
+        const size_t cnt = (size_t) c.lambda * n;
+        if (!zrecord_.p) return 0;
+        if (out && cap >= (int) cnt) zrecord_.download(out, cnt, p * cnt);
+        return (int) cnt;
+    }
+    if (k == "best_hist" || k == "kth_hist") {
+        if (out && cap >= c.hlen)
+            (k == "best_hist" ? hist_best_ : hist_kth_).download(out, c.hlen, (size_t) p * c.hlen);
+        return c.hlen;
+    }
+    CmaScal s;
+    scal_.download(&s, 1, p);
+    if (k == "sigma") return one(s.sigma);
+    if (k == "it") return one(s.it);
+    if (k == "fev") return one(s.fev);
+    if (k == "flag") return one(s.flag);
+    if (k == "stop") return one(s.stop);
+    if (k == "hsig") return one(s.hsig);
+    if (k == "pslen") return one(s.pslen);
+    if (k == "fbest") return one(s.fbest);
+    if (k == "fworst") return one(s.fworst);
+    if (k == "eigenlastev") return one(s.eigenlastev);
+    if (k == "eigen_done") return one(s.eigen_done);
+    if (k == "best_len") return one(s.hist_len);
+    if (k == "best_buffer") return one(s.hist_head);
+    if (k == "ibest") return one(s.ibw[0]);
+    if (k == "n") return one(c.n);
+    if (k == "lambda") return one(c.lambda);
+    if (k == "mu") return one(c.mu);
+    if (k == "mueff") return one(c.mueff);
+    if (k == "cc") return one(c.cc);
+    if (k == "cs") return one(c.cs);
+    if (k == "c1") return one(c.c1);
+    if (k == "cmu") return one(c.cmu);
+    if (k == "cneg") return one(c.cneg);
+    if (k == "alphaold") return one(c.alphaold);
+    if (k == "cm") return one(c.cm);
+    if (k == "damps") return one(c.damps);
+    if (k == "chi") return one(c.chi);
+    if (k == "eigenfreq") return one(c.eigenfreq);
+    if (k == "hlen") return one(c.hlen);
+    if (k == "ik") return one(c.ik);
+    if (k == "mit") return one(c.mit);
+    if (k == "mfev") return one(c.mfev);
+    if (k == "sigma0") return one(c.sigma0);
+    throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
+}
+
+int CmaEngine::set(const std::string &k, int p, const double *in, int count)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "set() before initialize()");
+    BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    const CmaConst &c = c_;
+    const size_t ld = c.ld, n = c.n;
+    auto vec = [&](DevBuf<double> &b) {
+        BBO_REQUIRE(count == (int) n, "set: wrong element count");
+        std::vector<double> tmp(ld, 0.);
+        std::copy(in, in + n, tmp.begin());
+        b.upload(tmp.data(), ld, p * ld);
+        return count;
+    };
+    auto mat = [&](DevBuf<double> &b) {
+        BBO_REQUIRE(count == (int) (n * n), "set: wrong element count");
+        std::vector<double> tmp(ld * ld, 0.);
+        for (size_t i = 0; i < n; i++) std::copy(in + i * n, in + (i + 1) * n, tmp.begin() + i * ld);
+        b.upload(tmp.data(), ld * ld, p * ld * ld);
+        return count;
+    };
+    if (k == "xmean") return vec(xmean_);
+    if (k == "xold") return vec(xold_);
+    if (k == "pc") return vec(pc_);
+    if (k == "ps") return vec(ps_);
+    if (k == "C") return mat(C_);
+    if (k == "invsqrtC") throw Error(BBO_ERR_KEY, "invsqrtC is derived from B and D: set those");
+    if (k == "B" || k == "D") {
+        int r;
+        if (k == "D") {
+            BBO_REQUIRE(count == (int) n, "set: wrong element count");
+            std::vector<double> tmp(ld, 1.);
+            std::copy(in, in + n, tmp.begin());
+            D_.upload(tmp.data(), ld, p * ld);
+            r = count;
+        } else {
+            r = mat(B_);
+        }
+        // refresh C^-1/2 and the packed MFMA operands
+        c_.honor_stop = 0;
+        dim3 grid(c.ld / 16, c.ld / 16, c.npop);
+        hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 1);
+        BBO_HIP(hipGetLastError());
+        BBO_HIP(hipStreamSynchronize(stream_));
+        return r;
+    }
+    if (k == "record_normals") {
+        BBO_REQUIRE(count == 1, "set: wrong element count");
+        if (in[0] != 0.) {
+            const size_t want = (size_t) c.npop * c.lambda * n;
+            if (zrecord_.count != want) zrecord_.alloc(want);
+            d_.zrecord = zrecord_.p;
+        } else {
+            d_.zrecord = nullptr;
+        }
+        return 1;
+    }
+    BBO_REQUIRE(count == 1, "set: wrong element count");
+    CmaScal s;
+    scal_.download(&s, 1, p);
+    if (k == "sigma") s.sigma = in[0];
+    else if (k == "it") s.it = (int) in[0];
+    else if (k == "fev") s.fev = (int) in[0];
+    else if (k == "eigenlastev") s.eigenlastev = (int) in[0];
+    else if (k == "fbest") s.fbest = in[0];
+    else if (k == "fworst") s.fworst = in[0];
+    else if (k == "stop") s.stop = (int) in[0];
+    else throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
+    scal_.upload(&s, 1, p);
+    return 1;
+}
+
+} // namespace bbo

@@ -1,0 +1,912 @@
+// bbo_cma_kernels.hpp -- the CMA-ES generation as hand-written gfx950 kernels.
+//
+//   kernel                 reference lines it replaces                    bound
+//   cma_sample_eval        cmaes.cpp:65-80 + base_cmaes.cpp:214-217        fp64 MFMA (2 n^2 flop/cand)
+//   cma_rank               std::sort in base_cmaes.cpp:221                 L2 / VALU (lambda^2 compares)
+//   cma_whiten             active_cmaes.cpp:115-132 (ycoeff norms)         fp64 MFMA (2 n^2 flop/cand, worst mu)
+//   cma_gram               active_cmaes.cpp:135-161 rank-mu +/- terms,     fp64 MFMA (2 n^2 flop/cand)
+//                          and the weighted mean :75-85
+//   cma_paths              active_cmaes.cpp:75-112 + base_cmaes.cpp:176-189 latency (1 workgroup)
+//   cma_cov                active_cmaes.cpp:137-160 (assembly of C)        HBM/L2 (slab reduce)
+//   cma_eigen              cmaes.cpp:229-478 (tred2 + tql2 + repair)       serial latency (1 workgroup)
+//   cma_post               cmaes.cpp:274-282 (C^-1/2) + operand packing    L2
+//   cma_history_stop       base_cmaes.cpp:191-209, cmaes.cpp:151-227       latency
+//
+// All arithmetic is fp64.  MFMA is v_mfma_f64_16x16x4_f64: A fragment = one double
+// per lane, A[row = lane & 15][k = lane >> 4]; B fragment B[k = lane >> 4][col = lane & 15];
+// C/D = 4 doubles per lane, col = lane & 15, row = (lane >> 4) + 4 * reg.
+#pragma once
+
+#include "bbo_cma.hpp"
+#include "bbo_objectives.hpp"
+#include "bbo_rng.hpp"
+
+namespace bbo {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+#define BBO_INF (__builtin_huge_val())
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline bool pop_frozen(const CmaConst &c, const CmaScal *sc)
+{
+    return c.honor_stop && sc->stop != 0;
+}
+
+// ---------------------------------------------------------------------------
+// sample + evaluate: X = m + sigma * Z (B diag D)^T, f = objective(X)
+// grid (lambda_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles
+// ---------------------------------------------------------------------------
+template<int MAXT>
+__global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y, mt = blockIdx.x;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = c.ld, ldz = ld + 2;
+    const int gen = sc->it;
+
+    // 1. the standard normals of these 16 candidates (Box-Muller pairs)
+    const int npairs = ld >> 1;
+    for (int q = tid; q < 16 * npairs; q += 256) {
+        const int r = q / npairs, pj = q - r * npairs;
+        const int row = mt * 16 + r, j = 2 * pj;
+        double z0 = 0., z1 = 0.;
+        if (row < c.lambda && j < c.n) {
+            if (d.zinject) {
+                const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
+                z0 = zi[j];
+                z1 = (j + 1 < c.n) ? zi[j + 1] : 0.;
+            } else {
+                normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
+                        stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
+                if (j + 1 >= c.n) z1 = 0.;
+            }
+            if (d.zrecord) {
+                double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
+                zr[j] = z0;
+                if (j + 1 < c.n) zr[j + 1] = z1;
+            }
+        }
+        lds[r * ldz + j] = z0;
+        lds[r * ldz + j + 1] = z1;
+    }
+    __syncthreads();
+
+    // 2. 16 x ld tile of Z (B D)^T on the matrix cores; wave w owns column tiles w, w+4, ...
+    d4_t acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+    const int NT = ld >> 4, KS = ld >> 2;
+    const double *bdp = d.BDp + (size_t) p * ld * ld;
+    const int ar = lane & 15, ak = lane >> 4;
+    for (int ks = 0; ks < KS; ks++) {
+        const double a = lds[ar * ldz + 4 * ks + ak];
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) {
+            const int nt = wave + 4 * t;
+            if (nt < NT) {
+                const double b = bdp[((size_t) nt * KS + ks) * 64 + lane];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3. x = m + sigma * y (clipped to the box when bound), to HBM and to LDS
+    const double sigma = sc->sigma;
+    const double *xm = d.xmean + (size_t) p * ld;
+    double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int nt = wave + 4 * t;
+        if (nt < NT) {
+            const int col = nt * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rl = (lane >> 4) + 4 * r;
+                double v = 0.;
+                if (col < c.n) {
+                    v = xm[col] + sigma * acc[t][r];
+                    if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+                }
+                lds[rl * ldz + col] = v;
+                Xp[((size_t) mt * 16 + rl) * ld + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // 4. objective: 16 lanes per candidate
+    if (c.obj >= 0) {
+        const int r = tid >> 4, g = tid & 15;
+        double f = eval_row_group<16>(c.obj, c.n, &lds[r * ldz], d.aux, g);
+        if (g == 0) {
+            const int row = mt * 16 + r;
+            if (!(row < c.lambda) || f != f) f = BBO_INF;   // padding rows; NaN -> +inf
+            d.f[(size_t) p * c.lambda_pad + row] = f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// rank: rank[i] = #{ j : f_j < f_i  or (f_j == f_i and j < i) }, order[rank[i]] = i
+// grid (ceil(lambda/32), P), 256 threads = 32 candidates x 8 slices of the population
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    const int tid = threadIdx.x;
+    const int cand = blockIdx.x * 32 + (tid >> 3), slice = tid & 7;
+    const double *f = d.f + (size_t) p * c.lambda_pad;
+    const bool live = cand < c.lambda;
+    const double fi = live ? f[cand] : BBO_INF;
+    int cnt = 0;
+    for (int j = slice; j < c.lambda; j += 8) {
+        const double fj = f[j];
+        cnt += (fj < fi) || (fj == fi && j < cand);
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 8);
+    if (live && slice == 0) {
+        d.rank[(size_t) p * c.lambda_pad + cand] = cnt;
+        d.order[(size_t) p * c.lambda_pad + cnt] = cand;
+        if (cnt == 0) { sc->ibw[0] = cand; sc->ybw[0] = fi; }
+        if (cnt == 1) { sc->ibw[1] = cand; sc->ybw[1] = fi; }
+        if (cnt == c.lambda - 2) { sc->ibw[2] = cand; sc->ybw[2] = fi; }
+        if (cnt == c.lambda - 1) { sc->ibw[3] = cand; sc->ybw[3] = fi; }
+    }
+    if (blockIdx.x == 0 && tid == 0) sc->fev += c.lambda;   // base_cmaes.cpp:218
+}
+
+// ---------------------------------------------------------------------------
+// whiten: S[r] = || C^-1/2 (x_{(lambda-mu+r):lambda} - xold) ||^2 for the worst mu
+// grid (mu_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles + 64
+// ---------------------------------------------------------------------------
+template<int MAXT>
+__global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y, mt = blockIdx.x;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = c.ld, ldz = ld + 2;
+    double *part = lds + 16 * ldz;   // [4][16]
+    const double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+    const double *xold = d.xmean + (size_t) p * ld;   // the mean has not moved yet
+    const int *order = d.order + (size_t) p * c.lambda_pad;
+
+    for (int q = tid; q < 16 * ld; q += 256) {
+        const int r = q / ld, j = q - r * ld;
+        const int wr = mt * 16 + r;
+        double v = 0.;
+        if (wr < c.mu && j < c.n) {
+            const int cand = order[c.lambda - c.mu + wr];
+            v = Xp[(size_t) cand * ld + j] - xold[j];
+        }
+        lds[r * ldz + j] = v;
+    }
+    __syncthreads();
+
+    d4_t acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+    const int NT = ld >> 4, KS = ld >> 2;
+    const double *isp = d.ISp + (size_t) p * ld * ld;
+    const int ar = lane & 15, ak = lane >> 4;
+    for (int ks = 0; ks < KS; ks++) {
+        const double a = lds[ar * ldz + 4 * ks + ak];
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) {
+            const int nt = wave + 4 * t;
+            if (nt < NT) {
+                const double b = isp[((size_t) nt * KS + ks) * 64 + lane];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // row sums of squares: lane holds rows (lane>>4)+4r, one column per tile
+    double ss[4] = { 0., 0., 0., 0. };
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (wave + 4 * t < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) ss[r] += acc[t][r] * acc[t][r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) ss[r] += __shfl_xor(ss[r], off, 16);
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[wave * 16 + (lane >> 4) + 4 * r] = ss[r];
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int wr = mt * 16 + tid;
+        if (wr < c.mu_pad)
+            d.S[(size_t) p * c.mu_pad + wr] = part[tid] + part[16 + tid] + part[32 + tid]
+                    + part[48 + tid];
+    }
+}
+
+// the rank-mu (+) / active (-) coefficient of the candidate with this rank
+// (active_cmaes.cpp:136,150,158; cmaes.cpp:137), and its recombination weight
+__device__ inline void rank_coefficients(const CmaDev &d, const CmaConst &c, int p, int rank,
+        double &wmean, double &vgram)
+{
+    wmean = 0.;
+    vgram = 0.;
+    if (rank < c.mu) {
+        wmean = d.weights[rank];
+        const double cmu1 = c.variant == 1 ? c.cmu + c.cneg * (1. - c.alphaold) : c.cmu;
+        vgram = cmu1 * d.weights[rank];
+    } else if (c.variant == 1 && rank >= c.lambda - c.mu) {
+        const int k = c.lambda - 1 - rank;
+        const double *S = d.S + (size_t) p * c.mu_pad;
+        const double ycoeff = S[k] / fmax(S[c.mu - 1 - k], 1e-8);
+        vgram = -c.cneg * d.weights[k] * ycoeff;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gram: slab s of  G = sum_k v_k y_k y_k^T  (lower 16x16 tiles) and of the weighted mean
+// grid (splits, tile_groups, P), 256 threads; dynamic LDS rps*ldy + rps doubles
+// ---------------------------------------------------------------------------
+__device__ inline void tri_tile(int q, int &ti, int &tj)
+{
+    ti = (int) ((sqrt(8. * q + 1.) - 1.) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+    while (ti * (ti + 1) / 2 > q) ti--;
+    tj = q - ti * (ti + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
+{
+    const int p = blockIdx.z, s = blockIdx.x, tg = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = c.ld, rps = c.rps;
+    double *Y = lds;                 // [rps][ldy]   y = (x - xold) / sigma
+    double *V = lds + rps * ldy;     // [rps]        gram coefficient of the row
+    double *W = V + rps;             // [rps]        recombination weight of the row
+    const double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+    const double *xold = d.xmean + (size_t) p * ld;
+    const int *rank = d.rank + (size_t) p * c.lambda_pad;
+    const double sigma = sc->sigma;
+    const int row0 = s * rps;
+
+    if (tid < rps) {
+        const int row = row0 + tid;
+        double wm = 0., vg = 0.;
+        if (row < c.lambda) rank_coefficients(d, c, p, rank[row], wm, vg);
+        V[tid] = vg;
+        W[tid] = wm;
+    }
+    __syncthreads();
+    // stage the slab; the same pass accumulates this slab's share of the mean
+    for (int col = tid; col < ld; col += 256) {
+        double msum = 0.;
+        const double xo = xold[col];
+        for (int r = 0; r < rps; r++) {
+            const int row = row0 + r;
+            double x = 0., y = 0.;
+            if (row < c.lambda && col < c.n) {
+                x = Xp[(size_t) row * ld + col];
+                y = (x - xo) / sigma;
+            }
+            Y[r * ldy + col] = y;
+            msum += W[r] * x;
+        }
+        if (tg == 0) d.mean_part[((size_t) p * c.splits + s) * ld + col] = msum;
+    }
+    __syncthreads();
+
+    const int NT = ld >> 4, LT = NT * (NT + 1) / 2;
+    d4_t acc[8];
+    int ti[8], tj[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        acc[t] = d4_t { 0., 0., 0., 0. };
+        const int q = tg * 32 + wave + 4 * t;
+        ti[t] = tj[t] = 0;
+        if (q < LT) tri_tile(q, ti[t], tj[t]);
+    }
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int ks = 0; ks < (rps >> 2); ks++) {
+        const int k = 4 * ks + fk;
+        const double vk = V[k];
+        const double *yk = Y + k * ldy;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int q = tg * 32 + wave + 4 * t;
+            if (q < LT) {
+                const double a = vk * yk[ti[t] * 16 + fr];
+                const double b = yk[tj[t] * 16 + fr];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    double *G = d.gram_part + ((size_t) p * c.splits + s) * ld * ld;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int q = tg * 32 + wave + 4 * t;
+        if (q < LT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = ti[t] * 16 + (lane >> 4) + 4 * r;
+                const int j = tj[t] * 16 + (lane & 15);
+                G[(size_t) i * ld + j] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.x;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    __shared__ double dm[512];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, ld = c.ld;
+    double *xmean = d.xmean + (size_t) p * ld, *xold = d.xold + (size_t) p * ld;
+    double *ps = d.ps + (size_t) p * ld, *pc = d.pc + (size_t) p * ld;
+    const double sigma = sc->sigma;
+
+    // weighted mean (active_cmaes.cpp:75-85 / cmaes.cpp:85-96)
+    for (int j = tid; j < ld; j += 256) {
+        double sum = 0.;
+        for (int s = 0; s < c.splits; s++)
+            sum += d.mean_part[((size_t) p * c.splits + s) * ld + j];
+        const double xo = xmean[j];
+        double xn = 0.;
+        if (j < c.n) {
+            xn = c.variant == 1 ? xo * (1. - c.cm) + sum * c.cm : sum;
+            if (c.bound) xn = fmax(d.lower[j], fmin(xn, d.upper[j]));
+        }
+        xold[j] = xo;
+        xmean[j] = xn;
+        dm[j] = xn - xo;
+    }
+    __syncthreads();
+
+    // ps (active_cmaes.cpp:88-95); C^-1/2 is symmetric, so column reads are row reads
+    const double csc = sqrt(c.cs * (2. - c.cs) * c.mueff);
+    const double den = c.variant == 1 ? c.cm * sigma : sigma;
+    const double *isc = d.isc + (size_t) p * ld * ld;
+    double ssq = 0.;
+    for (int i = tid; i < ld; i += 256) {
+        double v = 0.;
+        if (i < c.n) {
+            double acc = 0.;
+            for (int j = 0; j < c.n; j++) acc += isc[(size_t) j * ld + i] * dm[j];
+            v = (1. - c.cs) * ps[i] + csc * acc / den;
+        }
+        ps[i] = v;
+        ssq += v * v;
+    }
+    ssq = wave_sum(ssq);
+    if ((tid & 63) == 0) red[tid >> 6] = ssq;
+    __syncthreads();
+    const double pslen = sqrt(red[0] + red[1] + red[2] + red[3]);
+
+    // hsig (active_cmaes.cpp:98-105); fev already counts this generation
+    const double denom = 1. - pow(1. - c.cs, 2. * sc->fev / c.lambda);
+    const int hsig = (pslen / sqrt(denom) / c.chi < 1.4 + 2. / (c.n + 1.)) ? 1 : 0;
+
+    // pc (active_cmaes.cpp:108-112)
+    const double ccc = sqrt(c.cc * (2. - c.cc) * c.mueff);
+    for (int i = tid; i < ld; i += 256) {
+        double v = 0.;
+        if (i < c.n) v = (1. - c.cc) * pc[i] + hsig * ccc * dm[i] / den;
+        pc[i] = v;
+    }
+
+    // sigma (base_cmaes.cpp:176-189); uses the history of the PREVIOUS generations
+    if (tid == 0) {
+        const double *f = d.f + (size_t) p * c.lambda_pad;
+        const int *order = d.order + (size_t) p * c.lambda_pad;
+        double sg = sigma * exp(fmin(1., (c.cs / c.damps) * (pslen / c.chi - 1.)));
+        if (f[order[0]] == f[order[c.ik]]) sg *= exp(0.2 + c.cs / c.damps);
+        if (sc->it >= c.hlen && sc->fworst - sc->fbest == 0.) sg *= exp(0.2 + c.cs / c.damps);
+        sc->sigma = sg;
+        sc->hsig = hsig;
+        sc->pslen = pslen;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cov: C <- decay * C + c1 (pc pc^T + c2 C) + sum of the Gram slabs   (lower half,
+// mirrored).  grid (ceil(n*(n+1)/2 / 256), P), 256 threads.
+// NB launched BEFORE cma_paths commits the new sigma? No: the slabs already hold
+// y = (x - xold)/sigma_old, and this kernel reads only pc and hsig.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_cov(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int total = c.n * (c.n + 1) / 2;
+    if (q >= total) return;
+    int i, j;
+    tri_tile(q, i, j);   // same triangular unranking, on elements
+    const int ld = c.ld;
+    double *C = d.C + (size_t) p * ld * ld;
+    const double *pc = d.pc + (size_t) p * ld;
+    const double cij = C[(size_t) i * ld + j];
+    const double c2 = (1. - sc->hsig) * c.cc * (2. - c.cc);
+    const double decay = c.variant == 1 ? (1. - c.c1 - c.cmu + c.cneg * c.alphaold)
+                                        : (1. - c.c1 - c.cmu);
+    double sum = decay * cij + c.c1 * (pc[i] * pc[j] + c2 * cij);
+    const double *G = d.gram_part + (size_t) p * c.splits * ld * ld + (size_t) i * ld + j;
+    double g = 0.;
+    for (int s = 0; s < c.splits; s++) g += G[(size_t) s * ld * ld];
+    sum += g;
+    C[(size_t) i * ld + j] = sum;
+    C[(size_t) j * ld + i] = sum;
+}
+
+// ---------------------------------------------------------------------------
+// eigen: C = B diag(D^2) B^T by Householder tridiagonalisation + implicit QL, the
+// algorithm of cmaes.cpp:285-478 with the same sign conventions, parallelised inside
+// one workgroup.  The matrix lives in LDS when it fits (n <= 128), else in HBM/L2.
+// ---------------------------------------------------------------------------
+struct EigMat {
+    double *a;
+    int ld;
+    __device__ double& operator()(int i, int j) const { return a[(size_t) i * ld + j]; }
+};
+
+constexpr int EIG_THREADS = 512;
+constexpr int EIG_NMAX = 512;
+
+// sum over k < len of fn(k), by wave 0 only (called with tid < 64)
+template<class F>
+__device__ inline double wave0_sum(int len, int lane, F fn)
+{
+    double s = 0.;
+    for (int k = lane; k < len; k += 64) s += fn(k);
+    return wave_sum(s);
+}
+
+__global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, int use_lds,
+        int lda, int force)
+{
+    const int p = blockIdx.x;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    // cmaes.cpp:233: skip until enough evaluations have passed
+    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
+        if (threadIdx.x == 0) sc->eigen_done = 0;
+        return;
+    }
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, T = EIG_THREADS, lane = tid & 63;
+    const int n = c.n, ld = c.ld;
+    double *dv = lds;               // d[n]: diagonal / eigenvalues
+    double *ev = dv + EIG_NMAX;     // e[n]: sub-diagonal
+    double *gv = ev + EIG_NMAX;     // g[n], also Givens cosines
+    double *hv = gv + EIG_NMAX;     // v[n], also Givens sines
+    double *part = hv + EIG_NMAX;   // [T/64][...] small scratch
+    __shared__ double sh_s[4];
+    __shared__ int sh_i[4];
+    EigMat A { use_lds ? part + 1024 : d.eig_work + (size_t) p * ld * lda, lda };
+    double *C = d.C + (size_t) p * ld * ld;
+
+    for (int q = tid; q < n * n; q += T) {
+        const int i = q / n, j = q - i * n;
+        A(i, j) = C[(size_t) i * ld + j];
+    }
+    for (int j = tid; j < n; j += T) dv[j] = C[(size_t) (n - 1) * ld + j];
+    __syncthreads();
+
+    // ---- Householder reduction (cmaes.cpp:293-356) -------------------------------
+    for (int i = n - 1; i > 0; i--) {
+        if (tid < 64) {
+            const double scale = wave0_sum(i, lane, [&](int k) { return fabs(dv[k]); });
+            if (scale == 0.) {
+                if (lane == 0) {
+                    ev[i] = dv[i - 1];
+                    sh_s[0] = 0.;   // h
+                    sh_i[0] = 1;    // degenerate step
+                }
+            } else {
+                for (int k = lane; k < i; k += 64) dv[k] /= scale;
+                const double h0 = wave0_sum(i, lane, [&](int k) { return dv[k] * dv[k]; });
+                if (lane == 0) {
+                    const double f = dv[i - 1];
+                    double g = sqrt(h0);
+                    if (f > 0) g = -g;
+                    ev[i] = scale * g;
+                    sh_s[0] = h0 - f * g;
+                    dv[i - 1] = f - g;
+                    sh_i[0] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        const double h = sh_s[0];
+        if (sh_i[0]) {
+            for (int j = tid; j < i; j += T) {
+                dv[j] = A(i - 1, j);
+                A(i, j) = 0.;
+                A(j, i) = 0.;
+            }
+            if (tid == 0) dv[i] = 0.;
+            __syncthreads();
+            continue;
+        }
+        // e = A d over the active block (kept symmetric in full), stash d in column i
+        {
+            const int TPR = 4;   // threads per row
+            for (int j = tid / TPR; j < i; j += T / TPR) {
+                const int q = tid % TPR;
+                double g = 0.;
+                for (int k = q; k < i; k += TPR) g += A(j, k) * dv[k];
+                g += __shfl_xor(g, 1, TPR);
+                g += __shfl_xor(g, 2, TPR);
+                if (q == 0) gv[j] = g;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int k = lane; k < i; k += 64) gv[k] *= 1. / h;
+            const double f = wave0_sum(i, lane, [&](int k) { return gv[k] * dv[k]; });
+            const double hh = f / (h + h);
+            for (int k = lane; k < i; k += 64) {
+                gv[k] = gv[k] - hh * dv[k];
+            }
+        }
+        __syncthreads();
+        // A -= d e^T + e d^T on the active block (both halves, bitwise symmetric)
+        for (int q = tid; q < i * i; q += T) {
+            const int k = q / i, j = q - k * i;
+            A(k, j) -= (dv[j] * gv[k] + gv[j] * dv[k]);
+        }
+        __syncthreads();
+        for (int j = tid; j < i; j += T) {
+            A(j, i) = dv[j];
+            dv[j] = A(i - 1, j);
+            A(i, j) = 0.;
+        }
+        if (tid == 0) dv[i] = h;
+        __syncthreads();
+    }
+
+    // ---- accumulate the transformations (cmaes.cpp:358-381) -----------------------
+    for (int i = 0; i < n - 1; i++) {
+        if (tid == 0) {
+            A(n - 1, i) = A(i, i);
+            A(i, i) = 1.;
+        }
+        const double h = dv[i + 1];
+        __syncthreads();
+        if (h != 0.) {
+            for (int k = tid; k <= i; k += T) {
+                const double v = A(k, i + 1);
+                hv[k] = v;
+                gv[k] = v / h;   // the reference's d[k]
+            }
+            __syncthreads();
+            // g_j = sum_k v_k A(k,j);  A(k,j) -= g_j * v_k / h
+            const int cols = i + 1;
+            const int TPC = 8;   // threads per column, strided over rows
+            for (int j = tid / TPC; j < cols; j += T / TPC) {
+                const int q = tid % TPC;
+                double g = 0.;
+                for (int k = q; k <= i; k += TPC) g += hv[k] * A(k, j);
+                g += __shfl_xor(g, 1, TPC);
+                g += __shfl_xor(g, 2, TPC);
+                g += __shfl_xor(g, 4, TPC);
+                for (int k = q; k <= i; k += TPC) A(k, j) -= g * gv[k];
+            }
+            __syncthreads();
+        }
+        for (int k = tid; k <= i; k += T) A(k, i + 1) = 0.;
+        __syncthreads();
+    }
+    for (int j = tid; j < n; j += T) {
+        dv[j] = A(n - 1, j);
+        A(n - 1, j) = (j == n - 1) ? 1. : 0.;
+    }
+    __syncthreads();
+
+    // ---- implicit QL (cmaes.cpp:383-456): one lane walks the scalar recurrence and
+    // records the Givens pairs, then n lanes apply them to their row of A -------------
+    if (tid == 0) {
+        for (int i = 1; i < n; i++) ev[i - 1] = ev[i];
+        ev[n - 1] = 0.;
+        sh_s[1] = 0.;   // f
+        sh_s[2] = 0.;   // tst1
+    }
+    __syncthreads();
+    const double eps = 0x1.0p-52;
+    for (int l = 0; l < n; l++) {
+        if (tid == 0) {
+            const double tst1 = fmax(sh_s[2], fabs(dv[l]) + fabs(ev[l]));
+            sh_s[2] = tst1;
+            int m = l;
+            for (; m < n; m++)
+                if (fabs(ev[m]) <= eps * tst1) break;
+            sh_i[1] = m;
+        }
+        __syncthreads();
+        const int m = sh_i[1];
+        if (m >= n) break;
+        if (m > l) {
+            int again = 1;
+            while (again) {
+                if (tid == 0) {
+                    const double tst1 = sh_s[2];
+                    double g = dv[l];
+                    double pp = (dv[l + 1] - g) / (2. * ev[l]);
+                    double r = hypot(pp, 1.);
+                    r = pp >= 0. ? fabs(r) : -fabs(r);
+                    dv[l] = ev[l] / (pp + r);
+                    dv[l + 1] = ev[l] * (pp + r);
+                    const double dl1 = dv[l + 1];
+                    double h = g - dv[l];
+                    for (int i = l + 2; i < n; i++) dv[i] -= h;
+                    sh_s[1] += h;
+
+                    pp = dv[m];
+                    double cth = 1., c2 = 1., c3 = 1.;
+                    const double el1 = ev[l + 1];
+                    double s = 0., s2 = 0.;
+                    for (int i = m - 1; i >= l; i--) {
+                        c3 = c2;
+                        c2 = cth;
+                        s2 = s;
+                        const double ei = ev[i], di = dv[i];
+                        g = cth * ei;
+                        h = cth * pp;
+                        r = hypot(pp, ei);
+                        ev[i + 1] = s * r;
+                        s = ei / r;
+                        cth = pp / r;
+                        pp = cth * di - s * g;
+                        dv[i + 1] = h + s * (cth * g + s * di);
+                        gv[i] = cth;
+                        hv[i] = s;
+                    }
+                    pp = -s * s2 * c3 * el1 * ev[l] / dl1;
+                    ev[l] = s * pp;
+                    dv[l] = cth * pp;
+                    sh_i[2] = fabs(ev[l]) > eps * tst1 ? 1 : 0;
+                }
+                __syncthreads();
+                for (int k = tid; k < n; k += T) {
+                    double hcur = A(k, m);
+                    for (int i = m - 1; i >= l; i--) {
+                        const double cth = gv[i], s = hv[i];
+                        const double x = A(k, i);
+                        A(k, i + 1) = s * x + cth * hcur;
+                        hcur = cth * x - s * hcur;
+                    }
+                    A(k, l) = hcur;
+                }
+                again = sh_i[2];
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            dv[l] += sh_s[1];
+            ev[l] = 0.;
+        }
+        __syncthreads();
+    }
+
+    // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ---
+    int *perm = reinterpret_cast<int*>(part);   // rank of eigenvalue j
+    for (int j = tid; j < n; j += T) {
+        const double dj = dv[j];
+        int r = 0;
+        for (int k = 0; k < n; k++) {
+            const double dk = dv[k];
+            r += (dk < dj) || (dk == dj && k < j);
+        }
+        perm[j] = r;
+        gv[r] = dj;   // sorted eigenvalues
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double shift = 0.;
+        int neg = 0;
+        if (gv[0] <= 0.) {
+            neg = 1;
+            shift = fmax(gv[n - 1], 0.) / 1e14;
+        }
+        sh_s[0] = shift;
+        sh_i[0] = neg;
+    }
+    __syncthreads();
+    if (sh_i[0]) {
+        const double shift = sh_s[0];
+        for (int i = tid; i < n; i += T) {
+            gv[i] = fmax(gv[i], 0.) + shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+        __syncthreads();
+    }
+    if (gv[n - 1] > 1e14 * gv[0]) {
+        const double shift = gv[n - 1] / 1e14 - gv[0];
+        __syncthreads();
+        for (int i = tid; i < n; i += T) {
+            gv[i] += shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+    }
+    __syncthreads();
+    double *Dp = d.D + (size_t) p * ld;
+    double *Bp = d.B + (size_t) p * ld * ld;
+    for (int i = tid; i < ld; i += T) Dp[i] = i < n ? sqrt(gv[i]) : 1.;
+    for (int q = tid; q < n * n; q += T) {
+        const int k = q / n, j = q - k * n;
+        Bp[(size_t) k * ld + perm[j]] = A(k, j);
+    }
+    if (tid == 0) {
+        sc->eigenlastev = sc->fev;
+        sc->eigen_done = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// post: C^-1/2 = B diag(1/D) B^T (cmaes.cpp:274-282) and the two packed MFMA operands
+// grid (ld/16, ld/16, P), 256 threads (one 16x16 tile per workgroup)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
+{
+    const int p = blockIdx.z;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    // mode 0: after cma_eigen, only if it decomposed; 1: always; 2: pack only (C^-1/2 is
+    // taken as stored -- Cmaes::init sets it to I whatever B holds, cmaes.cpp:55-59)
+    if (mode == 0 && !sc->eigen_done) return;
+    const int ld = c.ld, n = c.n;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.y * 16 + (tid >> 4), j = blockIdx.x * 16 + (tid & 15);
+    const double *B = d.B + (size_t) p * ld * ld;
+    const double *D = d.D + (size_t) p * ld;
+    __shared__ double Bi[16][17], Bj[16][17], Dinv[16];
+    double sum = 0.;
+    for (int k0 = 0; k0 < ld; k0 += 16) {
+        const int r = tid >> 4, k = k0 + (tid & 15);
+        const int ri = blockIdx.y * 16 + r, rj = blockIdx.x * 16 + r;
+        Bi[r][tid & 15] = (ri < n && k < n) ? B[(size_t) ri * ld + k] : 0.;
+        Bj[r][tid & 15] = (rj < n && k < n) ? B[(size_t) rj * ld + k] : 0.;
+        if (tid < 16) Dinv[tid] = (k0 + tid < n) ? D[k0 + tid] : 1.;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) sum += Bi[tid >> 4][kk] / Dinv[kk] * Bj[tid & 15][kk];
+        __syncthreads();
+    }
+    const bool in = i < n && j < n;
+    double v = in ? sum : 0.;
+    if (mode == 2) v = in ? d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] : 0.;
+    else d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] = v;
+    // packed B-operand element (row i -> column tile/lane, col j -> k index)
+    const int KS = ld >> 2;
+    const size_t pk = ((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15);
+    d.ISp[(size_t) p * ld * ld + pk] = v;
+    d.BDp[(size_t) p * ld * ld + pk] = in ? B[(size_t) i * ld + j] * D[j] : 0.;
+}
+
+// ---------------------------------------------------------------------------
+// history + stop tests (base_cmaes.cpp:191-209, :155 it++, cmaes.cpp:151-227)
+// one workgroup of 64 threads per population
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.x;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    const int lane = threadIdx.x, ld = c.ld, n = c.n;
+    double *hb = d.hist_best + (size_t) p * c.hlen, *hk = d.hist_kth + (size_t) p * c.hlen;
+    const double *f = d.f + (size_t) p * c.lambda_pad;
+    const int *order = d.order + (size_t) p * c.lambda_pad;
+    int it = sc->it;
+    int head = sc->hist_head, len = sc->hist_len;
+    double fbest = sc->fbest, fworst = sc->fworst;
+
+    if (it < c.mit) {
+        head = (head + 1) % c.hlen;
+        if (lane == 0) {
+            hb[head] = f[order[0]];
+            hk[head] = f[order[c.ik]];
+        }
+        if (len < c.hlen) len++;
+        __syncthreads();
+        if (len == c.hlen) {
+            double lo = BBO_INF, hi = -BBO_INF;
+            for (int k = lane; k < c.hlen; k += 64) {
+                lo = fmin(lo, hb[k]);
+                hi = fmax(hi, hb[k]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = fmin(lo, __shfl_xor(lo, off, 64));
+                hi = fmax(hi, __shfl_xor(hi, off, 64));
+            }
+            fbest = lo;
+            fworst = hi;
+        }
+    }
+    it++;
+    __syncthreads();
+
+    const double sigma = sc->sigma;
+    const double *pc = d.pc + (size_t) p * ld, *xm = d.xmean + (size_t) p * ld;
+    const double *C = d.C + (size_t) p * ld * ld, *B = d.B + (size_t) p * ld * ld;
+    const double *D = d.D + (size_t) p * ld;
+    int flag = 0;
+    if (it >= c.mit) {
+        flag = 1;
+    } else if (it >= c.hlen && fworst - fbest < c.tol) {
+        flag = 2;
+    } else {
+        // EqualFunVals
+        if (len >= n) {
+            int eq = 0;
+            for (int i = lane; i < n; i += 64) {
+                const int idx = (c.hlen + head - i) % c.hlen;
+                eq += hb[idx] == hk[idx];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) eq += __shfl_xor(eq, off, 64);
+            if (3 * eq >= n) flag = 3;
+        }
+        if (!flag) {   // TolX
+            int bad = 0;
+            for (int i = lane; i < n; i += 64)
+                bad |= (fmax(pc[i], sqrt(C[(size_t) i * ld + i])) * sigma / c.sigma0 >= c.tol);
+            if (!__any(bad)) flag = 4;
+        }
+        if (!flag && sigma / c.sigma0 > 1.0e20 * D[n - 1]) flag = 5;
+        if (!flag && D[n - 1] > 1.0e7 * D[0]) flag = 7;
+        if (!flag) {   // NoEffectAxis
+            const int iaxis = n - 1 - ((it - 1) % n);
+            int moved = 0;
+            for (int i = lane; i < n; i += 64)
+                moved |= (xm[i] != xm[i] + 0.1 * sigma * D[iaxis] * B[(size_t) iaxis * ld + i]);
+            if (!__any(moved)) flag = 8;
+        }
+        if (!flag) {   // NoEffectCoor
+            int stuck = 0;
+            for (int i = lane; i < n; i += 64)
+                stuck |= (xm[i] == xm[i] + 0.2 * sigma * sqrt(C[(size_t) i * ld + i]));
+            if (__any(stuck)) flag = 9;
+        }
+    }
+    if (lane == 0) {
+        sc->it = it;
+        sc->hist_head = head;
+        sc->hist_len = len;
+        sc->fbest = fbest;
+        sc->fworst = fworst;
+        sc->flag = flag;
+        if (flag) sc->stop = 1;
+        else if (sc->fev >= c.mfev) sc->stop = 2;
+    }
+}
+
+} // namespace bbo

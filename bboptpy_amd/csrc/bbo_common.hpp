@@ -1,0 +1,138 @@
+// bbo_common.hpp -- host-side plumbing shared by the optimizer engines:
+// error propagation to the C ABI, owned device buffers, the optimizer base class
+// that mirrors MultivariateOptimizer (/root/reference/src/multivariate/multivariate.h:132-146).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bbopt_hip.h"
+
+namespace bbo {
+
+struct Error: std::runtime_error {
+    int status;
+    Error(int st, const std::string &msg) :
+            std::runtime_error(msg), status(st) {
+    }
+};
+
+#define BBO_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess)                                                      \
+            throw ::bbo::Error(BBO_ERR_HIP, std::string(#expr) + ": "              \
+                    + hipGetErrorString(e_));                                      \
+    } while (0)
+
+#define BBO_REQUIRE(cond, msg)                                                     \
+    do {                                                                           \
+        if (!(cond)) throw ::bbo::Error(BBO_ERR_ARG, msg);                         \
+    } while (0)
+
+inline int round_up(int v, int m)
+{
+    return (v + m - 1) / m * m;
+}
+
+// an owned, zero-initialised device allocation
+template<class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    void alloc(size_t n)
+    {
+        release();
+        count = n;
+        if (n == 0) return;
+        BBO_HIP(hipMalloc((void**) &p, n * sizeof(T)));
+        BBO_HIP(hipMemset(p, 0, n * sizeof(T)));
+    }
+    void upload(const T *src, size_t n, size_t offset = 0)
+    {
+        BBO_HIP(hipMemcpy(p + offset, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void download(T *dst, size_t n, size_t offset = 0) const
+    {
+        BBO_HIP(hipMemcpy(dst, p + offset, n * sizeof(T), hipMemcpyDeviceToHost));
+    }
+};
+
+// how the population's fitness is obtained
+struct ObjectiveSpec {
+    int kind = BBO_OBJECTIVE_BUILTIN;
+    int builtin = BBO_OBJ_ROSENBROCK;
+    bbo_scalar_fn scalar = nullptr;
+    bbo_batch_fn batch = nullptr;
+    void *user = nullptr;
+
+    bool on_device() const { return kind == BBO_OBJECTIVE_BUILTIN; }
+    // evaluates `rows` host-resident candidates through the callbacks
+    void eval_host(const double *X, int rows, int n, int ld, double *f_out) const
+    {
+        if (kind == BBO_OBJECTIVE_BATCH_CALLBACK) {
+            if (batch(X, rows, n, ld, f_out, user) != 0)
+                throw Error(BBO_ERR_CALLBACK, "objective batch callback failed");
+            return;
+        }
+        for (int r = 0; r < rows; r++) {
+            int failed = 0;
+            f_out[r] = scalar(X + (size_t) r * ld, n, user, &failed);
+            if (failed) throw Error(BBO_ERR_CALLBACK, "objective callback failed");
+        }
+    }
+};
+
+// per-coordinate objective constants; must equal bbo_objective_aux() of
+// oracle/objectives.h so the checker and the kernels see the same table
+inline void fill_objective_aux(int obj, int n, double *aux)
+{
+    for (int i = 0; i < n; i++) {
+        const double t = (n > 1) ? ((double) i) / (double) (n - 1) : 0.;
+        switch (obj) {
+        case BBO_OBJ_ELLIPSOID: aux[i] = pow(10., 6. * t); break;
+        case BBO_OBJ_DIFFPOW:   aux[i] = 2. + 4. * t; break;
+        case BBO_OBJ_GRIEWANK:  aux[i] = 1. / sqrt((double) (i + 1)); break;
+        default:                aux[i] = 0.; break;
+        }
+    }
+}
+
+// The C++ statement of MultivariateOptimizer (multivariate.h:132-146) that every
+// engine implements and the C ABI dispatches to.
+class Optimizer {
+public:
+    virtual ~Optimizer() {}
+    virtual void init(int n, const double *lower, const double *upper, const double *guess,
+            const ObjectiveSpec &obj) = 0;
+    virtual void iterate() = 0;
+    virtual void solution(int population, double *x_out, int *n_evals, int *converged) = 0;
+    // init + loop until the algorithm's own stop rule or the evaluation budget
+    virtual void optimize(int n, const double *lower, const double *upper,
+            const double *guess, const ObjectiveSpec &obj, double *x_out, int *n_evals,
+            int *converged) = 0;
+    virtual int run(int max_generations) = 0;
+    virtual int get(const std::string &key, int population, double *out, int cap) = 0;
+    virtual int set(const std::string &key, int population, const double *in, int count) = 0;
+    virtual int dimension() const = 0;
+
+    std::string last_error;
+};
+
+} // namespace bbo

@@ -1,0 +1,345 @@
+"""Python class surface of the reference, over the HIP C ABI.
+
+Mirrors the pybind11 module `_bboptpy` for the algorithms on the hot path
+(/root/reference/py/multivariate_py.cpp): same class names, the same class hierarchy
+(ActiveCMAES -> CMAES -> BaseCMAES -> MultivariateSearch, :99-115), the same positional
+order, keyword names and defaults of every constructor (:103-171, :265-269), the four
+methods optimize / initialize / iterate / solution (:376-420) and the MultivariateSolution
+result object (:360-371).  Every constructor additionally accepts keyword-only extensions
+that have no reference counterpart: `seed` (Philox key; default = fresh entropy, like the
+reference's random_device seeding), `device`, and `populations`.
+
+All computation happens in libbbopt_hip.so on the GPU.  A Python callable objective is
+supported through the host-callback path (X leaves HBM once per generation); the objects in
+`bboptpy_amd.objectives` select the built-in on-device objectives instead.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as _np
+
+from . import _ffi
+from .objectives import Builtin
+
+
+class MultivariateSolution:
+    """result record, multivariate.h:81-115 / multivariate_py.cpp:360-371"""
+
+    def __init__(self, x, n_evals, converged):
+        self._x = _np.array(x, dtype=_np.float64)
+        self._n_evals = int(n_evals)
+        self._converged = bool(converged)
+
+    @property
+    def x(self):
+        return self._x.copy()   # the reference returns a fresh array each time (:362-364)
+
+    @property
+    def converged(self):
+        return self._converged
+
+    @property
+    def n_evals(self):
+        return self._n_evals
+
+    def __str__(self):
+        # multivariate_solution::toString, multivariate.h:97-114 (std::to_string == "%f")
+        sol = "".join("%f " % v for v in self._x)
+        return ("x*: " + sol + "\n"
+                + "objective calls: %d\n" % self._n_evals
+                + "constraint calls: 0\n"
+                + "B/B constraint calls: 0\n"
+                + "converged: " + ("yes" if self._converged else "no/unknown"))
+
+    def __repr__(self):
+        return "<MultivariateSolution n_evals=%d converged=%s>" % (self._n_evals,
+                                                                   self._converged)
+
+
+def _as_vec(a, name):
+    v = _np.ascontiguousarray(_np.asarray(a, dtype=_np.float64)).ravel()
+    if v.size == 0:
+        raise ValueError("%s must not be empty" % name)
+    return v
+
+
+class _ObjectiveBinding:
+    """keeps the ctypes callback (and the user's callable) alive for the handle's life,
+    like the std::function captured by value in multivariate_py.cpp:385-388"""
+
+    def __init__(self, f, n):
+        self.error = None
+        self.struct = _ffi.Objective()
+        self._keep = None
+        if isinstance(f, Builtin):
+            self.struct.kind = _ffi.OBJ_BUILTIN
+            self.struct.builtin = f.builtin_id
+            return
+        if isinstance(f, str):
+            if f not in _ffi.BUILTIN_IDS:
+                raise ValueError("unknown built-in objective %r" % f)
+            self.struct.kind = _ffi.OBJ_BUILTIN
+            self.struct.builtin = _ffi.BUILTIN_IDS[f]
+            return
+        if not callable(f):
+            raise TypeError("objective must be callable or a built-in objective")
+        binding = self
+        if getattr(f, "_bbo_vectorized", False):
+            def batch(xptr, rows, ncol, ld, fout, user):
+                try:
+                    X = _np.ctypeslib.as_array(xptr, shape=(rows, ld))[:, :ncol].copy()
+                    vals = _np.asarray(f(X), dtype=_np.float64).ravel()
+                    if vals.size != rows:
+                        raise ValueError("vectorized objective returned %d values for %d rows"
+                                         % (vals.size, rows))
+                    _np.ctypeslib.as_array(fout, shape=(rows,))[:] = vals
+                    return 0
+                except BaseException as e:   # propagate like pybind's error_already_set
+                    binding.error = e
+                    return 1
+            self._keep = _ffi.BATCH_FN(batch)
+            self.struct.kind = _ffi.OBJ_BATCH_CB
+            self.struct.batch = self._keep
+        else:
+            def scalar(xptr, ncol, user, failed):
+                try:
+                    x = _np.ctypeslib.as_array(xptr, shape=(ncol,)).copy()
+                    return float(f(x))
+                except BaseException as e:
+                    binding.error = e
+                    failed[0] = 1
+                    return 0.0
+            self._keep = _ffi.SCALAR_FN(scalar)
+            self.struct.kind = _ffi.OBJ_SCALAR_CB
+            self.struct.scalar = self._keep
+
+
+class MultivariateSearch:
+    """MultivariateOptimizer (multivariate.h:132-146) as bound at multivariate_py.cpp:374-420"""
+
+    _algo = None
+
+    def __init__(self, *, seed=None, device=0, populations=1):
+        _ffi.lib()   # fail loudly at construction when the HIP library is missing
+        self._params = _ffi.default_params(self._algo)
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        self._params.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._params.device = int(device)
+        self._params.populations = int(populations)
+        self._handle = None
+        self._binding = None
+        self._n = None
+
+    # -- handle management --------------------------------------------------------
+    def _create(self):
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().bbo_create(C.byref(self._params), C.byref(h)))
+        return h
+
+    def _ensure_handle(self):
+        if self._handle is None:
+            self._handle = self._create()
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _ffi.lib().bbo_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status < 0:
+            err = self._binding.error if self._binding is not None else None
+            if err is not None:
+                self._binding.error = None
+                raise err
+            _ffi.check(status, self._handle)
+        return status
+
+    def _problem(self, f, lower, upper, guess):
+        lower = _as_vec(lower, "lower")
+        n = lower.size            # like the reference, n comes from `lower` (:380)
+        upper = _as_vec(upper, "upper")
+        guess = _as_vec(guess, "guess")
+        pops = self._params.populations
+        if upper.size < n or guess.size < n * pops:
+            raise ValueError("upper/guess are shorter than lower (n = %d)" % n)
+        self._binding = _ObjectiveBinding(f, n)
+        self._n = n
+        return n, lower, _np.ascontiguousarray(upper[:n]), _np.ascontiguousarray(
+            guess[:n * pops])
+
+    # -- the four reference methods --------------------------------------------------
+    def optimize(self, f, lower, upper, guess):
+        n, lower, upper, guess = self._problem(f, lower, upper, guess)
+        h = self._ensure_handle()
+        x = _np.zeros(n)
+        fev, conv = C.c_int(), C.c_int()
+        self._check(_ffi.lib().bbo_optimize(h, n, lower, upper, guess,
+                                            C.byref(self._binding.struct), x,
+                                            C.byref(fev), C.byref(conv)))
+        return MultivariateSolution(x, fev.value, conv.value)
+
+    def initialize(self, f, lower, upper, guess):
+        n, lower, upper, guess = self._problem(f, lower, upper, guess)
+        h = self._ensure_handle()
+        self._check(_ffi.lib().bbo_init(h, n, lower, upper, guess,
+                                        C.byref(self._binding.struct)))
+
+    def iterate(self):
+        if self._handle is None:
+            raise RuntimeError("iterate() called before initialize()")
+        self._check(_ffi.lib().bbo_iterate(self._handle))
+
+    def solution(self, population=0):
+        if self._handle is None:
+            raise RuntimeError("solution() called before initialize()")
+        x = _np.zeros(self._n)
+        fev, conv = C.c_int(), C.c_int()
+        self._check(_ffi.lib().bbo_solution_of(self._handle, int(population), x,
+                                               C.byref(fev), C.byref(conv)))
+        return MultivariateSolution(x, fev.value, conv.value)
+
+    # -- extensions ---------------------------------------------------------------------
+    def run(self, max_generations):
+        """advance up to max_generations on the device without returning to Python;
+        returns the number of generations launched"""
+        if self._handle is None:
+            raise RuntimeError("run() called before initialize()")
+        done = C.c_int()
+        self._check(_ffi.lib().bbo_run(self._handle, int(max_generations), C.byref(done)))
+        return done.value
+
+    def get_state(self, key, population=0):
+        """named optimizer state as a float64 array (keys: DESIGN.md)"""
+        if self._handle is None:
+            raise RuntimeError("get_state() called before initialize()")
+        L = _ffi.lib()
+        cnt = self._check(L.bbo_get(self._handle, key.encode(), population, None, 0))
+        out = _np.zeros(max(cnt, 1))
+        self._check(L.bbo_get(self._handle, key.encode(), population,
+                              out.ctypes.data_as(C.c_void_p), cnt))
+        return out[:cnt]
+
+    def set_state(self, key, value, population=0):
+        v = _np.ascontiguousarray(_np.asarray(value, dtype=_np.float64)).ravel()
+        self._check(_ffi.lib().bbo_set(self._handle, key.encode(), population, v, v.size))
+
+
+class BaseCMAES(MultivariateSearch):
+    """BaseCmaes, multivariate_py.cpp:99-101 (abstract in the reference)"""
+
+    def phase(self, which):
+        self._check(_ffi.lib().bbo_cma_phase_run(self._handle, int(which)))
+
+    def inject_normals(self, z):
+        if z is None:
+            self._check(_ffi.lib().bbo_cma_inject_normals(self._handle, None, 0))
+            return
+        z = _np.ascontiguousarray(_np.asarray(z, dtype=_np.float64)).ravel()
+        self._check(_ffi.lib().bbo_cma_inject_normals(
+            self._handle, z.ctypes.data_as(C.c_void_p), z.size))
+
+
+class CMAES(BaseCMAES):
+    """CMAES(mfev, tol, np, sigma0=2., bound=False, eigenrate=0.25) -- :103-108"""
+    _algo = _ffi.ALGO_CMAES
+
+    def __init__(self, mfev, tol, np, sigma0=2., bound=False, eigenrate=0.25, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.tol, p.np = int(mfev), float(tol), int(np)
+        p.sigma0, p.bound, p.eigenrate = float(sigma0), int(bool(bound)), float(eigenrate)
+
+
+class ActiveCMAES(CMAES):
+    """ActiveCMAES(mfev, tol, np, sigma0=2., bound=False, alphacov=2., eigenrate=0.25)
+    -- :110-115"""
+    _algo = _ffi.ALGO_ACTIVE_CMAES
+
+    def __init__(self, mfev, tol, np, sigma0=2., bound=False, alphacov=2., eigenrate=0.25,
+                 **ext):
+        super().__init__(mfev, tol, np, sigma0, bound, eigenrate, **ext)
+        self._params.alphacov = float(alphacov)
+
+
+class _RestartDriver(MultivariateSearch):
+    def __init__(self, base, **ext):
+        if not isinstance(base, BaseCMAES):
+            raise TypeError("base must be a CMA-ES optimizer (CMAES / ActiveCMAES)")
+        super().__init__(**ext)
+        self._base = base   # kept alive here; the reference only borrows the pointer
+
+    def _create(self):
+        h = C.c_void_p()
+        base_h = self._base._ensure_handle()
+        _ffi.check(_ffi.lib().bbo_create_restart(C.byref(self._params), base_h, C.byref(h)))
+        return h
+
+
+class IPopCMAES(_RestartDriver):
+    """IPopCMAES(base, mfev, print=False, sigma0=2., nipop=True, ksigmadec=1.6,
+    boundlambda=True) -- :137-142"""
+    _algo = _ffi.ALGO_IPOP
+
+    def __init__(self, base, mfev, print=False, sigma0=2., nipop=True, ksigmadec=1.6,
+                 boundlambda=True, **ext):
+        super().__init__(base, **ext)
+        p = self._params
+        p.mfev, p.print, p.sigma0 = int(mfev), int(bool(print)), float(sigma0)
+        p.nipop, p.ksigmadec, p.boundlambda = int(bool(nipop)), float(ksigmadec), int(
+            bool(boundlambda))
+
+
+class BiPopCMAES(_RestartDriver):
+    """BiPopCMAES(base, mfev, print=False, sigma0=2., maxlargeruns=9, nbipop=True,
+    ksigmadec=1.6, kbudget=2.) -- :144-151"""
+    _algo = _ffi.ALGO_BIPOP
+
+    def __init__(self, base, mfev, print=False, sigma0=2., maxlargeruns=9, nbipop=True,
+                 ksigmadec=1.6, kbudget=2., **ext):
+        super().__init__(base, **ext)
+        p = self._params
+        p.mfev, p.print, p.sigma0 = int(mfev), int(bool(print)), float(sigma0)
+        p.maxlargeruns, p.nipop = int(maxlargeruns), int(bool(nbipop))
+        p.ksigmadec, p.kbudget = float(ksigmadec), float(kbudget)
+
+
+class JADE(MultivariateSearch):
+    """JADE(mfev, np, tol, archive=True, repaircr=True, pelite=0.05, cdamp=0.1, sigma=0.07)
+    -- :159-164"""
+    _algo = _ffi.ALGO_JADE
+
+    def __init__(self, mfev, np, tol, archive=True, repaircr=True, pelite=0.05, cdamp=0.1,
+                 sigma=0.07, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.np, p.tol = int(mfev), int(np), float(tol)
+        p.archive, p.repaircr = int(bool(archive)), int(bool(repaircr))
+        p.pelite, p.cdamp, p.jade_sigma = float(pelite), float(cdamp), float(sigma)
+
+
+class SHADE(MultivariateSearch):
+    """SHADE(mfev, npinit, tol, archive=True, repaircr=True, h=100, npmin=4) -- :166-171"""
+    _algo = _ffi.ALGO_SHADE
+
+    def __init__(self, mfev, npinit, tol, archive=True, repaircr=True, h=100, npmin=4, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.np, p.tol = int(mfev), int(npinit), float(tol)
+        p.archive, p.repaircr, p.h, p.npmin = int(bool(archive)), int(bool(repaircr)), int(
+            h), int(npmin)
+
+
+class APSO(MultivariateSearch):
+    """APSO(mfev, tol, np, correct=True) -- :265-269"""
+    _algo = _ffi.ALGO_APSO
+
+    def __init__(self, mfev, tol, np, correct=True, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.tol, p.np, p.correct = int(mfev), float(tol), int(np), int(bool(correct))
