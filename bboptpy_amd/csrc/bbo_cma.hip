@@ -219,9 +219,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     scal_.upload(sc.data(), P);
 
     // the eigensolver keeps its matrix in LDS when it fits
-    const int lda = n | 1;
-    const size_t eig_lds = (size_t) (4 * EIG_NMAX + 1024 + (size_t) n * lda) * sizeof(double);
-    if (eig_lds > 160 * 1024 - 256) eig_work_.alloc((size_t) P * ld * (ld + 1));
+    if (!eig_plan(n, c.ld).use_lds) eig_work_.alloc((size_t) P * ld * (ld + 1));
     else eig_work_.release();
 
     CmaDev &d = d_;
@@ -233,6 +231,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     d.hist_best = hist_best_.p; d.hist_kth = hist_kth_.p; d.eig_work = eig_work_.p;
     d.weights = weights_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.zinject = nullptr; d.zrecord = nullptr; d.scal = scal_.p;
+    d.stamps = stamps_.p;
 
     // packed operands of the initial B, D, C^-1/2
     c.honor_stop = 0;
@@ -309,18 +308,15 @@ void CmaEngine::launch_update()
 void CmaEngine::launch_eigen()
 {
     const CmaConst &c = c_;
-    const int lda_lds = c.n | 1;
-    const size_t base = (size_t) (4 * EIG_NMAX + 1024) * sizeof(double);
-    const size_t with_mat = base + (size_t) c.n * lda_lds * sizeof(double);
-    const bool use_lds = with_mat <= 160 * 1024 - 256;
+    const EigPlan pl = eig_plan(c.n, c.ld);
     static bool attr_done = false;
     if (!attr_done) {
         BBO_HIP(hipFuncSetAttribute((const void*) cma_eigen,
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_done = true;
     }
-    hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), use_lds ? with_mat : base,
-            stream_, d_, c_, use_lds ? 1 : 0, use_lds ? lda_lds : c.ld + 1, 0);
+    hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
+            c_, pl, 0);
     BBO_HIP(hipGetLastError());
     dim3 grid(c.ld / 16, c.ld / 16, c.npop);
     hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 0);
@@ -630,6 +626,15 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
         if (out && cap >= (int) cnt) zrecord_.download(out, cnt, p * cnt);
         return (int) cnt;
     }
+    if (k == "eig_stamps") {
+        if (!stamps_.p) return 0;
+        if (out && cap >= 16) {
+            long long t[16];
+            stamps_.download(t, 16);
+            for (int i = 0; i < 16; i++) out[i] = (double) t[i];
+        }
+        return 16;
+    }
     if (k == "best_hist" || k == "kth_hist") {
         if (out && cap >= c.hlen)
             (k == "best_hist" ? hist_best_ : hist_kth_).download(out, c.hlen, (size_t) p * c.hlen);
@@ -719,6 +724,15 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         BBO_HIP(hipGetLastError());
         BBO_HIP(hipStreamSynchronize(stream_));
         return r;
+    }
+    if (k == "dbg") {
+        d_.dbg = (int) in[0];
+        return 1;
+    }
+    if (k == "eig_stamps") {
+        if (stamps_.count != 16) stamps_.alloc(16);
+        d_.stamps = stamps_.p;
+        return 1;
     }
     if (k == "record_normals") {
         BBO_REQUIRE(count == 1, "set: wrong element count");

@@ -63,6 +63,8 @@ struct CmaDev {
     const double *zinject;            // [P][lambda][n] or null
     double *zrecord;                  // [P][lambda][n] or null
     CmaScal *scal;                    // [P]
+    long long *stamps;                // [16] eigensolver phase clocks (diagnostic) or null
+    int dbg;                          // diagnostic switches (0 in production)
 };
 
 class CmaEngine: public Optimizer {
@@ -116,6 +118,7 @@ private:
             gram_part_, mean_part_, hist_best_, hist_kth_, eig_work_, weights_, lower_,
             upper_, aux_, zinject_, zrecord_;
     DevBuf<int> rank_, order_;
+    DevBuf<long long> stamps_;
     DevBuf<CmaScal> scal_;
     int *stop_host_ = nullptr;   // pinned
 };

@@ -20,6 +20,7 @@
 #include "bbo_cma.hpp"
 #include "bbo_objectives.hpp"
 #include "bbo_rng.hpp"
+#include "bbo_eig.hpp"
 
 namespace bbo {
 
@@ -464,310 +465,6 @@ __global__ __launch_bounds__(256) void cma_cov(CmaDev d, CmaConst c)
     sum += g;
     C[(size_t) i * ld + j] = sum;
     C[(size_t) j * ld + i] = sum;
-}
-
-// ---------------------------------------------------------------------------
-// eigen: C = B diag(D^2) B^T by Householder tridiagonalisation + implicit QL, the
-// algorithm of cmaes.cpp:285-478 with the same sign conventions, parallelised inside
-// one workgroup.  The matrix lives in LDS when it fits (n <= 128), else in HBM/L2.
-// ---------------------------------------------------------------------------
-struct EigMat {
-    double *a;
-    int ld;
-    __device__ double& operator()(int i, int j) const { return a[(size_t) i * ld + j]; }
-};
-
-constexpr int EIG_THREADS = 512;
-constexpr int EIG_NMAX = 512;
-
-// sum over k < len of fn(k), by wave 0 only (called with tid < 64)
-template<class F>
-__device__ inline double wave0_sum(int len, int lane, F fn)
-{
-    double s = 0.;
-    for (int k = lane; k < len; k += 64) s += fn(k);
-    return wave_sum(s);
-}
-
-__global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, int use_lds,
-        int lda, int force)
-{
-    const int p = blockIdx.x;
-    CmaScal *sc = d.scal + p;
-    if (pop_frozen(c, sc)) return;
-    // cmaes.cpp:233: skip until enough evaluations have passed
-    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
-        if (threadIdx.x == 0) sc->eigen_done = 0;
-        return;
-    }
-    extern __shared__ double lds[];
-    const int tid = threadIdx.x, T = EIG_THREADS, lane = tid & 63;
-    const int n = c.n, ld = c.ld;
-    double *dv = lds;               // d[n]: diagonal / eigenvalues
-    double *ev = dv + EIG_NMAX;     // e[n]: sub-diagonal
-    double *gv = ev + EIG_NMAX;     // g[n], also Givens cosines
-    double *hv = gv + EIG_NMAX;     // v[n], also Givens sines
-    double *part = hv + EIG_NMAX;   // [T/64][...] small scratch
-    __shared__ double sh_s[4];
-    __shared__ int sh_i[4];
-    EigMat A { use_lds ? part + 1024 : d.eig_work + (size_t) p * ld * lda, lda };
-    double *C = d.C + (size_t) p * ld * ld;
-
-    for (int q = tid; q < n * n; q += T) {
-        const int i = q / n, j = q - i * n;
-        A(i, j) = C[(size_t) i * ld + j];
-    }
-    for (int j = tid; j < n; j += T) dv[j] = C[(size_t) (n - 1) * ld + j];
-    __syncthreads();
-
-    // ---- Householder reduction (cmaes.cpp:293-356) -------------------------------
-    for (int i = n - 1; i > 0; i--) {
-        if (tid < 64) {
-            const double scale = wave0_sum(i, lane, [&](int k) { return fabs(dv[k]); });
-            if (scale == 0.) {
-                if (lane == 0) {
-                    ev[i] = dv[i - 1];
-                    sh_s[0] = 0.;   // h
-                    sh_i[0] = 1;    // degenerate step
-                }
-            } else {
-                for (int k = lane; k < i; k += 64) dv[k] /= scale;
-                const double h0 = wave0_sum(i, lane, [&](int k) { return dv[k] * dv[k]; });
-                if (lane == 0) {
-                    const double f = dv[i - 1];
-                    double g = sqrt(h0);
-                    if (f > 0) g = -g;
-                    ev[i] = scale * g;
-                    sh_s[0] = h0 - f * g;
-                    dv[i - 1] = f - g;
-                    sh_i[0] = 0;
-                }
-            }
-        }
-        __syncthreads();
-        const double h = sh_s[0];
-        if (sh_i[0]) {
-            for (int j = tid; j < i; j += T) {
-                dv[j] = A(i - 1, j);
-                A(i, j) = 0.;
-                A(j, i) = 0.;
-            }
-            if (tid == 0) dv[i] = 0.;
-            __syncthreads();
-            continue;
-        }
-        // e = A d over the active block (kept symmetric in full), stash d in column i
-        {
-            const int TPR = 4;   // threads per row
-            for (int j = tid / TPR; j < i; j += T / TPR) {
-                const int q = tid % TPR;
-                double g = 0.;
-                for (int k = q; k < i; k += TPR) g += A(j, k) * dv[k];
-                g += __shfl_xor(g, 1, TPR);
-                g += __shfl_xor(g, 2, TPR);
-                if (q == 0) gv[j] = g;
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            for (int k = lane; k < i; k += 64) gv[k] *= 1. / h;
-            const double f = wave0_sum(i, lane, [&](int k) { return gv[k] * dv[k]; });
-            const double hh = f / (h + h);
-            for (int k = lane; k < i; k += 64) {
-                gv[k] = gv[k] - hh * dv[k];
-            }
-        }
-        __syncthreads();
-        // A -= d e^T + e d^T on the active block (both halves, bitwise symmetric)
-        for (int q = tid; q < i * i; q += T) {
-            const int k = q / i, j = q - k * i;
-            A(k, j) -= (dv[j] * gv[k] + gv[j] * dv[k]);
-        }
-        __syncthreads();
-        for (int j = tid; j < i; j += T) {
-            A(j, i) = dv[j];
-            dv[j] = A(i - 1, j);
-            A(i, j) = 0.;
-        }
-        if (tid == 0) dv[i] = h;
-        __syncthreads();
-    }
-
-    // ---- accumulate the transformations (cmaes.cpp:358-381) -----------------------
-    for (int i = 0; i < n - 1; i++) {
-        if (tid == 0) {
-            A(n - 1, i) = A(i, i);
-            A(i, i) = 1.;
-        }
-        const double h = dv[i + 1];
-        __syncthreads();
-        if (h != 0.) {
-            for (int k = tid; k <= i; k += T) {
-                const double v = A(k, i + 1);
-                hv[k] = v;
-                gv[k] = v / h;   // the reference's d[k]
-            }
-            __syncthreads();
-            // g_j = sum_k v_k A(k,j);  A(k,j) -= g_j * v_k / h
-            const int cols = i + 1;
-            const int TPC = 8;   // threads per column, strided over rows
-            for (int j = tid / TPC; j < cols; j += T / TPC) {
-                const int q = tid % TPC;
-                double g = 0.;
-                for (int k = q; k <= i; k += TPC) g += hv[k] * A(k, j);
-                g += __shfl_xor(g, 1, TPC);
-                g += __shfl_xor(g, 2, TPC);
-                g += __shfl_xor(g, 4, TPC);
-                for (int k = q; k <= i; k += TPC) A(k, j) -= g * gv[k];
-            }
-            __syncthreads();
-        }
-        for (int k = tid; k <= i; k += T) A(k, i + 1) = 0.;
-        __syncthreads();
-    }
-    for (int j = tid; j < n; j += T) {
-        dv[j] = A(n - 1, j);
-        A(n - 1, j) = (j == n - 1) ? 1. : 0.;
-    }
-    __syncthreads();
-
-    // ---- implicit QL (cmaes.cpp:383-456): one lane walks the scalar recurrence and
-    // records the Givens pairs, then n lanes apply them to their row of A -------------
-    if (tid == 0) {
-        for (int i = 1; i < n; i++) ev[i - 1] = ev[i];
-        ev[n - 1] = 0.;
-        sh_s[1] = 0.;   // f
-        sh_s[2] = 0.;   // tst1
-    }
-    __syncthreads();
-    const double eps = 0x1.0p-52;
-    for (int l = 0; l < n; l++) {
-        if (tid == 0) {
-            const double tst1 = fmax(sh_s[2], fabs(dv[l]) + fabs(ev[l]));
-            sh_s[2] = tst1;
-            int m = l;
-            for (; m < n; m++)
-                if (fabs(ev[m]) <= eps * tst1) break;
-            sh_i[1] = m;
-        }
-        __syncthreads();
-        const int m = sh_i[1];
-        if (m >= n) break;
-        if (m > l) {
-            int again = 1;
-            while (again) {
-                if (tid == 0) {
-                    const double tst1 = sh_s[2];
-                    double g = dv[l];
-                    double pp = (dv[l + 1] - g) / (2. * ev[l]);
-                    double r = hypot(pp, 1.);
-                    r = pp >= 0. ? fabs(r) : -fabs(r);
-                    dv[l] = ev[l] / (pp + r);
-                    dv[l + 1] = ev[l] * (pp + r);
-                    const double dl1 = dv[l + 1];
-                    double h = g - dv[l];
-                    for (int i = l + 2; i < n; i++) dv[i] -= h;
-                    sh_s[1] += h;
-
-                    pp = dv[m];
-                    double cth = 1., c2 = 1., c3 = 1.;
-                    const double el1 = ev[l + 1];
-                    double s = 0., s2 = 0.;
-                    for (int i = m - 1; i >= l; i--) {
-                        c3 = c2;
-                        c2 = cth;
-                        s2 = s;
-                        const double ei = ev[i], di = dv[i];
-                        g = cth * ei;
-                        h = cth * pp;
-                        r = hypot(pp, ei);
-                        ev[i + 1] = s * r;
-                        s = ei / r;
-                        cth = pp / r;
-                        pp = cth * di - s * g;
-                        dv[i + 1] = h + s * (cth * g + s * di);
-                        gv[i] = cth;
-                        hv[i] = s;
-                    }
-                    pp = -s * s2 * c3 * el1 * ev[l] / dl1;
-                    ev[l] = s * pp;
-                    dv[l] = cth * pp;
-                    sh_i[2] = fabs(ev[l]) > eps * tst1 ? 1 : 0;
-                }
-                __syncthreads();
-                for (int k = tid; k < n; k += T) {
-                    double hcur = A(k, m);
-                    for (int i = m - 1; i >= l; i--) {
-                        const double cth = gv[i], s = hv[i];
-                        const double x = A(k, i);
-                        A(k, i + 1) = s * x + cth * hcur;
-                        hcur = cth * x - s * hcur;
-                    }
-                    A(k, l) = hcur;
-                }
-                again = sh_i[2];
-                __syncthreads();
-            }
-        }
-        if (tid == 0) {
-            dv[l] += sh_s[1];
-            ev[l] = 0.;
-        }
-        __syncthreads();
-    }
-
-    // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ---
-    int *perm = reinterpret_cast<int*>(part);   // rank of eigenvalue j
-    for (int j = tid; j < n; j += T) {
-        const double dj = dv[j];
-        int r = 0;
-        for (int k = 0; k < n; k++) {
-            const double dk = dv[k];
-            r += (dk < dj) || (dk == dj && k < j);
-        }
-        perm[j] = r;
-        gv[r] = dj;   // sorted eigenvalues
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double shift = 0.;
-        int neg = 0;
-        if (gv[0] <= 0.) {
-            neg = 1;
-            shift = fmax(gv[n - 1], 0.) / 1e14;
-        }
-        sh_s[0] = shift;
-        sh_i[0] = neg;
-    }
-    __syncthreads();
-    if (sh_i[0]) {
-        const double shift = sh_s[0];
-        for (int i = tid; i < n; i += T) {
-            gv[i] = fmax(gv[i], 0.) + shift;
-            C[(size_t) i * ld + i] += shift;
-        }
-        __syncthreads();
-    }
-    if (gv[n - 1] > 1e14 * gv[0]) {
-        const double shift = gv[n - 1] / 1e14 - gv[0];
-        __syncthreads();
-        for (int i = tid; i < n; i += T) {
-            gv[i] += shift;
-            C[(size_t) i * ld + i] += shift;
-        }
-    }
-    __syncthreads();
-    double *Dp = d.D + (size_t) p * ld;
-    double *Bp = d.B + (size_t) p * ld * ld;
-    for (int i = tid; i < ld; i += T) Dp[i] = i < n ? sqrt(gv[i]) : 1.;
-    for (int q = tid; q < n * n; q += T) {
-        const int k = q / n, j = q - k * n;
-        Bp[(size_t) k * ld + perm[j]] = A(k, j);
-    }
-    if (tid == 0) {
-        sc->eigenlastev = sc->fev;
-        sc->eigen_done = 1;
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,674 @@
+// bbo_eig.hpp -- symmetric eigendecomposition C = B diag(D^2) B^T inside ONE workgroup.
+//
+// The algorithm is the reference's (Cmaes::eigenDecomposition, cmaes.cpp:229-283:
+// Householder tridiagonalisation = tred2 :285-381, implicit-shift QL = tql2 :383-456,
+// ascending order :459-477, repair :250-266, square roots :269-271) with the same sign
+// conventions, so the eigenvectors -- not only C -- agree with the reference.  What
+// changes is the execution: CDNA4 has no fast serial core, so
+//   * tred2's matrix-vector product and rank-2 update run over a 4-lanes-per-row tiling
+//     of the active block (kept symmetric in full), every wavefront recomputes the O(n)
+//     reductions redundantly instead of waiting for a broadcast: 2 barriers per step;
+//   * the back-accumulation of the reflectors runs column-parallel: 2 barriers per step;
+//   * tql2 is split into a PRODUCER (wavefront 0: the scalar shift/rotation recurrence on
+//     (d, e) only, recording the Givens pairs) and CONSUMERS (one lane per row of the
+//     eigenvector matrix, applying a recorded chunk) that overlap through two LDS
+//     buffers -- the serial recurrence, ~1e2 cycles per rotation, is the critical path.
+// The matrix lives in LDS when it fits (n <= 128), else in HBM/L2.
+#pragma once
+
+#include "bbo_cma.hpp"
+
+namespace bbo {
+
+constexpr int EIG_THREADS = 512;
+constexpr int EIG_NMAX = 512;
+constexpr int EIG_MAXSEQ = 64;
+
+struct EigPlan {
+    int use_lds;      // matrix in LDS?
+    int reg_path;     // n <= 128: tred2 + accumulation run out of registers
+    int lda;          // leading dimension of the work matrix
+    int rc;           // Givens pairs per chunk buffer
+    int vl;           // stride of the LDS vectors (>= 128, includes a 2-element front pad)
+    size_t lds_bytes;
+};
+
+constexpr int EIG_NVEC = 9;   // d, e, u, w, g, h, tdiag, uh0, uh1
+
+inline EigPlan eig_plan(int n, int ld)
+{
+    EigPlan pl {};
+    pl.vl = (((n > 128 ? n : 128) + 1) & ~1) + 2;
+    pl.reg_path = n <= 128 ? 1 : 0;
+    const size_t budget = 160 * 1024 - 1024;
+    const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
+    const size_t vecs = (size_t) (EIG_NVEC + (pl.reg_path ? 0 : 4)) * pl.vl * sizeof(double);
+    const int lda_lds = n | 1;
+    const size_t mat = (size_t) n * lda_lds * sizeof(double);
+    const size_t fixed = vecs + ints;
+    // the chunk buffers need room for at least one full QL sweep (n-1 pairs) each
+    if (fixed + mat + (size_t) 2 * n * 16 <= budget) {
+        pl.use_lds = 1;
+        pl.lda = lda_lds;
+        size_t rc = (budget - fixed - mat) / (2 * 16);
+        if (rc > 4096) rc = 4096;
+        pl.rc = (int) rc;
+        pl.lds_bytes = fixed + mat + (size_t) 2 * pl.rc * 16;
+    } else {
+        pl.use_lds = 0;
+        pl.lda = ld + 1;
+        pl.rc = 2048;
+        pl.lds_bytes = fixed + (size_t) 2 * pl.rc * 16;
+    }
+    return pl;
+}
+
+struct EigMat {
+    double *a;
+    int ld;
+    __device__ double& operator()(int i, int j) const { return a[(size_t) i * ld + j]; }
+};
+
+// wavefront sum on the cross-lane data path (DPP row rotations, then one readlane per
+// 16-lane row) instead of LDS permutes; every lane gets the same total, and the fixed
+// order makes it identical in every wavefront that sums the same values
+template<int CTRL>
+__device__ inline double eig_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double eig_readlane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double eig_wave_sum(double v)
+{
+    v += eig_dpp<0x128>(v);   // row_ror:8
+    v += eig_dpp<0x124>(v);   // row_ror:4
+    v += eig_dpp<0x122>(v);   // row_ror:2
+    v += eig_dpp<0x121>(v);   // row_ror:1
+    return ((eig_readlane(v, 0) + eig_readlane(v, 16)) + eig_readlane(v, 32))
+            + eig_readlane(v, 48);
+}
+
+// state of the QL recurrence, uniform across the producer wavefront
+struct QlState {
+    int l, m, need_m, done;
+    double f, tst1;
+};
+
+// Producer: advances the QL recurrence on (dv, ev), recording up to `rc` Givens pairs of
+// whole sweeps into `rot` (pair for column i of sweep q at rot[off_q + i - l_q]) and their
+// descriptors (l, m, off) into `desc`.  Executed by all 64 lanes of wavefront 0; lane 0
+// walks the recurrence, the other lanes help with the O(n) shift and the split search.
+__device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, double2 *rot,
+        int *desc, int rc, int lane)
+{
+    const double eps = 0x1.0p-52;
+    int count = 0, ns = 0;
+    while (!st.done) {
+        if (st.need_m) {
+            const double dl = dv[st.l], el = ev[st.l];
+            st.tst1 = fmax(st.tst1, fabs(dl) + fabs(el));
+            const double thr = eps * st.tst1;
+            int m = n;
+            for (int base = st.l; base < n; base += 64) {
+                const int idx = base + lane;
+                const bool ok = idx < n && fabs(ev[idx]) <= thr;
+                const unsigned long long mask = __ballot(ok);
+                if (mask) {
+                    m = base + __builtin_ctzll(mask);
+                    break;
+                }
+            }
+            st.m = m;
+            st.need_m = 0;
+            if (m >= n) {   // unreachable for finite input: e[n-1] == 0
+                st.done = 1;
+                break;
+            }
+            if (m == st.l) {
+                if (lane == 0) {
+                    dv[st.l] = dl + st.f;
+                    ev[st.l] = 0.;
+                }
+                st.l++;
+                st.need_m = 1;
+                if (st.l >= n) st.done = 1;
+                continue;
+            }
+        }
+        const int l = st.l, m = st.m, len = m - l;
+        if (count + len > rc || ns >= EIG_MAXSEQ) break;
+        const double thr = eps * st.tst1;
+
+        // implicit shift (cmaes.cpp:405-417)
+        const double g0 = dv[l], d1 = dv[l + 1], el = ev[l];
+        const double p0 = (d1 - g0) / (2. * el);
+        double r0 = hypot(p0, 1.);
+        r0 = p0 >= 0. ? fabs(r0) : -fabs(r0);
+        const double dl_new = el / (p0 + r0);
+        const double dl1 = el * (p0 + r0);
+        const double h0 = g0 - dl_new;
+        for (int i = l + 2 + lane; i < n; i += 64) dv[i] -= h0;
+        st.f += h0;
+
+        if (lane == 0) {
+            dv[l] = dl_new;
+            dv[l + 1] = dl1;
+            // implicit QL sweep (cmaes.cpp:419-449)
+            double pp = dv[m];
+            double cth = 1., c2 = 1., c3 = 1., s = 0., s2 = 0.;
+            const double el1 = ev[l + 1];
+            double ei = ev[m - 1], di = dv[m - 1];
+            double2 *out = rot + count;
+            for (int i = m - 1; i >= l; i--) {
+                // next column's (e, d): always a legal address (the vectors carry a front pad)
+                const double ein = ev[i - 1], din = dv[i - 1];
+                c3 = c2;
+                c2 = cth;
+                s2 = s;
+                const double g = cth * ei;
+                const double h = cth * pp;
+                const double t = fma(pp, pp, ei * ei);
+                // 1/sqrt(t): hardware estimate + one third-order correction (full fp64)
+                double y = __builtin_amdgcn_rsq(t);
+                const double err = fma(-t * y, y, 1.);
+                y = fma(y * err, fma(err, 0.375, 0.5), y);
+                const double r = t * y;             // = hypot(pp, ei) to rounding
+                ev[i + 1] = s * r;
+                s = ei * y;
+                cth = pp * y;
+                pp = fma(cth, di, -(s * g));
+                dv[i + 1] = h + s * fma(cth, g, s * di);
+                out[i - l] = make_double2(cth, s);
+                ei = ein;
+                di = din;
+            }
+            pp = -s * s2 * c3 * el1 * ev[l] / dl1;
+            ev[l] = s * pp;
+            dv[l] = cth * pp;
+        }
+        desc[3 * ns + 0] = l;
+        desc[3 * ns + 1] = m;
+        desc[3 * ns + 2] = count;
+        count += len;
+        ns++;
+        const double el_new = ev[l];
+        if (!(fabs(el_new) > thr)) {
+            if (lane == 0) {
+                dv[l] += st.f;
+                ev[l] = 0.;
+            }
+            st.l++;
+            st.need_m = 1;
+            if (st.l >= n) st.done = 1;
+        }
+    }
+    return ns;
+}
+
+// Consumer: applies the recorded sweeps to row k of the eigenvector matrix
+// (the inner k-loop of cmaes.cpp:438-443, one lane per k)
+__device__ inline void ql_apply_row(const EigMat &A, int k, const double2 *rot,
+        const int *desc, int ns)
+{
+    for (int q = 0; q < ns; q++) {
+        const int l = desc[3 * q], m = desc[3 * q + 1];
+        const int cb = desc[3 * q + 2] - l;               // rot[cb + i] = pair of column i
+        double hcur = A(k, m);
+        int i = m - 1;
+        for (; i - 3 >= l; i -= 4) {
+            const double x0 = A(k, i), x1 = A(k, i - 1), x2 = A(k, i - 2), x3 = A(k, i - 3);
+            const double2 r0 = rot[cb + i], r1 = rot[cb + i - 1], r2 = rot[cb + i - 2],
+                    r3 = rot[cb + i - 3];
+            A(k, i + 1) = r0.y * x0 + r0.x * hcur;
+            hcur = r0.x * x0 - r0.y * hcur;
+            A(k, i) = r1.y * x1 + r1.x * hcur;
+            hcur = r1.x * x1 - r1.y * hcur;
+            A(k, i - 1) = r2.y * x2 + r2.x * hcur;
+            hcur = r2.x * x2 - r2.y * hcur;
+            A(k, i - 2) = r3.y * x3 + r3.x * hcur;
+            hcur = r3.x * x3 - r3.y * hcur;
+        }
+        for (; i >= l; i--) {
+            const double x = A(k, i);
+            const double2 r = rot[cb + i];
+            A(k, i + 1) = r.y * x + r.x * hcur;
+            hcur = r.x * x - r.y * hcur;
+        }
+        A(k, l) = hcur;
+    }
+}
+
+
+// tred2 + reflector accumulation for n <= 128 with the matrix in REGISTERS: thread
+// (row j = tid >> 2, class q = tid & 3) owns A(j, k) for k = 32a + 8q + b (a < 4, b < 8);
+// LDS carries only the O(n) vectors (zero-padded beyond the active block, so the inner
+// loops need no bounds tests) and the stashed Householder vectors (column i of Astash).
+// Phase 2 rebuilds Q column-tiled (thread owns Q(k, j) for its 32 rows k of column j).
+__device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, const EigMat &As,
+        double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
+        double *uh0, double *uh1, int tid)
+{
+    const int T = EIG_THREADS, lane = tid & 63;
+    const int j = tid >> 2, q = tid & 3;
+    double a_[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int k = 32 * a + 8 * q + b;
+            a_[a][b] = (j < n && k < n) ? C[(size_t) j * ld + k] : 0.;
+        }
+    for (int x = tid; x < n * As.ld; x += T) As.a[x] = 0.;
+    for (int k = tid; k < 128; k += T) {
+        dv[k] = k < n ? C[(size_t) (n - 1) * ld + k] : 0.;
+        hvec[k] = 0.;
+    }
+
+    for (int i = n - 1; i > 0; i--) {
+        __syncthreads();
+        const double d0 = lane < i ? dv[lane] : 0.;
+        const double d1 = lane + 64 < i ? dv[lane + 64] : 0.;
+        const double scale = eig_wave_sum(fabs(d0) + fabs(d1));
+        if (scale == 0.) {
+            const double dprev = dv[i - 1];
+            __syncthreads();
+            if (tid == 0) {
+                ev[i] = dprev;
+                hvec[i] = 0.;
+            }
+            if (j == i - 1) {
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 8; b++) dv[32 * a + 8 * q + b] = a_[a][b];
+            }
+            continue;
+        }
+        const double u0 = d0 / scale, u1 = d1 / scale;
+        double h = eig_wave_sum(u0 * u0 + u1 * u1);
+        {
+            const double f = dv[i - 1] / scale;
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            h = h - f * g;
+            uv[lane] = lane < i ? (lane == i - 1 ? f - g : u0) : 0.;
+            uv[lane + 64] = lane + 64 < i ? (lane + 64 == i - 1 ? f - g : u1) : 0.;
+            if (tid == 0) ev[i] = scale * g;
+        }
+        // g = A u (no bounds tests: u is zero beyond the active block); this thread's 32
+        // entries of u stay in registers for the rank-2 update below
+        double ur[4][8];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                const double2 t2 = *reinterpret_cast<const double2*>(&uv[32 * a + 8 * q + b]);
+                ur[a][b] = t2.x;
+                ur[a][b + 1] = t2.y;
+            }
+        {
+            double acc = 0.;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) acc += a_[a][b] * ur[a][b];
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            if (q == 0 && j < i) {
+                gv[j] = acc;
+                As(j, i) = uv[j];
+            }
+        }
+        __syncthreads();
+        const double rh = 1. / h;
+        const double e0 = lane < i ? gv[lane] * rh : 0.;
+        const double e1 = lane + 64 < i ? gv[lane + 64] * rh : 0.;
+        const double uu0 = uv[lane], uu1 = uv[lane + 64];
+        const double hh = eig_wave_sum(e0 * uu0 + e1 * uu1) / (h + h);
+        wv[lane] = lane < i ? e0 - hh * uu0 : 0.;
+        wv[lane + 64] = lane + 64 < i ? e1 - hh * uu1 : 0.;
+        // A -= u w^T + w u^T; rows >= i and columns >= i see zeros and do not move
+        {
+            const double uj = uv[j], wj = wv[j];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b += 2) {
+                    const double2 w2 = *reinterpret_cast<const double2*>(&wv[32 * a + 8 * q + b]);
+                    a_[a][b] = a_[a][b] - (ur[a][b] * wj + w2.x * uj);
+                    a_[a][b + 1] = a_[a][b + 1] - (ur[a][b + 1] * wj + w2.y * uj);
+                }
+            if (j == i - 1) {
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 8; b++) dv[32 * a + 8 * q + b] = a_[a][b];
+            }
+        }
+        if (tid == 0) hvec[i] = h;
+    }
+    __syncthreads();
+    // diagonal of the tridiagonal matrix: A(j, j) as it stands
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if (32 * a + 8 * q + b == j && j < n) td[j] = a_[a][b];
+
+    // ---- phase 2: Q = H(n-1) ... H(1), column-tiled in registers, starting from I ----------
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) a_[a][b] = (32 * a + 8 * q + b == j) ? 1. : 0.;
+    for (int i = 0; i < n - 1; i++) {
+        const double h = hvec[i + 1];
+        double *uh = (i & 1) ? uh1 : uh0;
+        if (h != 0. && tid < 128) uh[tid] = tid < n ? As(tid, i + 1) / h : 0.;
+        __syncthreads();
+        if (h != 0.) {
+            double acc = 0.;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const int k = 32 * a + 8 * q + b;
+                    const double uk = k < n ? As(k, i + 1) : 0.;
+                    acc += uk * a_[a][b];
+                }
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b += 2) {
+                    const double2 h2 = *reinterpret_cast<const double2*>(&uh[32 * a + 8 * q + b]);
+                    a_[a][b] -= acc * h2.x;
+                    a_[a][b + 1] -= acc * h2.y;
+                }
+        }
+    }
+    __syncthreads();
+    if (j < n) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int k = 32 * a + 8 * q + b;
+                if (k < n) As(k, j) = a_[a][b];
+            }
+    }
+    for (int k = tid; k < n; k += T) dv[k] = td[k];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, EigPlan pl,
+        int force)
+{
+    const int p = blockIdx.x;
+    CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    // cmaes.cpp:233: skip until enough evaluations have passed
+    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
+        if (threadIdx.x == 0) sc->eigen_done = 0;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, T = EIG_THREADS, lane = tid & 63, wave = tid >> 6;
+    const int n = c.n, ld = c.ld, nv = pl.vl;
+    double *dv = lds + 2;         // diagonal / eigenvalues        (each vector: 2-element front pad)
+    double *ev = dv + nv;         // sub-diagonal
+    double *uv = ev + nv;         // Householder vector u / scaled reflector column
+    double *wv = uv + nv;         // w = (A u)/h - hh u
+    double *gv = wv + nv;         // A u, later sorted eigenvalues
+    double *hvec = gv + nv;       // h of every Householder step
+    double *td = hvec + nv;       // diagonal of the tridiagonal matrix
+    double *uh0 = td + nv, *uh1 = uh0 + nv;
+    double *part = uh1 + nv - 2;  // [4][nv] column partial sums (generic path only)
+    double2 *rot = reinterpret_cast<double2*>(part + (pl.reg_path ? 0 : 4 * nv));   // [2][rc]
+    int *ibuf = reinterpret_cast<int*>(rot + 2 * pl.rc);        // desc[2][MAXSEQ*3], nseq[2], done[2], misc
+    int *desc = ibuf;
+    int *nseq = ibuf + 2 * EIG_MAXSEQ * 3;
+    int *sdone = nseq + 2;
+    int *perm = reinterpret_cast<int*>(uv);                     // reused after QL
+    EigMat A { pl.use_lds ? reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8)
+                          : d.eig_work + (size_t) p * ld * pl.lda, pl.lda };
+    double *C = d.C + (size_t) p * ld * ld;
+
+#define EIG_STAMP(slot) do { if (d.stamps && p == 0 && tid == 0) d.stamps[slot] = wall_clock64(); } while (0)
+    EIG_STAMP(0);
+    if (tid < 2) {   // front pads read by the QL prefetch
+        dv[-1 - tid] = 0.;
+        ev[-1 - tid] = 0.;
+    }
+    if (pl.reg_path) {
+        eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, uh0, uh1, tid);
+    } else {
+    for (int i = wave; i < n; i += T / 64)
+        for (int j = lane; j < n; j += 64) A(i, j) = C[(size_t) i * ld + j];
+    for (int j = tid; j < n; j += T) dv[j] = C[(size_t) (n - 1) * ld + j];
+    EIG_STAMP(1);
+
+    // ---- Householder reduction (cmaes.cpp:293-356) -------------------------------------
+    // row tiling: 4 lanes per row; lane q of a row owns the columns k = 32a + 8q + b,
+    // which keeps the 32 lanes of an LDS access group on 32 different bank pairs
+    const int rq = tid & 3, rj0 = tid >> 2;
+    for (int i = n - 1; i > 0; i--) {
+        __syncthreads();
+        // every wavefront recomputes the norms of d[0..i) (= row i of the active matrix)
+        double sabs = 0.;
+        for (int k = lane; k < i; k += 64) sabs += fabs(dv[k]);
+        const double scale = eig_wave_sum(sabs);
+        if (scale == 0.) {
+            const double dprev = dv[i - 1];
+            __syncthreads();
+            if (tid == 0) {
+                ev[i] = dprev;
+                dv[i] = 0.;
+            }
+            for (int j = tid; j < i; j += T) {
+                dv[j] = A(i - 1, j);
+                A(i, j) = 0.;
+                A(j, i) = 0.;
+            }
+            continue;
+        }
+        double hsum = 0.;
+        for (int k = lane; k < i; k += 64) {
+            const double u = dv[k] / scale;
+            hsum += u * u;
+        }
+        double h = eig_wave_sum(hsum);
+        {
+            // every wavefront writes the SAME u (one store per element, no fix-up pass), so
+            // a wavefront may read what it wrote without waiting for the others
+            const double f = dv[i - 1] / scale;
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            h = h - f * g;
+            for (int k = lane; k < i; k += 64) uv[k] = (k == i - 1) ? f - g : dv[k] / scale;
+            if (tid == 0) ev[i] = scale * g;
+        }
+        // g = A u on the active block; stash u in column i
+        for (int j = rj0; j < i; j += T / 4) {
+            double acc = 0.;
+            for (int a = 0; a < i; a += 32) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const int k = a + 8 * rq + b;
+                    if (k < i) acc += A(j, k) * uv[k];
+                }
+            }
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            if (rq == 0) {
+                gv[j] = acc;
+                A(j, i) = uv[j];
+            }
+        }
+        __syncthreads();
+        // w = g/h - (g.u / 2h^2) u, recomputed by every wavefront
+        const double rh = 1. / h;
+        double fsum = 0.;
+        for (int k = lane; k < i; k += 64) fsum += (gv[k] * rh) * uv[k];
+        const double hh = eig_wave_sum(fsum) / (h + h);
+        for (int k = lane; k < i; k += 64) wv[k] = gv[k] * rh - hh * uv[k];
+        // A -= u w^T + w u^T (both halves, bitwise symmetric); row i-1 becomes the next d
+        for (int j = rj0; j < i; j += T / 4) {
+            const double uj = uv[j], wj = wv[j];
+            for (int a = 0; a < i; a += 32) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const int k = a + 8 * rq + b;
+                    if (k < i) {
+                        const double v = A(j, k) - (uv[k] * wj + wv[k] * uj);
+                        A(j, k) = v;
+                        if (j == i - 1) dv[k] = v;
+                    }
+                }
+            }
+            if (rq == 0) A(i, j) = 0.;
+        }
+        if (tid == 0) dv[i] = h;
+    }
+    __syncthreads();
+    EIG_STAMP(2);
+
+    // ---- accumulate the transformations (cmaes.cpp:358-381) -----------------------------
+    // column tiling: lane group q in 0..3 owns the rows k = q (mod 4) of column j
+    const int cq = tid >> 7, cj0 = tid & 127;
+    for (int i = 0; i < n - 1; i++) {
+        if (tid == 0) {
+            A(n - 1, i) = A(i, i);
+            A(i, i) = 1.;
+        }
+        const double h = dv[i + 1];
+        __syncthreads();
+        if (h != 0.) {
+            for (int j = cj0; j <= i; j += 128) {
+                double acc = 0.;
+                for (int k = cq; k <= i; k += 4) acc += A(k, i + 1) * A(k, j);
+                part[cq * nv + j] = acc;
+            }
+            if (cj0 == 0)
+                for (int k = cq; k <= i; k += 4) uv[k] = A(k, i + 1) / h;
+            __syncthreads();
+            for (int j = cj0; j <= i; j += 128) {
+                const double g = part[j] + part[nv + j] + part[2 * nv + j] + part[3 * nv + j];
+                for (int k = cq; k <= i; k += 4) A(k, j) -= g * uv[k];
+            }
+        }
+        // column i+1 is dead now (its reads happened before the barrier above)
+        if (cj0 == 127)
+            for (int k = cq; k <= i; k += 4) A(k, i + 1) = 0.;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += T) {
+        dv[j] = A(n - 1, j);
+        A(n - 1, j) = (j == n - 1) ? 1. : 0.;
+    }
+    __syncthreads();
+    }   // generic path
+    {   // tql2 prologue: shift the sub-diagonal down (cmaes.cpp:384-387); T >= n
+        const double t = (tid + 1 < n) ? ev[tid + 1] : 0.;
+        __syncthreads();
+        if (tid < n) ev[tid] = t;
+    }
+    __syncthreads();
+    EIG_STAMP(3);
+
+    // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
+    {
+        QlState st { 0, 0, 1, 0, 0., 0. };
+        int prev_done = 0;
+        for (int epoch = 0;; epoch++) {
+            const int cur = epoch & 1;
+            if (wave == 0) {
+                if (!prev_done) {
+                    const int ns = ql_produce(st, n, dv, ev, rot + (size_t) cur * pl.rc,
+                            desc + cur * EIG_MAXSEQ * 3, pl.rc, lane);
+                    if (lane == 0) {
+                        nseq[cur] = ns;
+                        sdone[cur] = st.done;
+                        if (d.stamps && p == 0) {   // diagnostic: sweeps and Givens pairs so far
+                            int pairs = 0;
+                            for (int q = 0; q < ns; q++)
+                                pairs += desc[cur * EIG_MAXSEQ * 3 + 3 * q + 1]
+                                        - desc[cur * EIG_MAXSEQ * 3 + 3 * q];
+                            d.stamps[8] = (epoch == 0 ? 0 : d.stamps[8]) + ns;
+                            d.stamps[9] = (epoch == 0 ? 0 : d.stamps[9]) + pairs;
+                            d.stamps[10] = epoch + 1;
+                        }
+                    }
+                }
+            } else if (epoch > 0) {
+                const int prv = cur ^ 1;
+                const int ns = nseq[prv];
+                if (!(d.dbg & 1))
+                for (int k = tid - 64; k < n; k += T - 64)
+                    ql_apply_row(A, k, rot + (size_t) prv * pl.rc, desc + prv * EIG_MAXSEQ * 3,
+                            ns);
+            }
+            __syncthreads();
+            if (prev_done) break;
+            prev_done = sdone[cur];
+        }
+    }
+    __syncthreads();
+    EIG_STAMP(4);
+
+    // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ---------
+    for (int j = tid; j < n; j += T) {
+        const double dj = dv[j];
+        int r = 0;
+        for (int k = 0; k < n; k++) {
+            const double dk = dv[k];
+            r += (dk < dj) || (dk == dj && k < j);
+        }
+        perm[j] = r;
+        gv[r] = dj;   // sorted eigenvalues
+    }
+    __syncthreads();
+    const double lo = gv[0], hi = gv[n - 1];
+    __syncthreads();
+    if (lo <= 0.) {
+        const double shift = fmax(hi, 0.) / 1e14;
+        for (int i = tid; i < n; i += T) {
+            gv[i] = fmax(gv[i], 0.) + shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+        __syncthreads();
+    }
+    const double lo2 = gv[0], hi2 = gv[n - 1];
+    __syncthreads();
+    if (hi2 > 1e14 * lo2) {
+        const double shift = hi2 / 1e14 - lo2;
+        for (int i = tid; i < n; i += T) {
+            gv[i] += shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+        __syncthreads();
+    }
+    double *Dp = d.D + (size_t) p * ld;
+    double *Bp = d.B + (size_t) p * ld * ld;
+    for (int i = tid; i < ld; i += T) Dp[i] = i < n ? sqrt(gv[i]) : 1.;
+    for (int k = wave; k < n; k += T / 64)
+        for (int j = lane; j < n; j += 64) Bp[(size_t) k * ld + perm[j]] = A(k, j);
+    if (tid == 0) {
+        sc->eigenlastev = sc->fev;
+        sc->eigen_done = 1;
+    }
+    EIG_STAMP(5);
+#undef EIG_STAMP
+}
+
+} // namespace bbo

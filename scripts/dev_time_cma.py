@@ -12,3 +12,11 @@ alg.initialize(b.objectives.rosenbrock,-10*np.ones(n),10*np.ones(n),g)
 alg.run(20)
 t=time.time(); d=alg.run(gens); dt=time.time()-t
 print("n",n,"lam",lam,"P",P,"gens",d,"ms/gen",1e3*dt/d,"evals/s %.3e"%(P*lam*d/dt), "sigma",alg.get_state("sigma")[0], "fbest", alg.get_state("fit_val")[0])
+alg.set_state("eig_stamps",[1.0])
+alg.run(3)
+t=alg.get_state("eig_stamps")
+print("eigen phases (us at 100MHz): load %.1f tred %.1f accum %.1f ql %.1f sort/out %.1f" % tuple((t[i+1]-t[i])/100. for i in range(5)))
+alg.set_state("dbg",[1.0]); alg.run(3)
+t=alg.get_state("eig_stamps")
+print("dbg=1 (no apply): tred+accum %.1f ql %.1f" % ((t[3]-t[0])/100., (t[4]-t[3])/100.))
+print("sweeps %d pairs %d epochs %d" % (t[8], t[9], t[10]))
