@@ -14,6 +14,9 @@ namespace bbo {
 
 namespace {
 
+// kernel slots of the profile report (bbo_get "profile"), in launch order
+enum { K_SAMPLE = 0, K_RANK, K_WHITEN, K_GRAM, K_PATHS, K_COV, K_EIGEN, K_POST, K_STOP, K_COUNT };
+
 int pick_maxt(int ld)
 {
     const int per_wave = ((ld >> 4) + 3) / 4;
@@ -250,12 +253,14 @@ void CmaEngine::launch_sample_eval()
     const CmaConst &c = c_;
     dim3 grid(c.lambda_pad / 16, c.npop);
     const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
+    timer_.begin(stream_, K_SAMPLE);
     switch (pick_maxt(c.ld)) {
     case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
     case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;
     case 4: hipLaunchKernelGGL(cma_sample_eval<4>, grid, dim3(256), lds, stream_, d_, c_); break;
     default: hipLaunchKernelGGL(cma_sample_eval<8>, grid, dim3(256), lds, stream_, d_, c_); break;
     }
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
 
@@ -263,7 +268,9 @@ void CmaEngine::launch_rank()
 {
     const CmaConst &c = c_;
     dim3 grid((c.lambda + 31) / 32, c.npop);
+    timer_.begin(stream_, K_RANK);
     hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
 
@@ -273,12 +280,14 @@ void CmaEngine::launch_update()
     if (c.variant == 1) {
         dim3 grid(c.mu_pad / 16, c.npop);
         const size_t lds = (size_t) (16 * (c.ld + 2) + 64) * sizeof(double);
+        timer_.begin(stream_, K_WHITEN);
         switch (pick_maxt(c.ld)) {
         case 1: hipLaunchKernelGGL(cma_whiten<1>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 2: hipLaunchKernelGGL(cma_whiten<2>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 4: hipLaunchKernelGGL(cma_whiten<4>, grid, dim3(256), lds, stream_, d_, c_); break;
         default: hipLaunchKernelGGL(cma_whiten<8>, grid, dim3(256), lds, stream_, d_, c_); break;
         }
+        timer_.end(stream_);
         BBO_HIP(hipGetLastError());
     }
     {
@@ -292,15 +301,21 @@ void CmaEngine::launch_update()
                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
             attr_done = true;
         }
+        timer_.begin(stream_, K_GRAM);
         hipLaunchKernelGGL(cma_gram, grid, dim3(256), lds, stream_, d_, c_, ldy);
+        timer_.end(stream_);
         BBO_HIP(hipGetLastError());
     }
+    timer_.begin(stream_, K_PATHS);
     hipLaunchKernelGGL(cma_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     {
         const int total = c.n * (c.n + 1) / 2;
         dim3 grid((total + 255) / 256, c.npop);
+        timer_.begin(stream_, K_COV);
         hipLaunchKernelGGL(cma_cov, grid, dim3(256), 0, stream_, d_, c_);
+        timer_.end(stream_);
         BBO_HIP(hipGetLastError());
     }
 }
@@ -315,17 +330,23 @@ void CmaEngine::launch_eigen()
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_done = true;
     }
+    timer_.begin(stream_, K_EIGEN);
     hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
             c_, pl, 0);
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     dim3 grid(c.ld / 16, c.ld / 16, c.npop);
+    timer_.begin(stream_, K_POST);
     hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 0);
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
 
 void CmaEngine::launch_history_stop()
 {
+    timer_.begin(stream_, K_STOP);
     hipLaunchKernelGGL(cma_history_stop, dim3(c_.npop), dim3(64), 0, stream_, d_, c_);
+    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
 
@@ -399,6 +420,7 @@ void CmaEngine::iterate()
     BBO_HIP(hipSetDevice(params_.device));
     generation(false);
     BBO_HIP(hipStreamSynchronize(stream_));
+    timer_.collect();
 }
 
 void CmaEngine::fetch_scal(std::vector<CmaScal> &out)
@@ -440,6 +462,7 @@ int CmaEngine::run(int max_generations)
         const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
         for (int g = 0; g < chunk; g++) generation(true);
         BBO_HIP(hipStreamSynchronize(stream_));
+        timer_.collect();
         done += chunk;
     }
     return done;
@@ -626,6 +649,7 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
         if (out && cap >= (int) cnt) zrecord_.download(out, cnt, p * cnt);
         return (int) cnt;
     }
+    if (k == "profile") return timer_.report(out, cap);
     if (k == "eig_stamps") {
         if (!stamps_.p) return 0;
         if (out && cap >= 16) {
@@ -724,6 +748,10 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         BBO_HIP(hipGetLastError());
         BBO_HIP(hipStreamSynchronize(stream_));
         return r;
+    }
+    if (k == "profile") {
+        timer_.enable(in[0] != 0., K_COUNT);
+        return 1;
     }
     if (k == "dbg") {
         d_.dbg = (int) in[0];

@@ -121,6 +121,7 @@ private:
     DevBuf<long long> stamps_;
     DevBuf<CmaScal> scal_;
     int *stop_host_ = nullptr;   // pinned
+    KernelTimer timer_;
 };
 
 } // namespace bbo

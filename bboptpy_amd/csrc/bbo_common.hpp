@@ -74,6 +74,73 @@ struct DevBuf {
     }
 };
 
+// Per-kernel device timing with HIP events on the engine's own stream (bench.py's
+// roofline leg): disabled by default; when enabled every launch is bracketed by an event
+// pair, collect() (after a stream sync) folds the elapsed times into per-kernel totals.
+class KernelTimer {
+public:
+    ~KernelTimer()
+    {
+        for (auto &e : pool_) {
+            (void) hipEventDestroy(e.a);
+            (void) hipEventDestroy(e.b);
+        }
+    }
+    void enable(bool on, int nslots)
+    {
+        on_ = on;
+        ms_.assign(nslots, 0.);
+        calls_.assign(nslots, 0);
+        used_ = 0;
+    }
+    bool on() const { return on_; }
+    void begin(hipStream_t st, int slot)
+    {
+        if (!on_) return;
+        if (used_ == pool_.size()) {
+            Pair p;
+            BBO_HIP(hipEventCreate(&p.a));
+            BBO_HIP(hipEventCreate(&p.b));
+            pool_.push_back(p);
+        }
+        pool_[used_].slot = slot;
+        BBO_HIP(hipEventRecord(pool_[used_].a, st));
+    }
+    void end(hipStream_t st)
+    {
+        if (!on_) return;
+        BBO_HIP(hipEventRecord(pool_[used_].b, st));
+        used_++;
+    }
+    void collect()   // call after the stream has been synchronised
+    {
+        for (size_t i = 0; i < used_; i++) {
+            float ms = 0.f;
+            BBO_HIP(hipEventElapsedTime(&ms, pool_[i].a, pool_[i].b));
+            ms_[pool_[i].slot] += ms;
+            calls_[pool_[i].slot]++;
+        }
+        used_ = 0;
+    }
+    int report(double *out, int cap) const   // [ms0, calls0, ms1, calls1, ...]
+    {
+        const int cnt = 2 * (int) ms_.size();
+        if (out && cap >= cnt)
+            for (size_t i = 0; i < ms_.size(); i++) {
+                out[2 * i] = ms_[i];
+                out[2 * i + 1] = calls_[i];
+            }
+        return cnt;
+    }
+private:
+    struct Pair { hipEvent_t a, b; int slot; };
+    std::vector<Pair> pool_;
+    std::vector<double> ms_;
+    std::vector<long> calls_;
+    size_t used_ = 0;
+    bool on_ = false;
+};
+
 // how the population's fitness is obtained
 struct ObjectiveSpec {
     int kind = BBO_OBJECTIVE_BUILTIN;

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-generation hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A *step* is one generation (sample -> evaluate -> rank -> update) of every population the
+GPU holds.  Metric (BASELINE.json): candidate-evaluations per second.
+
+Workloads (BASELINE.json configs; `--workload`):
+  M   ActiveCMAES n=128 lambda=4096 Rosenbrock      <- the metric config (default)
+  C3  ActiveCMAES n=128 lambda=1024 Rosenbrock
+  C2  L-SHADE     n=128 np=4096    Rastrigin
+  C4  APSO        n=512 np=65536   Sphere
+`--populations P` independent populations of that exact shape are advanced in lockstep on
+each GPU (population p uses Philox sub-stream p).  P = 1 is the strict single-run reading of
+the config; the JSON line always carries BOTH the aggregate over P (`value`) and a
+single-population measurement (`single_population`).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs the same
+shape with different seeds, no data-path collective (weak scaling); the time is the MAX over
+ranks between two barriers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix peak (AMD datasheet; the guide's
+                            # table stops at fp32: 157.3 TF, fp64 is half of it)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.)),
+    "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.)),
+    "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12)),
+    "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.)),
+}
+
+CMA_KERNELS = ["cma_sample_eval", "cma_rank", "cma_whiten", "cma_gram", "cma_paths", "cma_cov",
+               "cma_eigen", "cma_post", "cma_history_stop"]
+
+
+def cma_kernel_costs(n, lam, P):
+    """algorithmic work of ONE launch (all P populations), SURVEY.md section 8d:
+    flops for the MFMA-bound kernels, bytes for the bandwidth-bound ones"""
+    mu = lam // 2
+    return {
+        "cma_sample_eval": ("mfma", P * lam * (2 * n * n + 8 * n)),
+        "cma_whiten": ("mfma", P * mu * 2 * n * n),
+        "cma_gram": ("mfma", P * lam * 2 * n * n),
+        "cma_eigen": ("mfma", P * 9 * n ** 3),
+        "cma_post": ("mfma", P * 2 * n ** 3),
+        "cma_rank": ("hbm", P * lam * 16),
+        "cma_paths": ("hbm", P * 8 * (n * n + 8 * n)),
+        "cma_cov": ("hbm", P * 8 * 2 * (n * (n + 1) // 2)),
+        "cma_history_stop": ("hbm", P * 8 * 4 * n),
+    }
+
+
+def make_optimizer(bb, wl, P, seed, device):
+    huge = 2 ** 31 - 1
+    a = wl["algo"]
+    if a == "ActiveCMAES":
+        # tol = 0: TolHistFun / TolX can never fire inside the timed region
+        return bb.ActiveCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
+                              populations=P)
+    if a == "SHADE":
+        return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
+                        device=device, populations=P)
+    if a == "APSO":
+        return bb.APSO(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device, populations=P)
+    raise ValueError(a)
+
+
+def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
+    n = wl["n"]
+    lo = wl["box"][0] * np.ones(n)
+    up = wl["box"][1] * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(wl["box"][0], wl["box"][1], (P, n))
+    alg = make_optimizer(bb, wl, P, seed, device)
+    alg.initialize(getattr(bb.objectives, wl["objective"]), lo, up, guess)
+    if warmup > 0:
+        assert alg.run(warmup) == warmup
+    if profile:
+        alg.set_state("profile", [1.0])
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    done = alg.run(steps)
+    dt = time.perf_counter() - t0
+    if barrier:
+        barrier()
+    assert done == steps, "a population stopped inside the timed region (%d of %d)" % (done,
+                                                                                       steps)
+    prof = alg.get_state("profile") if profile else None
+    fev = alg.get_state("fev")[0]
+    return dt, prof, fev, alg
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """the same workload on ONE host core: the real reference when oracle/_ref travelled
+    here, else the oracle restatement (a port)"""
+    import pyoracle as po
+    lib = po.reference()
+    kind = "reference" if lib is not None else "port"
+    if lib is None:
+        lib = po.oracle()
+    n, lam = wl["n"], wl["np"]
+    lo, up = wl["box"][0] * np.ones(n), wl["box"][1] * np.ones(n)
+    guess = np.random.default_rng(1).uniform(wl["box"][0], wl["box"][1], n)
+    lib.seed(1)
+    a = wl["algo"]
+    if a == "ActiveCMAES":
+        h = po.cma(lib, "active", 2 ** 31 - 1, 0., lam)
+    elif a == "SHADE":
+        h = po.shade(lib, 2 ** 31 - 1, lam, 0., npmin=lam)
+    else:
+        h = po.apso(lib, 2 ** 31 - 1, 0., lam)
+    h.init(wl["objective"], lo, up, guess)
+    fev0 = h.scalar("fev")
+    gens = 0
+    t0 = time.perf_counter()
+    while True:
+        h.iterate()
+        gens += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or gens >= 200:
+            break
+    evals = h.scalar("fev") - fev0
+    return {"value": evals / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
+            "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s" % (
+                gens, a, n, lam, wl["objective"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="M", choices=sorted(WORKLOADS))
+    ap.add_argument("--populations", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    barrier = None
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+    import bboptpy_amd as bb
+
+    wl = WORKLOADS[args.workload]
+    P = args.populations
+    dt, prof, _, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
+                             profile=True, barrier=barrier)
+    if world > 1:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_evals = world * P * wl["np"] * args.steps
+    value = total_evals / dt
+
+    out = None
+    if rank == 0:
+        # per-kernel device time (HIP events on the engine's stream) -> roofline
+        names = CMA_KERNELS if wl["algo"] == "ActiveCMAES" else []
+        kernels = {}
+        if prof is not None and names:
+            costs = cma_kernel_costs(wl["n"], wl["np"], P)
+            for i, name in enumerate(names):
+                ms, calls = prof[2 * i], prof[2 * i + 1]
+                if calls <= 0:
+                    continue
+                bound, work = costs[name]
+                avg_s = ms * 1e-3 / calls
+                if bound == "mfma":
+                    ach, peak, unit = work / avg_s / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
+                else:
+                    ach, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+                kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
+                                 "achieved": ach, "peak": peak, "unit": unit,
+                                 "frac": ach / peak}
+            tot = sum(k["share"] for k in kernels.values())
+            for k in kernels.values():
+                k["share"] = k["share"] / tot
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["share"])
+            kd = kernels[dom]
+            roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"],
+                        "peak": kd["peak"], "unit": kd["unit"], "frac": kd["frac"],
+                        "traffic": None, "avg_us": kd["avg_us"], "time_share": kd["share"]}
+        single = None
+        if P != 1 and world == 1:
+            dt1, _, _, _ = measure(bb, wl, 1, max(10, args.steps // 2), 5, 77, local_rank,
+                                   profile=False)
+            s1 = max(10, args.steps // 2)
+            single = {"value": wl["np"] * s1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
+                      "unit": "candidate-evals/s"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(wl)
+        out = {
+            "metric": "candidate-evals/sec", "value": value, "unit": "candidate-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s n=%d np=%d %s, %d independent populations per GPU "
+                                   "in lockstep" % (wl["algo"], wl["n"], wl["np"],
+                                                    wl["objective"], P),
+                       "populations_per_gpu": P, "n": wl["n"], "np": wl["np"],
+                       "objective": wl["objective"], "box": list(wl["box"])},
+            "single_population": single,
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
