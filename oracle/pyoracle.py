@@ -132,8 +132,10 @@ class _Lib:
             f("philox_normals").argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, _dp]
             f("philox_normals").restype = None
             if hasattr(L, p + "pop_set_mode"):
-                f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64]
+                f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
                 f("pop_set_mode").restype = None
+                f("restart_set_rng").argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+                f("restart_set_rng").restype = None
 
     def f(self, name):
         return getattr(self.lib, self.p + name)
@@ -216,7 +218,13 @@ class Handle:
         self.lib.f("cma_" + name)(self.ptr, *args)
 
     def set_mode(self, sync, rng_mode=RNG_MT, seed=0):
-        self.lib.f("pop_set_mode")(self.ptr, 1 if sync else 0, rng_mode, seed)
+        """SHADE / JADE / APSO: async (reference) or sync (device) semantics + generator;
+        restart drivers: generator of the driver and of its inner CMA"""
+        if self.alg in ("bipop", "ipop"):
+            self.lib.f("restart_set_rng")(self.ptr, rng_mode, seed)
+        else:
+            self.lib.f("pop_set_mode")(self.ptr, 1 if self.alg == "apso" else 0,
+                                        1 if sync else 0, rng_mode, seed)
 
     def destroy(self):
         if self.ptr:

@@ -1,0 +1,111 @@
+"""The CPU oracle against the REAL reference, live (development container only: needs
+oracle/_ref/libbbo_ref.so; skipped elsewhere).  Wider than the committed fixtures: several
+shapes, objectives and seeds, every generation compared bit for bit."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+
+def _same(a, b, keys, tag):
+    for k in keys:
+        np.testing.assert_array_equal(a.get(k), b.get(k), err_msg="%s: %s" % (tag, k))
+
+
+@pytest.mark.parametrize("variant", ["active", "cmaes"])
+@pytest.mark.parametrize("n,lam,obj", [(10, 20, "rosenbrock"), (5, 8, "sphere"),
+                                       (24, 40, "rastrigin"), (13, 17, "ackley")])
+def test_cma_bit_exact(oracle_lib, ref_lib, variant, n, lam, obj):
+    oracle_lib.seed(21)
+    ref_lib.seed(21)
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(n).uniform(-5, 5, n)
+    o = po.cma(oracle_lib, variant, 4000 * lam, 1e-8, lam)
+    r = po.cma(ref_lib, variant, 4000 * lam, 1e-8, lam)
+    o.init(obj, lo, up, guess)
+    r.init(obj, lo, up, guess)
+    for it in range(150):
+        o.iterate()
+        r.iterate()
+        _same(o, r, ("xmean", "sigma", "C", "B", "D", "invsqrtC", "pc", "ps", "arx", "fit_val",
+                     "fit_idx"), "%s n=%d it=%d" % (variant, n, it))
+        fo, fr = o.converged(), r.converged()
+        assert fo == fr
+        if fo:
+            break
+
+
+def test_cma_bound_and_lazy_eigen(oracle_lib, ref_lib):
+    """bound=True clipping (cmaes.cpp:74-77,93-95) and the lazy eigen schedule of plain CMAES
+    at small lambda (cmaes.cpp:48,233)"""
+    n, lam = 20, 8
+    oracle_lib.seed(2)
+    ref_lib.seed(2)
+    lo, up = -1. * np.ones(n), 2. * np.ones(n)
+    guess = 1.9 * np.ones(n)
+    o = po.cma(oracle_lib, "cmaes", 40000, 1e-10, lam, sigma0=1., bound=True)
+    r = po.cma(ref_lib, "cmaes", 40000, 1e-10, lam, sigma0=1., bound=True)
+    o.init("rosenbrock", lo, up, guess)
+    r.init("rosenbrock", lo, up, guess)
+    skipped = 0
+    for it in range(120):
+        o.iterate()
+        r.iterate()
+        _same(o, r, ("xmean", "sigma", "C", "B", "D", "arx", "eigenlastev"), "it=%d" % it)
+        skipped += int(o.scalar("eigen_done") == 0)
+    assert skipped > 0
+    assert o.get("arx").max() <= 2. and o.get("arx").min() >= -1.
+
+
+@pytest.mark.parametrize("algo,kw,keys", [
+    ("shade", dict(mfev=6000, npinit=30, tol=1e-8), ("x", "f", "arch", "MCR", "MF", "k", "np", "fev")),
+    ("shade", dict(mfev=3000, npinit=20, tol=1e-8, archive=False, repaircr=False, h=5, npmin=6),
+     ("x", "f", "MCR", "MF", "k", "np", "fev")),
+    ("jade", dict(mfev=6000, np_=25, tol=1e-8), ("x", "f", "arch", "mucr", "muf", "fev")),
+    ("jade", dict(mfev=3000, np_=20, tol=1e-8, archive=False, repaircr=False, pelite=0.2),
+     ("x", "f", "mucr", "muf", "fev")),
+    ("apso", dict(mfev=6000, tol=1e-8, np_=15), ("x", "v", "xb", "f", "fb", "xbest", "fbest", "w",
+                                                 "c1", "c2", "state", "it", "fev")),
+    ("apso", dict(mfev=6000, tol=1e-8, np_=10, correct=False), ("x", "v", "f", "xbest", "fbest",
+                                                                "state", "fev")),
+])
+@pytest.mark.parametrize("obj", ["rastrigin", "rosenbrock", "griewank"])
+def test_de_pso_bit_exact(oracle_lib, ref_lib, algo, kw, keys, obj):
+    n = 9
+    oracle_lib.seed(33)
+    ref_lib.seed(33)
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    o = getattr(po, algo)(oracle_lib, **kw)
+    r = getattr(po, algo)(ref_lib, **kw)
+    o.init(obj, lo, up, np.zeros(n))
+    r.init(obj, lo, up, np.zeros(n))
+    _same(o, r, keys, "%s init" % algo)
+    for it in range(100):
+        o.iterate()
+        r.iterate()
+        if algo == "apso" and not (0 <= r.scalar("state") <= 4):
+            break   # the reference indexed past its rule table (apso.cpp:384): undefined
+        _same(o, r, keys, "%s it=%d" % (algo, it))
+        if r.scalar("fev") >= kw["mfev"]:
+            break
+    xo, fo, co = o.solution()
+    xr, fr, cr = r.solution()
+    if algo != "apso" or 0 <= r.scalar("state") <= 4:
+        np.testing.assert_array_equal(xo, xr)
+        assert (fo, co) == (fr, cr)
+
+
+@pytest.mark.parametrize("driver", ["bipop", "ipop"])
+@pytest.mark.parametrize("variant", ["active", "cmaes"])
+def test_restart_drivers_bit_exact(oracle_lib, ref_lib, driver, variant):
+    n = 5
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(8).uniform(-5, 5, n)
+    oracle_lib.seed(44)
+    ref_lib.seed(44)
+    o = getattr(po, driver)(oracle_lib, po.cma(oracle_lib, variant, 1, 1e-6, 4), 40000)
+    r = getattr(po, driver)(ref_lib, po.cma(ref_lib, variant, 1, 1e-6, 4), 40000)
+    xo, fo, _ = o.optimize("rastrigin", lo, up, guess)
+    xr, fr, _ = r.optimize("rastrigin", lo, up, guess)
+    np.testing.assert_array_equal(xo, xr)
+    assert fo == fr
