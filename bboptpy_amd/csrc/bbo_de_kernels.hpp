@@ -1,0 +1,544 @@
+// bbo_de_kernels.hpp -- one L-SHADE / JADE generation as gfx950 kernels.
+//
+//   kernel          reference lines it replaces                               bound
+//   de_init         shade.cpp:77-93 / jade.cpp:84-95 (uniform population)      HBM (8n B/ind.)
+//   de_generation   shade.cpp:98-184 / jade.cpp:104-178 (the i-loop, fused)    HBM: 4 row reads + 1
+//                                                                              row write = 40n+16 B
+//   de_bookkeep     archive :164-172, success memory :188-212 / jade :180-205  latency (1 WG)
+//   de_archive_copy archive row copies                                         HBM (16n B/success)
+//   de_rank         std::sort shade.cpp:215 / jade.cpp:101                     L2 (np^2 compares)
+//   de_finish       LPSR :218-225, archive trim :228-235, stop test :258-275   latency (1 WG)
+//
+// 16 lanes share one individual; lane g owns the coordinate PAIRS g, g+16, ... so every row
+// access is a 16-byte-per-lane coalesced stream.  No MFMA: the path is byte-bound.
+#pragma once
+
+#include "bbo_de.hpp"
+#include "bbo_objectives.hpp"
+#include "bbo_rng.hpp"
+
+namespace bbo {
+
+#define BBO_INF_D (__builtin_huge_val())
+constexpr double DE_PI = 3.14159265358979323846;
+constexpr int DE_MAX_TRIES = 64;
+
+__device__ inline bool de_frozen(const DeConst &c, const DeScal *sc)
+{
+    return c.honor_stop && sc->stop != 0;
+}
+
+template<int G>
+__device__ inline double group_sum_d(double v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// initial population: x = lb + u (ub - lb), f = objective(x)
+// grid (ceil(npinit/16), P), 256 threads; dynamic LDS 16 * ld doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void de_init(DeDev d, DeConst c)
+{
+    const int p = blockIdx.y;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r;
+    const int ld = c.ld;
+    double *row = lds + r * ld;
+    double *X = d.X[0] + (size_t) p * c.npinit * ld;
+    double ssq = 0.;
+    if (i < c.npinit) {
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, 0,
+                    stream_word(STREAM_INIT, (uint32_t) p));
+            double2 v = make_double2(0., 0.);
+            const int j = 2 * pj;
+            if (j < c.n) v.x = u01(w.x, w.y) * (d.upper[j] - d.lower[j]) + d.lower[j];
+            if (j + 1 < c.n) v.y = u01(w.z, w.w) * (d.upper[j + 1] - d.lower[j + 1]) + d.lower[j + 1];
+            *reinterpret_cast<double2*>(&row[j]) = v;
+            *reinterpret_cast<double2*>(&X[(size_t) i * ld + j]) = v;
+            ssq += v.x * v.x + v.y * v.y;
+        }
+    }
+    __syncthreads();
+    ssq = group_sum_d<16>(ssq);
+    if (c.obj >= 0) {
+        double f = eval_row_group<16>(c.obj, c.n, row, d.aux, g);
+        if (g == 0 && i < c.npinit) {
+            if (f != f) f = BBO_INF_D;
+            d.f[0][(size_t) p * c.npinit + i] = f;
+        }
+    }
+    if (g == 0 && i < c.npinit) d.radius[(size_t) p * c.npinit + i] = sqrt(ssq);
+}
+
+// ---------------------------------------------------------------------------
+// rank of f[which] over the first np individuals (stable in the row index)
+// grid (ceil(np_launch/32), P), 256 threads = 32 individuals x 8 slices
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void de_rank(DeDev d, DeConst c, int which_next)
+{
+    const int p = blockIdx.y;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    const int np = sc->np;
+    const int which = which_next ? (sc->cur ^ 1) : sc->cur;
+    const int tid = threadIdx.x;
+    const int cand = blockIdx.x * 32 + (tid >> 3), slice = tid & 7;
+    const double *f = d.f[which] + (size_t) p * c.npinit;
+    const bool live = cand < np;
+    const double fi = live ? f[cand] : BBO_INF_D;
+    int cnt = 0;
+    for (int j = slice; j < np; j += 8) {
+        const double fj = f[j];
+        cnt += (fj < fi) || (fj == fi && j < cand);
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 8);
+    if (live && slice == 0) {
+        d.rank[(size_t) p * c.npinit + cand] = cnt;
+        d.order[(size_t) p * c.npinit + cnt] = cand;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the fused generation.  grid (ceil(np_launch/16), P), 256 threads; LDS 16 * ld doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
+{
+    const int p = blockIdx.y;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r;
+    const int ld = c.ld, n = c.n, np = sc->np, larch = sc->larch, gen = sc->gen, cur = sc->cur;
+    const bool live = i < np;
+    double *trial = lds + r * ld;
+    const size_t pbase = (size_t) p * c.npinit;
+    const double *Xc = d.X[cur] + pbase * ld;
+    double *Xn = d.X[cur ^ 1] + pbase * ld;
+    const double *fc = d.f[cur] + pbase;
+    const int *order = d.order + pbase;
+    const uint32_t sub = (uint32_t) p;
+
+    // ---- per-individual draws (lane 0 of the group), shade.cpp:105-131 / jade.cpp:107-133 --
+    double CR = 0., F = 0.;
+    int ibest = 0, r1 = 0, r2 = 0, jrand = 0;
+    if (live && g == 0) {
+        double z0, z1;
+        normal_pair(c.seed, (uint32_t) i, 0, (uint32_t) gen, stream_word(STREAM_DE_PARAM, sub),
+                z0, z1);
+        u32x4 w = philox4x32_10(c.seed, (uint32_t) i, 1, (uint32_t) gen,
+                stream_word(STREAM_DE_PARAM, sub));
+        const int ri = uint_below(w.x, c.h);
+        jrand = uint_below(w.y, n);
+        const double up = u01(w.z, w.w);
+        const double mcr = c.variant == 0 ? d.MCR[(size_t) p * c.h + ri] : sc->mucr;
+        const double mf = c.variant == 0 ? d.MF[(size_t) p * c.h + ri] : sc->muf;
+        CR = fmax(0., fmin(z0 * 0.1 + mcr, 1.));
+        bool got = false;
+        for (int t = 0; t < DE_MAX_TRIES && !got; t++) {
+            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (16 + t), (uint32_t) gen,
+                    stream_word(STREAM_DE_PARAM, sub));
+            F = fmin(1., tan(DE_PI * (u01(w.x, w.y) - 0.5)) * 0.1 + mf);
+            got = c.variant == 0 ? (F > 0.) : !(F < 0.);
+        }
+        if (!got) F = fmax(1e-8, fmin(1., mf));
+        int nelite;
+        if (c.variant == 0) {
+            const double plo = fmin(2. / n, 0.2);
+            const double pi = up * (0.2 - plo) + plo;
+            nelite = max(1, (int) (pi * np));
+        } else {
+            nelite = max(1, (int) (c.pelite * np));
+        }
+        w = philox4x32_10(c.seed, (uint32_t) i, 2, (uint32_t) gen,
+                stream_word(STREAM_DE_PARAM, sub));
+        ibest = uint_below(w.x, nelite);
+        r1 = (i + 1) % np;
+        for (int t = 0; t < DE_MAX_TRIES; t++) {
+            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (96 + t), (uint32_t) gen,
+                    stream_word(STREAM_DE_PARAM, sub));
+            const int cnd = uint_below(w.x, np);
+            if (cnd != i) {
+                r1 = cnd;
+                break;
+            }
+        }
+        r2 = -1;
+        for (int t = 0; t < DE_MAX_TRIES; t++) {
+            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (160 + t), (uint32_t) gen,
+                    stream_word(STREAM_DE_PARAM, sub));
+            const int cnd = uint_below(w.x, np + larch);
+            if (cnd != i && cnd != r1) {
+                r2 = cnd;
+                break;
+            }
+        }
+        if (r2 < 0) {
+            r2 = 0;
+            while (r2 == i || r2 == r1) r2++;
+        }
+    }
+    CR = __shfl(CR, 0, 16);
+    F = __shfl(F, 0, 16);
+    ibest = __shfl(ibest, 0, 16);
+    r1 = __shfl(r1, 0, 16);
+    r2 = __shfl(r2, 0, 16);
+    jrand = __shfl(jrand, 0, 16);
+
+    // ---- mutation + binomial crossover + midpoint bound repair, into LDS ------------------
+    double cnt = 0.;
+    const double *xi = nullptr;
+    if (live) {
+        xi = Xc + (size_t) order[i] * ld;
+        const double *xb = Xc + (size_t) order[ibest] * ld;
+        const double *x1 = Xc + (size_t) order[r1] * ld;
+        const double *x2 = r2 >= np ? d.arch + (pbase + (r2 - np)) * ld
+                                    : Xc + (size_t) order[r2] * ld;
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const int j = 2 * pj;
+            const double2 a = *reinterpret_cast<const double2*>(&xi[j]);
+            const double2 b = *reinterpret_cast<const double2*>(&xb[j]);
+            const double2 q1 = *reinterpret_cast<const double2*>(&x1[j]);
+            const double2 q2 = *reinterpret_cast<const double2*>(&x2[j]);
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen,
+                    stream_word(STREAM_DE_CROSS, sub));
+            double2 v = a;
+            if (j < n && (j == jrand || u01(w.x, w.y) < CR)) {
+                v.x = a.x + F * (b.x - a.x) + F * (q1.x - q2.x);
+                cnt += 1.;
+            }
+            if (j + 1 < n && (j + 1 == jrand || u01(w.z, w.w) < CR)) {
+                v.y = a.y + F * (b.y - a.y) + F * (q1.y - q2.y);
+                cnt += 1.;
+            }
+            if (j < n) {
+                if (v.x < d.lower[j]) v.x = (d.lower[j] + a.x) / 2.;
+                else if (v.x > d.upper[j]) v.x = (d.upper[j] + a.x) / 2.;
+            }
+            if (j + 1 < n) {
+                if (v.y < d.lower[j + 1]) v.y = (d.lower[j + 1] + a.y) / 2.;
+                else if (v.y > d.upper[j + 1]) v.y = (d.upper[j + 1] + a.y) / 2.;
+            }
+            *reinterpret_cast<double2*>(&trial[j]) = v;
+        }
+    }
+    __syncthreads();
+    cnt = group_sum_d<16>(cnt);
+
+    // ---- evaluate, select into the other buffer ---------------------------------------------
+    double ft = BBO_INF_D;
+    if (c.obj >= 0) {
+        ft = eval_row_group<16>(c.obj, n, trial, d.aux, g);
+        if (ft != ft) ft = BBO_INF_D;
+    }
+    if (c.obj < 0) {
+        // host objective: park the trial in the other buffer; de_select finishes the job
+        if (live)
+            for (int pj = g; pj < ld / 2; pj += 16)
+                *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + 2 * pj]) =
+                        *reinterpret_cast<const double2*>(&trial[2 * pj]);
+        if (live && g == 0) {
+            d.rec_cr[pbase + i] = c.repaircr ? cnt / n : CR;
+            d.rec_f[pbase + i] = F;
+        }
+        return;
+    }
+    double ssq = 0.;
+    bool accept = false;
+    double fold = 0.;
+    if (live) {
+        fold = fc[order[i]];
+        accept = ft <= fold;
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const int j = 2 * pj;
+            const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j])
+                                     : *reinterpret_cast<const double2*>(&xi[j]);
+            *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + j]) = v;
+            ssq += v.x * v.x + v.y * v.y;
+        }
+    }
+    ssq = group_sum_d<16>(ssq);
+    if (live && g == 0) {
+        d.f[cur ^ 1][pbase + i] = accept ? ft : fold;
+        d.radius[pbase + i] = sqrt(ssq);
+        d.rec_cr[pbase + i] = c.repaircr ? cnt / n : CR;
+        d.rec_f[pbase + i] = F;
+        d.rec_df[pbase + i] = fold - ft;
+        d.rec_flag[pbase + i] = (accept ? 1 : 0) | ((accept && ft < fold) ? 2 : 0);
+    }
+}
+
+// host-objective path: the trials sit in X[cur^1], their fitness in f[cur^1]; finish the
+// selection (same arithmetic as the tail of de_generation)
+__global__ __launch_bounds__(256) void de_select(DeDev d, DeConst c)
+{
+    const int p = blockIdx.y;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r;
+    const int ld = c.ld, np = sc->np, cur = sc->cur;
+    const bool live = i < np;
+    const size_t pbase = (size_t) p * c.npinit;
+    const double *Xc = d.X[cur] + pbase * ld;
+    double *Xn = d.X[cur ^ 1] + pbase * ld;
+    double ssq = 0.;
+    bool accept = false;
+    double fold = 0., ft = 0.;
+    if (live) {
+        const int row = d.order[pbase + i];
+        fold = d.f[cur][pbase + row];
+        ft = d.f[cur ^ 1][pbase + i];
+        if (ft != ft) ft = BBO_INF_D;
+        accept = ft <= fold;
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const int j = 2 * pj;
+            double2 v = *reinterpret_cast<const double2*>(&Xn[(size_t) i * ld + j]);
+            if (!accept) {
+                v = *reinterpret_cast<const double2*>(&Xc[(size_t) row * ld + j]);
+                *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + j]) = v;
+            }
+            ssq += v.x * v.x + v.y * v.y;
+        }
+    }
+    ssq = group_sum_d<16>(ssq);
+    if (live && g == 0) {
+        d.f[cur ^ 1][pbase + i] = accept ? ft : fold;
+        d.radius[pbase + i] = sqrt(ssq);
+        d.rec_df[pbase + i] = fold - ft;
+        d.rec_flag[pbase + i] = (accept ? 1 : 0) | ((accept && ft < fold) ? 2 : 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bookkeeping: archive slots (successes in index order: push while there is room, else a
+// drawn slot, the later index wins) and the success-history / adaptive-mean update.
+// one workgroup of 1024 threads per population
+// ---------------------------------------------------------------------------
+__device__ inline double block_sum_1024(double v, double *scratch)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.;
+    for (int w = 0; w < 16; w++) s += scratch[w];
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
+{
+    const int p = blockIdx.x;
+    DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = sc->np, gen = sc->gen, larch0 = sc->larch;
+    const size_t pbase = (size_t) p * c.npinit;
+    const int *flag = d.rec_flag + pbase;
+    const int mask = c.variant == 0 ? 2 : 1;   // SHADE archives strict improvements only
+
+    // ---- archive slots ------------------------------------------------------------------
+    if (c.archive) {
+        for (int s = tid; s < np; s += 1024) d.claim[pbase + s] = -1;
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (int base = 0; base < np; base += 1024) {
+            const int i = base + tid;
+            const int rec = (i < np && (flag[i] & mask)) ? 1 : 0;
+            // exclusive prefix of rec over the block
+            const unsigned long long bal = __ballot(rec);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wave; w++) woff += wave_tot[w];
+            const int s_idx = carry + woff + before;
+            int slot = -1;
+            if (rec) {
+                if (larch0 + s_idx < np) {
+                    slot = larch0 + s_idx;
+                } else {
+                    const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, 0, (uint32_t) gen,
+                            stream_word(STREAM_DE_ARCH, (uint32_t) p));
+                    slot = uint_below(w.x, np);
+                }
+                atomicMax(&d.claim[pbase + slot], i);
+            }
+            if (i < np) d.slot_of[pbase + i] = slot;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int w = 0; w < 16; w++) tot += wave_tot[w];
+                carry += tot;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- parameter adaptation --------------------------------------------------------------
+    const double *cr = d.rec_cr + pbase, *ff = d.rec_f + pbase, *df = d.rec_df + pbase;
+    if (c.variant == 0) {
+        // weighted arithmetic mean of CR, weighted Lehmer mean of F (shade.cpp:188-205)
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        int cntl = 0;
+        for (int i = tid; i < np; i += 1024)
+            if (flag[i] & 2) {
+                const double w = df[i];
+                a0 += w * cr[i];
+                a1 += w;
+                a2 += w * ff[i] * ff[i];
+                a3 += w * ff[i];
+                cntl++;
+            }
+        a0 = block_sum_1024(a0, scratch);
+        a1 = block_sum_1024(a1, scratch);
+        a2 = block_sum_1024(a2, scratch);
+        a3 = block_sum_1024(a3, scratch);
+        const double nsd = block_sum_1024((double) cntl, scratch);
+        if (tid == 0) {
+            sc->nsucc = (int) nsd;
+            if (nsd > 0.) {
+                d.MCR[(size_t) p * c.h + sc->k - 1] = a0 / a1;
+                d.MF[(size_t) p * c.h + sc->k - 1] = a2 / a3;
+                sc->k = sc->k + 1 > c.h ? 1 : sc->k + 1;
+            }
+        }
+    } else {
+        // jade.cpp:180-205: mean / root-mean-square of the successful CR, Lehmer mean of F
+        double s1 = 0., s2 = 0., f1 = 0., f2 = 0.;
+        int cntl = 0;
+        for (int i = tid; i < np; i += 1024)
+            if (flag[i] & 1) {
+                s1 += cr[i];
+                s2 += cr[i] * cr[i];
+                f1 += ff[i];
+                f2 += ff[i] * ff[i];
+                cntl++;
+            }
+        s1 = block_sum_1024(s1, scratch);
+        s2 = block_sum_1024(s2, scratch);
+        f1 = block_sum_1024(f1, scratch);
+        f2 = block_sum_1024(f2, scratch);
+        const double ns = block_sum_1024((double) cntl, scratch);
+        double dev = 0.;
+        if (ns > 0.) {
+            const double mean = s1 / ns;
+            for (int i = tid; i < np; i += 1024)
+                if (flag[i] & 1) dev += (cr[i] - mean) * (cr[i] - mean);
+        }
+        dev = block_sum_1024(dev, scratch);
+        if (tid == 0) {
+            sc->nsucc = (int) ns;
+            double meancr = 0., meanf = 0.;
+            if (ns > 0.) {
+                meancr = sqrt(dev / ns) > c.jsigma ? sqrt(s2 / ns) : s1 / ns;
+                meanf = (f2 / ns) / (f1 / ns);
+            }
+            sc->mucr = (1. - c.cdamp) * sc->mucr + c.cdamp * meancr;
+            sc->muf = (1. - c.cdamp) * sc->muf + c.cdamp * meanf;
+        }
+    }
+    if (tid == 0) {
+        sc->fev += np;
+        if (c.archive) {
+            int tot = carry;
+            sc->larch = min(np, larch0 + tot);
+        }
+    }
+}
+
+// copies the replaced parents into the archive slots they won
+// grid (ceil(np_launch/16), P), 256 threads
+__global__ __launch_bounds__(256) void de_archive_copy(DeDev d, DeConst c)
+{
+    const int p = blockIdx.y;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc) || !c.archive) return;
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r;
+    if (i >= sc->np) return;
+    const size_t pbase = (size_t) p * c.npinit;
+    const int slot = d.slot_of[pbase + i];
+    if (slot < 0 || d.claim[pbase + slot] != i) return;
+    const double *src = d.X[sc->cur] + (pbase + d.order[pbase + i]) * c.ld;
+    double *dst = d.arch + (pbase + slot) * c.ld;
+    for (int pj = g; pj < c.ld / 2; pj += 16)
+        *reinterpret_cast<double2*>(&dst[2 * pj]) = *reinterpret_cast<const double2*>(&src[2 * pj]);
+}
+
+// ---------------------------------------------------------------------------
+// finish: linear population-size reduction, archive trim, stop test, buffer flip.
+// Runs after de_rank(next).  One workgroup of 1024 threads per population.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void de_finish(DeDev d, DeConst c)
+{
+    const int p = blockIdx.x;
+    DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    __shared__ double scratch[16];
+    __shared__ int sh_idx;
+    const int tid = threadIdx.x;
+    const size_t pbase = (size_t) p * c.npinit;
+    int np = sc->np;
+    const int gen = sc->gen;
+    int larch = sc->larch;
+    if (c.variant == 0) {
+        const int npnew = (int) round((c.npmin - c.npinit) * ((1. * sc->fev) / c.mfev) + c.npinit);
+        if (npnew < np) np = npnew;
+        if (c.archive) {
+            // swap-with-last removal of drawn slots until the archive fits (shade.cpp:228-235)
+            int t = 0;
+            while (larch > npnew) {
+                if (tid == 0) {
+                    const u32x4 w = philox4x32_10(c.seed, (uint32_t) t, 1, (uint32_t) gen,
+                            stream_word(STREAM_DE_ARCH, (uint32_t) p));
+                    sh_idx = uint_below(w.x, larch);
+                }
+                __syncthreads();
+                const int ir = sh_idx;
+                if (ir != larch - 1)
+                    for (int j = tid; j < c.ld; j += 1024)
+                        d.arch[(pbase + ir) * c.ld + j] = d.arch[(pbase + larch - 1) * c.ld + j];
+                __syncthreads();
+                larch--;
+                t++;
+            }
+        }
+    }
+    // radius spread of the surviving population (two passes)
+    const int *order = d.order + pbase;
+    const double *rad = d.radius + pbase;
+    double s = 0.;
+    for (int q = tid; q < np; q += 1024) s += rad[order[q]];
+    const double mean = block_sum_1024(s, scratch) / np;
+    double m2 = 0.;
+    for (int q = tid; q < np; q += 1024) {
+        const double dd = rad[order[q]] - mean;
+        m2 += dd * dd;
+    }
+    m2 = block_sum_1024(m2, scratch);
+    if (tid == 0) {
+        sc->np = np;
+        sc->larch = larch;
+        sc->cur ^= 1;
+        sc->gen = gen + 1;
+        sc->m2 = m2;
+        const int conv = m2 <= (np - 1) * c.tol * c.tol ? 1 : 0;
+        sc->conv = conv;
+        if (conv) sc->stop = 1;
+        else if (sc->fev >= c.mfev) sc->stop = 2;
+    }
+}
+
+} // namespace bbo
