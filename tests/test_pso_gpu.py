@@ -1,0 +1,77 @@
+"""GPU parity: the APSO generation against the oracle's generation-synchronous restatement
+(Apso with sync = True) fed by the same Philox draws.
+
+The evolutionary factor is the one quantity computed differently: the device forms the
+all-pairs distances from a Gram matrix of the CENTRED swarm on the matrix cores, the oracle
+subtracts coordinates like apso.cpp:316-321 -- tolerance 1e-9 on f, and the fuzzy state must
+be identical.
+"""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, what):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape, what
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert err <= rtol, "%s: rel err %.3e > %.1e" % (what, err, rtol)
+
+
+@pytest.mark.parametrize("n,np_,obj,correct", [
+    (8, 12, "rastrigin", True),
+    (8, 12, "rosenbrock", True),
+    (33, 70, "sphere", True),         # odd n, np not a multiple of 16 or 64
+    (16, 64, "ackley", False),
+    (64, 130, "griewank", True),
+])
+def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    seed = 4242
+    g = hip.APSO(mfev=10 ** 7, tol=1e-12, np=np_, correct=correct, seed=seed)
+    o = po.apso(oracle_lib, 10 ** 7, 1e-12, np_, correct)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    g.initialize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
+    o.init(obj, lo, up, np.zeros(n))
+    np.testing.assert_array_equal(g.get_state("x"), o.get("x"))   # same Philox words
+    _close(g.get_state("f"), o.get("f"), 1e-12, "init f")
+    _close(g.get_state("fbest"), o.get("fbest"), 1e-12, "init fbest")
+    states = []
+    for gen in range(40):
+        g.iterate()
+        o.iterate()
+        tag = "gen %d" % gen
+        _close(g.get_state("evof"), o.get("evof"), 1e-9, tag + " evolutionary factor")
+        assert int(g.get_state("state")[0]) == int(o.scalar("state")), tag
+        states.append(int(o.scalar("state")))
+        for k, tol in (("w", 1e-10), ("c1", 1e-12), ("c2", 1e-12)):
+            _close(g.get_state(k), o.get(k), tol, tag + " " + k)
+        assert int(g.get_state("fev")[0]) == int(o.scalar("fev")), tag
+        _close(g.get_state("x"), o.get("x"), 1e-11, tag + " x")
+        _close(g.get_state("v"), o.get("v"), 1e-10, tag + " v")
+        _close(g.get_state("xb"), o.get("xb"), 1e-11, tag + " pbest")
+        _close(g.get_state("f"), o.get("f"), 1e-10, tag + " f")
+        _close(g.get_state("xbest"), o.get("xbest"), 1e-11, tag + " gbest")
+        _close(g.get_state("fbest"), o.get("fbest"), 1e-10, tag + " fbest")
+    assert len(set(states)) >= 2   # the fuzzy state machine actually moved
+
+
+def test_apso_solves_sphere(hip):
+    n = 8
+    alg = hip.APSO(mfev=200000, tol=1e-6, np=40, seed=3)
+    sol = alg.optimize(hip.objectives.sphere, -10 * np.ones(n), 10 * np.ones(n), np.zeros(n))
+    assert hip.objectives.sphere(sol.x) < 1e-4
+
+
+def test_apso_python_callback(hip):
+    n = 5
+
+    def f(x):
+        return float(np.sum((x + 1.0) ** 2))
+
+    alg = hip.APSO(mfev=8000, tol=1e-7, np=20, seed=9)
+    sol = alg.optimize(f, -4 * np.ones(n), 4 * np.ones(n), np.zeros(n))
+    assert np.abs(sol.x + 1.0).max() < 0.05
