@@ -1,0 +1,313 @@
+// bbo_restart.hip -- IPOP / BIPOP restart drivers around a borrowed CMA-ES engine.
+//
+// Reference: IPopCmaes (src/multivariate/cma/ipop_cmaes.cpp:65-189) and BiPopCmaes
+// (src/multivariate/cma/bipop_cmaes.cpp:61-267).  The drivers are host logic (a regime
+// decision and three random numbers per restart); every inner run is a complete device-side
+// CMA-ES optimize().  Like the reference they re-use ONE base optimizer through setParams
+// (base_cmaes.cpp:136-148) -- including its quirk that B and C keep their off-diagonal
+// entries across restarts (cmaes.cpp:53-59) -- and spend one extra evaluation on the point
+// each run returns (bipop_cmaes.cpp:86-87).  The driver's own draws (restart point, u, u')
+// come from the RESTART Philox stream; restart r runs the inner engine under the key
+// seed + 0x9E3779B97F4A7C15 * (r + 1).
+#include "bbo_cma.hpp"
+#include "bbo_rng.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace bbo {
+
+class RestartDriver: public Optimizer {
+public:
+    RestartDriver(const bbo_params &p, CmaEngine *base) :
+            params_(p), base_(base), kind_(p.algo == BBO_ALGO_IPOP_CMAES ? 0 : 1)
+    {
+        BBO_REQUIRE(base != nullptr, "restart driver needs a base CMA-ES optimizer");
+    }
+
+    void init(int n, const double *lower, const double *upper, const double *guess,
+            const ObjectiveSpec &obj) override
+    {
+        n_ = n;
+        obj_ = obj;
+        lower_.assign(lower, lower + n);
+        upper_.assign(upper, upper + n);
+        guess_.assign(guess, guess + n);
+        fev_ = 0;
+        draws_ = 0;
+        lambda_ = lambdadef_ = 4 + (int) (3. * std::log(1. * n));
+        lambdamax_ = 10 * n * n;
+        sigma_ = params_.sigma0;
+        const int maxfev = max_evaluations(lambdadef_);
+        it_ = -1;   // the first run always becomes the incumbent
+        inner(lambdadef_, params_.sigma0, maxfev, guess_.data());
+        largebudget_ = smallbudget_ = 0;
+        largerestarts_ = smallrestarts_ = 0;
+        bestregime_ = 1;
+        it_ = 0;
+        x0_.assign(n, 0.);
+        last_regime_ = 0;
+        inited_ = true;
+        if (params_.print) {
+            if (kind_ == 1) {
+                widths_ = { 5, 5, 5, 5, 10, 10, 10, 5, 25, 25, 25 };
+                print_row({ "run", "regime", "run1", "run2", "budget1", "budget2", "fev", "pop",
+                        "sigma", "f*", "best f*" }, true);
+                print_row({ istr(it_), istr(0), istr(largerestarts_), istr(smallrestarts_),
+                        istr(largebudget_), istr(smallbudget_), istr(fev_), istr(lambdadef_),
+                        dstr(params_.sigma0), dstr(fx_), dstr(fxbest_) }, false);
+            } else {
+                widths_ = { 5, 10, 5, 25, 25, 25 };
+                print_row({ "run", "budget", "pop", "sigma", "f*", "best f*" }, true);
+                print_row({ istr(it_), istr(fev_), istr(lambdadef_), dstr(params_.sigma0),
+                        dstr(fx_), dstr(fxbest_) }, false);
+            }
+        }
+    }
+
+    void iterate() override
+    {
+        if (!inited_) throw Error(BBO_ERR_STATE, "iterate() before initialize()");
+        if (kind_ == 0) iterate_ipop();
+        else iterate_bipop();
+    }
+
+    // IPopCmaes::solution / BiPopCmaes::solution always report converged = false
+    void solution(int population, double *x_out, int *n_evals, int *converged) override
+    {
+        if (!inited_) throw Error(BBO_ERR_STATE, "solution() before initialize()");
+        BBO_REQUIRE(population == 0, "restart drivers hold one incumbent");
+        std::copy(xbest_.begin(), xbest_.end(), x_out);
+        *n_evals = fev_;
+        *converged = 0;
+    }
+
+    void optimize(int n, const double *lower, const double *upper, const double *guess,
+            const ObjectiveSpec &obj, double *x_out, int *n_evals, int *converged) override
+    {
+        init(n, lower, upper, guess, obj);
+        if (kind_ == 0) {
+            while (fev_ < params_.mfev) iterate();          // ipop_cmaes.cpp:171-173
+        } else {
+            while (true) {                                   // bipop_cmaes.cpp:174-187
+                iterate();
+                if (largerestarts_ >= params_.maxlargeruns) {
+                    if (params_.print)
+                        fprintf(stderr, "Warning [BIPOP-CMAES]: reached the maximum number of "
+                                "large population restarts.\n");
+                    break;
+                }
+                if (fev_ >= params_.mfev) break;
+            }
+        }
+        solution(0, x_out, n_evals, converged);
+    }
+
+    int run(int max_generations) override
+    {
+        int done = 0;
+        while (done < max_generations) {
+            if (kind_ == 0 && fev_ >= params_.mfev) break;
+            if (kind_ == 1 && (largerestarts_ >= params_.maxlargeruns || fev_ >= params_.mfev))
+                break;
+            iterate();
+            done++;
+        }
+        return done;
+    }
+
+    int get(const std::string &k, int population, double *out, int cap) override
+    {
+        (void) population;
+        auto one = [&](double v) {
+            if (out && cap >= 1) out[0] = v;
+            return 1;
+        };
+        if (k == "xbest" || k == "x0") {
+            const auto &v = k == "xbest" ? xbest_ : x0_;
+            if (out && cap >= (int) v.size()) std::copy(v.begin(), v.end(), out);
+            return (int) v.size();
+        }
+        if (k == "fev") return one(fev_);
+        if (k == "it") return one(it_);
+        if (k == "lambdadef") return one(lambdadef_);
+        if (k == "lambda") return one(lambda_);
+        if (k == "sigma") return one(sigma_);
+        if (k == "largelambda") return one(largelambda_);
+        if (k == "smalllambda") return one(smalllambda_);
+        if (k == "largebudget") return one(largebudget_);
+        if (k == "smallbudget") return one(smallbudget_);
+        if (k == "largerestarts") return one(largerestarts_);
+        if (k == "smallrestarts") return one(smallrestarts_);
+        if (k == "bestregime") return one(bestregime_);
+        if (k == "fx") return one(fx_);
+        if (k == "fxbest" || k == "fbest") return one(fxbest_);
+        if (k == "largesigma") return one(largesigma_);
+        if (k == "smallsigma") return one(smallsigma_);
+        if (k == "last_regime") return one(last_regime_);
+        if (k == "last_lambda") return one(last_lambda_);
+        if (k == "last_sigma") return one(last_sigma_);
+        if (k == "last_inner_fev") return one(last_inner_fev_);
+        if (k == "last_inner_converged") return one(last_inner_conv_);
+        throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
+    }
+
+    int set(const std::string &k, int, const double *, int) override
+    {
+        throw Error(BBO_ERR_KEY, "restart drivers have no writable state ('" + k + "')");
+    }
+
+    int dimension() const override { return n_; }
+
+private:
+    double uniform(double a, double b)
+    {
+        const u32x4 w = philox4x32_10(params_.seed, (uint32_t) draws_, 0, 0,
+                stream_word(STREAM_RESTART, 0));
+        draws_++;
+        return u01(w.x, w.y) * (b - a) + a;
+    }
+
+    // bipop_cmaes.cpp:191-202 == ipop_cmaes.cpp:178-189
+    int max_evaluations(int lam) const
+    {
+        const int maxit = (int) (100. + 50. * (n_ + 3) * (n_ + 3) / std::sqrt(1. * lam));
+        return std::min(maxit * lam, params_.mfev - fev_);
+    }
+
+    int inner(int lam, double sig, int maxfev, const double *start)
+    {
+        base_->set_params(lam, sig, maxfev);
+        base_->set_seed(params_.seed + 0x9E3779B97F4A7C15ull * (uint64_t) (it_ + 1));
+        std::vector<double> x(n_);
+        int ifev = 0, iconv = 0;
+        base_->optimize(n_, lower_.data(), upper_.data(), start, obj_, x.data(), &ifev, &iconv);
+        fx_ = base_->evaluate_point(x.data());
+        fev_ += ifev + 1;
+        last_inner_fev_ = ifev;
+        last_inner_conv_ = iconv;
+        last_lambda_ = lam;
+        last_sigma_ = sig;
+        if (it_ < 0 || fx_ < fxbest_) {
+            fxbest_ = fx_;
+            xbest_ = x;
+            return 1;
+        }
+        return 0;
+    }
+
+    // ipop_cmaes.cpp:112-162
+    void iterate_ipop()
+    {
+        for (int i = 0; i < n_; i++) x0_[i] = uniform(lower_[i], upper_[i]);
+        if (params_.boundlambda) {
+            lambda_ <<= 1;
+            if (lambda_ > lambdamax_) {
+                if (lambda_ - lambdamax_ < lambdamax_ - (lambda_ >> 1)) lambda_ = lambdamax_;
+                else lambda_ = lambdadef_;
+            }
+        } else {
+            lambda_ <<= 1;
+        }
+        if (params_.nipop) {
+            sigma_ /= params_.ksigmadec;
+            sigma_ = std::max(sigma_, 0.01 * params_.sigma0);
+        }
+        const int maxfev = max_evaluations(lambda_);
+        inner(lambda_, sigma_, maxfev, x0_.data());
+        it_++;
+        if (params_.print)
+            print_row({ istr(it_), istr(fev_), istr(lambda_), dstr(sigma_), dstr(fx_),
+                    dstr(fxbest_) }, false);
+    }
+
+    // bipop_cmaes.cpp:109-164, :204-267
+    void iterate_bipop()
+    {
+        for (int i = 0; i < n_; i++) x0_[i] = uniform(lower_[i], upper_[i]);
+        int regime;
+        if (params_.nipop) {   // NBIPOP: favour the regime that found the incumbent
+            if (bestregime_ == 1) regime = (largebudget_ <= smallbudget_ * params_.kbudget) ? 1 : 2;
+            else regime = (smallbudget_ <= params_.kbudget * largebudget_) ? 2 : 1;
+        } else {
+            regime = (largebudget_ <= smallbudget_) ? 1 : 2;
+        }
+        if (regime == 1) {
+            largelambda_ = (int) (lambdadef_ * std::pow(2, largerestarts_ + 1));
+            if (params_.nipop) {
+                largesigma_ = params_.sigma0 * std::pow(1. / params_.ksigmadec, largerestarts_ + 1);
+                largesigma_ = std::max(largesigma_, 0.01 * params_.sigma0);
+            } else {
+                largesigma_ = params_.sigma0;
+            }
+            const int maxfev = max_evaluations(largelambda_);
+            if (inner(largelambda_, largesigma_, maxfev, x0_.data())) bestregime_ = 1;
+            largebudget_ += last_inner_fev_;
+            largerestarts_++;
+        } else {
+            const double u = uniform(0., 1.);
+            smalllambda_ = (int) (lambdadef_
+                    * std::pow((0.5 * largelambda_) / lambdadef_, u * u));
+            smallsigma_ = params_.sigma0 * std::pow(10., -2. * uniform(0., 1.));
+            int maxfev = max_evaluations(smalllambda_);
+            maxfev = std::min(maxfev, largebudget_ >> 1);
+            if (inner(smalllambda_, smallsigma_, maxfev, x0_.data())) bestregime_ = 2;
+            smallbudget_ += last_inner_fev_;
+            smallrestarts_++;
+        }
+        last_regime_ = regime;
+        it_++;
+        if (params_.print)
+            print_row({ istr(it_), istr(regime), istr(largerestarts_), istr(smallrestarts_),
+                    istr(largebudget_), istr(smallbudget_), istr(fev_),
+                    istr(regime == 1 ? largelambda_ : smalllambda_),
+                    dstr(regime == 1 ? largesigma_ : smallsigma_), dstr(fx_), dstr(fxbest_) },
+                    false);
+    }
+
+    // the Tabular row format of src/tabular.hpp:65-77 (values at max_digits10)
+    static std::string istr(long v) { return std::to_string(v); }
+    static std::string dstr(double v)
+    {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.17g", v);
+        return buf;
+    }
+    void print_row(const std::vector<std::string> &cells, bool header)
+    {
+        int sum = 0;
+        for (size_t i = 0; i < cells.size(); i++) {
+            printf(" | %*s", widths_[i], cells[i].c_str());
+            sum += widths_[i];
+        }
+        printf(" | \n");
+        if (header)
+            printf(" |%s| \n", std::string(sum + 3 * ((int) cells.size() - 1) + 2, '=').c_str());
+        fflush(stdout);
+    }
+
+    bbo_params params_;
+    CmaEngine *base_;
+    int kind_;
+    ObjectiveSpec obj_;
+    bool inited_ = false;
+    int n_ = 0;
+    std::vector<double> lower_, upper_, guess_, x0_, xbest_;
+    std::vector<int> widths_;
+    int fev_ = 0, it_ = 0, draws_ = 0;
+    int lambdadef_ = 0, lambda_ = 0, lambdamax_ = 0;
+    int largelambda_ = 0, smalllambda_ = 0, largebudget_ = 0, smallbudget_ = 0;
+    int largerestarts_ = 0, smallrestarts_ = 0, bestregime_ = 1;
+    int last_regime_ = 0, last_inner_fev_ = 0, last_inner_conv_ = 0, last_lambda_ = 0;
+    double fx_ = 0., fxbest_ = 0., sigma_ = 0., largesigma_ = 0., smallsigma_ = 0.,
+            last_sigma_ = 0.;
+};
+
+Optimizer* make_restart_driver(const bbo_params &p, Optimizer *base)
+{
+    auto *cma = dynamic_cast<CmaEngine*>(base);
+    if (!cma) throw Error(BBO_ERR_ARG, "restart driver: base is not a CMA-ES engine");
+    return new RestartDriver(p, cma);
+}
+
+} // namespace bbo
