@@ -1,0 +1,247 @@
+"""Concurrent BIPOP-CMA-ES across the GPUs of one node (one process per GPU).
+
+The reference's BiPopCmaes (src/multivariate/cma/bipop_cmaes.cpp:109-267) is strictly
+sequential: each regime decision depends on the budgets every earlier restart used.  This
+module is the DOCUMENTED EXTENSION of SURVEY.md section 8e: restarts run in ROUNDS of W =
+world_size concurrent runs, rank g owning slot g of every round (a complete CMA-ES run on its
+own GPU: own mean, sigma, C, Philox key, lambda).  Inside a round nothing is exchanged.  After a
+round ONE all_gather (RCCL over xGMI with backend "nccl"; gloo in the CPU tests) moves one
+record per rank -- {ran, regime, lambda, sigma, budget, evaluations used, f, x[n]}, (n + 7)
+doubles -- and every rank applies the same deterministic reduction in slot order, so the
+replicated driver state (budgets, restart counters, incumbent) stays identical everywhere
+without a broadcast.
+
+Planning a round applies the reference's own rule (NBIPOP budget rule :117-142, large-regime
+lambda/sigma :207-214, small-regime lambda/sigma/budget cap :241-248, per-run evaluation cap
+:191-202) slot by slot, charging each planned run its evaluation CAP until the real counts
+arrive; with W = 1 every cap is replaced by the real count before the next decision, i.e. the
+schedule degenerates to the reference's sequential one.
+"""
+import math
+
+import numpy as _np
+
+from .multivariate import ActiveCMAES, CMAES, MultivariateSolution
+from .objectives import Builtin
+
+_GOLDEN = 0x9E3779B97F4A7C15
+_M64 = (1 << 64) - 1
+_STREAM_RESTART = 7
+
+
+def philox4x32_10(seed, c0, c1, c2, c3):
+    """host twin of bbo::philox4x32_10 (bboptpy_amd/csrc/bbo_rng.hpp) for the driver's few
+    draws per round"""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, \
+            ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
+        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def _u01(lo, hi):
+    return float((((hi << 32) | lo) >> 11)) * 2.0 ** -53
+
+
+class _State:
+    """driver state replicated on every rank"""
+
+    def __init__(self):
+        self.fev = 0
+        self.largebudget = self.smallbudget = 0
+        self.largerestarts = self.smallrestarts = 0
+        self.largelambda = 0
+        self.bestregime = 1
+        self.fxbest = math.inf
+        self.xbest = None
+        self.round = 0
+        self.history = []
+
+
+class ConcurrentBiPop:
+    """BIPOP/NBIPOP-CMA-ES with world_size concurrent restart populations.
+
+    Parameters mirror BiPopCMAES(base, mfev, print, sigma0, maxlargeruns, nbipop, ksigmadec,
+    kbudget) (py/multivariate_py.cpp:144-151); instead of a `base` object the inner optimizer
+    is described by `variant` ("active" | "cmaes") and `tol`.  `group` is a torch.distributed
+    process group (None = the default group, or no collective at all when torch.distributed is
+    not initialised: a single-process run).  `runner(lam, sigma, maxfev, x0, seed) -> (x,
+    evaluations_used, f(x))` replaces the device run in the CPU tests.
+    """
+
+    def __init__(self, mfev, tol=1e-8, sigma0=2., maxlargeruns=9, nbipop=True, ksigmadec=1.6,
+                 kbudget=2., variant="active", seed=0, device=None, group=None, runner=None,
+                 world_size=None, rank=None):
+        self.mfev, self.tol, self.sigma0 = int(mfev), float(tol), float(sigma0)
+        self.maxlargeruns, self.nbipop = int(maxlargeruns), bool(nbipop)
+        self.ksigmadec, self.kbudget = float(ksigmadec), float(kbudget)
+        self.variant, self.seed = variant, int(seed) & _M64
+        self.device, self.group, self.runner = device, group, runner
+        self._world, self._rank = world_size, rank
+
+    # -- topology ---------------------------------------------------------------------------
+    def _topology(self):
+        if self._world is not None:
+            return self._world, (self._rank or 0), None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_world_size(self.group), dist.get_rank(self.group), dist
+        except ImportError:
+            pass
+        return 1, 0, None
+
+    # -- the reference's rules --------------------------------------------------------------
+    def _max_evals(self, lam, fev):   # bipop_cmaes.cpp:191-202
+        maxit = int(100. + 50. * (self.n + 3) * (self.n + 3) / math.sqrt(1. * lam))
+        return min(maxit * lam, self.mfev - fev)
+
+    def _uniform(self, rnd, slot, k, a, b):
+        w = philox4x32_10(self.seed, rnd, slot, k, (_STREAM_RESTART << 24) | 1)
+        return _u01(w[0], w[1]) * (b - a) + a
+
+    def plan_round(self, st, world):
+        """the W runs of round st.round: a list of dicts (or None for an idle slot)"""
+        slots = []
+        lb, sb = st.largebudget, st.smallbudget
+        nl, largelambda, fev = st.largerestarts, st.largelambda, st.fev
+        for s in range(world):
+            if st.round == 0 and s == 0:
+                # the reference's first default run from the user's guess (:76-87)
+                maxfev = self._max_evals(self.lambdadef, fev)
+                slots.append(dict(regime=0, lam=self.lambdadef, sigma=self.sigma0,
+                                  maxfev=maxfev, x0=self.guess.copy()))
+                fev += maxfev + 1
+                continue
+            if nl >= self.maxlargeruns or fev >= self.mfev:
+                slots.append(None)
+                continue
+            if self.nbipop:
+                if st.bestregime == 1:
+                    regime = 1 if lb <= sb * self.kbudget else 2
+                else:
+                    regime = 2 if sb <= self.kbudget * lb else 1
+            else:
+                regime = 1 if lb <= sb else 2
+            x0 = _np.array([self._uniform(st.round, s, 16 + j, self.lower[j], self.upper[j])
+                            for j in range(self.n)])
+            if regime == 1:
+                lam = int(self.lambdadef * math.pow(2, nl + 1))
+                if self.nbipop:
+                    sigma = max(self.sigma0 * math.pow(1. / self.ksigmadec, nl + 1),
+                                0.01 * self.sigma0)
+                else:
+                    sigma = self.sigma0
+                maxfev = self._max_evals(lam, fev)
+                if maxfev > 0:
+                    nl += 1
+                    largelambda = lam
+                    lb += maxfev
+            else:
+                u = self._uniform(st.round, s, 0, 0., 1.)
+                u2 = self._uniform(st.round, s, 1, 0., 1.)
+                lam = int(self.lambdadef * math.pow((0.5 * largelambda) / self.lambdadef, u * u))
+                sigma = self.sigma0 * math.pow(10., -2. * u2)
+                maxfev = min(self._max_evals(lam, fev), lb >> 1)
+                if maxfev > 0:
+                    sb += maxfev
+            if maxfev <= 0 or lam < 4:
+                slots.append(None)
+                continue
+            slots.append(dict(regime=regime, lam=lam, sigma=sigma, maxfev=maxfev, x0=x0))
+            fev += maxfev + 1
+        return slots
+
+    def apply_round(self, st, slots, records):
+        """the deterministic reduction every rank applies to the gathered records"""
+        for s, (plan, rec) in enumerate(zip(slots, records)):
+            if plan is None or rec[0] == 0.:
+                continue
+            used, fx, x = int(rec[5]), float(rec[6]), _np.array(rec[7:7 + self.n])
+            st.fev += used + 1          # +1: the re-evaluation of the returned point (:86-87)
+            if plan["regime"] == 1:
+                st.largebudget += used
+                st.largerestarts += 1
+                st.largelambda = plan["lam"]
+            elif plan["regime"] == 2:
+                st.smallbudget += used
+                st.smallrestarts += 1
+            if st.xbest is None or fx < st.fxbest:
+                st.fxbest, st.xbest = fx, x
+                if plan["regime"] != 0:
+                    st.bestregime = plan["regime"]
+            st.history.append(dict(round=st.round, slot=s, regime=plan["regime"],
+                                   lam=plan["lam"], sigma=plan["sigma"], maxfev=plan["maxfev"],
+                                   used=used, fx=fx))
+        st.round += 1
+
+    # -- one inner run on this rank's GPU -----------------------------------------------------
+    def _device_run(self, f, lam, sigma, maxfev, x0, seed):
+        cls = ActiveCMAES if self.variant == "active" else CMAES
+        alg = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
+                  device=self.device or 0)
+        sol = alg.optimize(f, self.lower, self.upper, x0)
+        fx = float(f(sol.x))
+        return sol.x, sol.n_evals, fx
+
+    def optimize(self, f, lower, upper, guess):
+        self.lower = _np.ascontiguousarray(lower, dtype=_np.float64)
+        self.upper = _np.ascontiguousarray(upper, dtype=_np.float64)
+        self.guess = _np.ascontiguousarray(guess, dtype=_np.float64)
+        self.n = self.lower.size
+        self.lambdadef = 4 + int(3. * math.log(1. * self.n))
+        world, rank, dist = self._topology()
+        st = _State()
+        self.state = st
+        reclen = 7 + self.n
+        while True:
+            slots = self.plan_round(st, world)
+            if all(p is None for p in slots):
+                break
+            mine = slots[rank]
+            rec = _np.zeros(reclen)
+            if mine is not None:
+                seed = (self.seed + _GOLDEN * (st.round * world + rank + 1)) & _M64
+                if self.runner is not None:
+                    x, used, fx = self.runner(mine["lam"], mine["sigma"], mine["maxfev"],
+                                              mine["x0"], seed)
+                else:
+                    x, used, fx = self._device_run(f, mine["lam"], mine["sigma"],
+                                                   mine["maxfev"], mine["x0"], seed)
+                rec[:7] = [1., mine["regime"], mine["lam"], mine["sigma"], mine["maxfev"], used,
+                           fx]
+                rec[7:] = x
+            if dist is not None:
+                import torch
+                dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+                mine_t = torch.from_numpy(rec).to(dev)
+                out = [torch.empty_like(mine_t) for _ in range(world)]
+                dist.all_gather(out, mine_t, group=self.group)
+                records = [t.cpu().numpy() for t in out]
+            else:
+                records = [rec] if world == 1 else self._serial_records(f, slots, st, world, rec,
+                                                                        rank)
+            self.apply_round(st, slots, records)
+            if st.largerestarts >= self.maxlargeruns or st.fev >= self.mfev:
+                break
+        return MultivariateSolution(st.xbest, st.fev, False)
+
+    def _serial_records(self, f, slots, st, world, rec, rank):
+        """world_size > 1 without torch.distributed: run every slot in this process (the
+        "fake collective" of SURVEY.md section 4) -- same plan, same reduction"""
+        records = []
+        for s, plan in enumerate(slots):
+            r = _np.zeros(7 + self.n)
+            if plan is not None:
+                seed = (self.seed + _GOLDEN * (st.round * world + s + 1)) & _M64
+                run = self.runner if self.runner is not None else \
+                    (lambda lam, sig, mf, x0, sd: self._device_run(f, lam, sig, mf, x0, sd))
+                x, used, fx = run(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"], seed)
+                r[:7] = [1., plan["regime"], plan["lam"], plan["sigma"], plan["maxfev"], used, fx]
+                r[7:] = x
+            records.append(r)
+        return records

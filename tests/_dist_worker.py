@@ -1,0 +1,46 @@
+"""worker of tests/test_distributed_cpu.py: one rank of a gloo process group running the
+concurrent BIPOP driver with the CPU oracle as the inner optimizer (test infrastructure)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def oracle_runner(lo, up, obj):
+    import pyoracle as po
+    O = po.oracle()
+
+    def run(lam, sigma, maxfev, x0, seed):
+        h = po.cma(O, "active", maxfev, 1e-8, lam, sigma0=sigma)
+        h.set_rng(po.RNG_PHILOX, seed)
+        x, fev, _ = h.optimize(obj, lo, up, x0)
+        return x, fev, O.objective(obj, x)
+    return run
+
+
+def drive(world=None, rank=None, mfev=60000, n=5, seed=17):
+    from bboptpy_amd.distributed import ConcurrentBiPop
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    d = ConcurrentBiPop(mfev=mfev, seed=seed, runner=oracle_runner(lo, up, "rastrigin"),
+                        world_size=world, rank=rank)
+    sol = d.optimize(None, lo, up, np.random.default_rng(seed).uniform(-5, 5, n))
+    st = d.state
+    return {"x": [float(v).hex() for v in sol.x], "fev": sol.n_evals, "fxbest": st.fxbest.hex(),
+            "large": [st.largebudget, st.largerestarts], "small": [st.smallbudget, st.smallrestarts],
+            "rounds": st.round, "history": st.history}
+
+
+if __name__ == "__main__":
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    res = drive()
+    with open(os.path.join(sys.argv[1], "rank%d.json" % dist.get_rank()), "w") as fh:
+        json.dump(res, fh)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,125 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/bbopt_hip.h declares, the default parameters are the reference's keyword defaults,
+the Python classes carry the reference's names / hierarchy / signatures, and the product
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bbopt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bbo_[a-z_]+)\s*\(", text)) - {"bbo_scalar_fn", "bbo_batch_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    from bboptpy_amd import _ffi
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), "libbbopt_hip.so does not export %s" % name
+    assert set(names) == set(_ffi.EXPORTED_SYMBOLS)
+    assert b"gfx950" in _ffi.lib().bbo_version()
+
+
+def test_default_parameters_are_the_reference_defaults():
+    from bboptpy_amd import _ffi
+    p = _ffi.default_params(_ffi.ALGO_ACTIVE_CMAES)
+    # py/multivariate_py.cpp:103-171,265-269
+    assert (p.sigma0, p.bound, p.alphacov, p.eigenrate) == (2., 0, 2., 0.25)
+    assert (p.archive, p.repaircr, p.pelite, p.cdamp, p.jade_sigma) == (1, 1, 0.05, 0.1, 0.07)
+    assert (p.h, p.npmin, p.correct) == (100, 4, 1)
+    assert (p.print, p.nipop, p.ksigmadec, p.boundlambda, p.maxlargeruns, p.kbudget) == \
+        (0, 1, 1.6, 1, 9, 2.)
+    assert p.populations == 1
+
+
+def test_class_surface_matches_the_reference():
+    import bboptpy_amd as bb
+
+    def sig(cls):
+        ps = inspect.signature(cls.__init__).parameters
+        return [(k, v.default) for k, v in ps.items() if k not in ("self", "ext")]
+
+    E = inspect.Parameter.empty
+    assert sig(bb.CMAES) == [("mfev", E), ("tol", E), ("np", E), ("sigma0", 2.), ("bound", False),
+                             ("eigenrate", 0.25)]
+    assert sig(bb.ActiveCMAES) == [("mfev", E), ("tol", E), ("np", E), ("sigma0", 2.),
+                                   ("bound", False), ("alphacov", 2.), ("eigenrate", 0.25)]
+    assert sig(bb.IPopCMAES) == [("base", E), ("mfev", E), ("print", False), ("sigma0", 2.),
+                                 ("nipop", True), ("ksigmadec", 1.6), ("boundlambda", True)]
+    assert sig(bb.BiPopCMAES) == [("base", E), ("mfev", E), ("print", False), ("sigma0", 2.),
+                                  ("maxlargeruns", 9), ("nbipop", True), ("ksigmadec", 1.6),
+                                  ("kbudget", 2.)]
+    assert sig(bb.JADE) == [("mfev", E), ("np", E), ("tol", E), ("archive", True),
+                            ("repaircr", True), ("pelite", 0.05), ("cdamp", 0.1), ("sigma", 0.07)]
+    assert sig(bb.SHADE) == [("mfev", E), ("npinit", E), ("tol", E), ("archive", True),
+                             ("repaircr", True), ("h", 100), ("npmin", 4)]
+    assert sig(bb.APSO) == [("mfev", E), ("tol", E), ("np", E), ("correct", True)]
+    # ActiveCMAES -> CMAES -> BaseCMAES -> MultivariateSearch (multivariate_py.cpp:99-115)
+    assert bb.ActiveCMAES.__mro__[:4] == (bb.ActiveCMAES, bb.CMAES, bb.BaseCMAES,
+                                          bb.MultivariateSearch)
+    for cls in (bb.CMAES, bb.JADE, bb.SHADE, bb.APSO, bb.IPopCMAES, bb.BiPopCMAES):
+        for m in ("optimize", "initialize", "iterate", "solution"):
+            assert callable(getattr(cls, m))
+
+
+def test_solution_string_is_the_reference_format():
+    from bboptpy_amd import MultivariateSolution
+    s = MultivariateSolution(np.array([0.999989, 1.0000005, -2.5]), 6980, True)
+    # multivariate.h:97-114: std::to_string per coordinate, four status lines
+    assert str(s) == ("x*: 0.999989 1.000001 -2.500000 \nobjective calls: 6980\n"
+                      "constraint calls: 0\nB/B constraint calls: 0\nconverged: yes")
+    assert str(MultivariateSolution([0.], 1, False)).endswith("converged: no/unknown")
+    x = s.x
+    x[0] = 5.
+    assert s.x[0] == 0.999989 and s.n_evals == 6980 and s.converged is True
+
+
+def test_no_cpu_fallback():
+    """without a GPU the product raises; it never routes through the oracle or NumPy"""
+    import bboptpy_amd as bb
+    from bboptpy_amd import _ffi
+    if _ffi.lib().bbo_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    alg = bb.ActiveCMAES(mfev=100, tol=1e-4, np=8)
+    with pytest.raises(_ffi.BboError) as ei:
+        alg.optimize(bb.objectives.rosenbrock, -np.ones(4), np.ones(4), np.zeros(4))
+    assert ei.value.status == -4
+    for mod in ("pyoracle",):
+        src = open(os.path.join(ROOT, "bboptpy_amd", "multivariate.py")).read()
+        assert mod not in src
+
+
+def test_builtin_objectives_agree_with_the_oracle(oracle_lib):
+    """the host-side convenience formulas of bboptpy_amd.objectives (never used by the
+    optimizers) describe the same functions as the device / oracle definitions"""
+    import bboptpy_amd as bb
+    rng = np.random.default_rng(0)
+    for ob in bb.objectives.ALL:
+        x = rng.uniform(-3, 3, 11)
+        assert ob(x) == pytest.approx(oracle_lib.objective(ob.name, x), rel=1e-12, abs=1e-12)
+
+
+def test_philox_known_answers(oracle_lib):
+    """Random123 known-answer vectors for Philox4x32-10, and the host twin used by the
+    concurrent BIPOP driver"""
+    from bboptpy_amd.distributed import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    out = (ctypes.c_uint32 * 4)()
+    for ctr, key, want in kat:
+        seed = key[0] | (key[1] << 32)
+        oracle_lib.f("philox")(seed, *ctr, out)
+        assert tuple(out) == want
+        assert philox4x32_10(seed, *ctr) == want

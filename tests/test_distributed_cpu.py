@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: the concurrent BIPOP driver over a world_size-2 gloo group, with the
+CPU oracle standing in for the device run (the product's collective and reduction logic is what
+is under test here, not the inner optimizer)."""
+import json
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from _dist_worker import drive
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_world1_degenerates_to_the_reference_schedule():
+    """one slot per round: every cap is replaced by the real count before the next decision,
+    so the regime / lambda / sigma sequence obeys bipop_cmaes.cpp:117-142,:207-214,:241-248"""
+    res = drive(world=1, rank=0, mfev=40000)
+    n, lamdef = 5, 4 + int(3. * math.log(5))
+    large = small = nl = 0
+    best, fbest = 1, math.inf
+    for h in res["history"]:
+        if h["regime"] == 0:
+            assert h["lam"] == lamdef and h["sigma"] == 2.
+        else:
+            want = (1 if large <= small * 2. else 2) if best == 1 else (2 if small <= 2. * large else 1)
+            assert h["regime"] == want
+            if want == 1:
+                assert h["lam"] == lamdef * 2 ** (nl + 1)
+                assert h["sigma"] == max(2. * (1. / 1.6) ** (nl + 1), 0.02)
+                large += h["used"]
+                nl += 1
+            else:
+                assert h["maxfev"] <= large >> 1
+                small += h["used"]
+        if h["fx"] < fbest:
+            fbest = h["fx"]
+            if h["regime"]:
+                best = h["regime"]
+    assert res["large"] == [large, nl]
+    assert float.fromhex(res["fxbest"]) == fbest
+    assert res["fev"] == sum(h["used"] + 1 for h in res["history"])
+
+
+def test_gloo_world2_matches_the_serial_reduction(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "_dist_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=os.path.dirname(HERE))
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    r1 = json.load(open(tmp_path / "rank1.json"))
+    assert r0 == r1                      # replicated state, no broadcast needed
+    serial = drive(world=2, rank=0)      # same plan, slots run one after the other
+    assert json.loads(json.dumps(serial)) == r0
+    assert r0["rounds"] >= 2 and len(r0["history"]) > r0["rounds"]   # two runs per round
