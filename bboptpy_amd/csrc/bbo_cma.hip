@@ -267,9 +267,24 @@ void CmaEngine::launch_sample_eval()
 void CmaEngine::launch_rank()
 {
     const CmaConst &c = c_;
-    dim3 grid((c.lambda + 31) / 32, c.npop);
     timer_.begin(stream_, K_RANK);
-    hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
+    // few populations: the counting kernel spreads one ranking over many CUs; many
+    // populations: one in-LDS sort per population is far less work in total
+    if (c.lambda <= SORT_LDS_MAX && c.npop >= 4) {
+        int m = 2;
+        while (m < c.lambda) m <<= 1;
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_rank_sort,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX * 12));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(1024), (size_t) m * 12, stream_, d_,
+                c_, m);
+    } else {
+        dim3 grid((c.lambda + 31) / 32, c.npop);
+        hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
+    }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }

@@ -21,6 +21,7 @@
 #include "bbo_objectives.hpp"
 #include "bbo_rng.hpp"
 #include "bbo_eig.hpp"
+#include "bbo_rank.hpp"
 
 namespace bbo {
 
@@ -147,19 +148,14 @@ __global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
     const int p = blockIdx.y;
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
+    __shared__ __attribute__((aligned(16))) double tile[RANK_TILE];
     const int tid = threadIdx.x;
     const int cand = blockIdx.x * 32 + (tid >> 3), slice = tid & 7;
     const double *f = d.f + (size_t) p * c.lambda_pad;
     const bool live = cand < c.lambda;
-    const double fi = live ? f[cand] : BBO_INF;
-    int cnt = 0;
-    for (int j = slice; j < c.lambda; j += 8) {
-        const double fj = f[j];
-        cnt += (fj < fi) || (fj == fi && j < cand);
-    }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 8);
+    const int cnt = rank_by_counting(f, c.lambda, cand, slice, tile);
     if (live && slice == 0) {
+        const double fi = f[cand];
         d.rank[(size_t) p * c.lambda_pad + cand] = cnt;
         d.order[(size_t) p * c.lambda_pad + cnt] = cand;
         if (cnt == 0) { sc->ibw[0] = cand; sc->ybw[0] = fi; }
@@ -168,6 +164,29 @@ __global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
         if (cnt == c.lambda - 1) { sc->ibw[3] = cand; sc->ybw[3] = fi; }
     }
     if (blockIdx.x == 0 && tid == 0) sc->fev += c.lambda;   // base_cmaes.cpp:218
+}
+
+// the same ranking by one in-LDS bitonic sort per population (lambda <= SORT_LDS_MAX):
+// grid (P), 1024 threads, dynamic LDS m * 12 bytes
+__global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int m)
+{
+    const int p = blockIdx.x;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double sortbuf[];
+    double *keys = sortbuf;
+    int *idx = reinterpret_cast<int*>(sortbuf + m);
+    const double *f = d.f + (size_t) p * c.lambda_pad;
+    int *order = d.order + (size_t) p * c.lambda_pad, *rank = d.rank + (size_t) p * c.lambda_pad;
+    bitonic_sort_lds(f, c.lambda, m, keys, idx, order, rank);
+    if (threadIdx.x == 0) {
+        const int L = c.lambda;
+        sc->ibw[0] = idx[0]; sc->ybw[0] = keys[0];
+        sc->ibw[1] = idx[1]; sc->ybw[1] = keys[1];
+        sc->ibw[2] = idx[L - 2]; sc->ybw[2] = keys[L - 2];
+        sc->ibw[3] = idx[L - 1]; sc->ybw[3] = keys[L - 1];
+        sc->fev += L;   // base_cmaes.cpp:218
+    }
 }
 
 // ---------------------------------------------------------------------------

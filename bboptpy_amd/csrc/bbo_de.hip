@@ -128,10 +128,30 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
             d_, c_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(0, c.npinit);
-    dim3 rgrid((c.npinit + 31) / 32, P);
-    hipLaunchKernelGGL(de_rank, rgrid, dim3(256), 0, stream_, d_, c_, 0);
-    BBO_HIP(hipGetLastError());
+    launch_rank(0, c.npinit);
     BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+// ranks f[cur] (which_next = 0) or f[cur ^ 1] (1) of the first np individuals
+void DeEngine::launch_rank(int which_next, int np_bound)
+{
+    const DeConst &c = c_;
+    if (np_bound <= SORT_LDS_MAX && c.npop >= 4) {
+        int m = 2;
+        while (m < np_bound) m <<= 1;
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) de_rank_sort,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX * 12));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(de_rank_sort, dim3(c.npop), dim3(1024), (size_t) m * 12, stream_, d_,
+                c_, which_next, m);
+    } else {
+        dim3 rgrid((np_bound + 31) / 32, c.npop);
+        hipLaunchKernelGGL(de_rank, rgrid, dim3(256), 0, stream_, d_, c_, which_next);
+    }
+    BBO_HIP(hipGetLastError());
 }
 
 // host objective: fitness of rows [0, rows) of buffer `which` of every population
@@ -162,7 +182,7 @@ void DeEngine::generation(bool honor_stop)
     c.honor_stop = honor_stop ? 1 : 0;
     c.np_launch = np_host_;
     const int P = c.npop;
-    dim3 g16((np_host_ + 15) / 16, P), g32((np_host_ + 31) / 32, P);
+    dim3 g16((np_host_ + 15) / 16, P);
     const size_t lds = (size_t) 16 * c.ld * sizeof(double);
     timer_.begin(stream_, K_GEN);
     hipLaunchKernelGGL(de_generation, g16, dim3(256), lds, stream_, d_, c_);
@@ -186,9 +206,8 @@ void DeEngine::generation(bool honor_stop)
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_RANK);
-    hipLaunchKernelGGL(de_rank, g32, dim3(256), 0, stream_, d_, c_, 1);
+    launch_rank(1, np_host_);
     timer_.end(stream_);
-    BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_FINISH);
     hipLaunchKernelGGL(de_finish, dim3(P), dim3(1024), 0, stream_, d_, c_);
     timer_.end(stream_);
@@ -400,9 +419,7 @@ int DeEngine::set(const std::string &k, int p, const double *in, int count)
         (s.cur == 0 ? fa_ : fb_).upload(in, count, pbase);
         c_.honor_stop = 0;
         c_.np_launch = c.npinit;
-        dim3 rgrid((c.npinit + 31) / 32, c.npop);
-        hipLaunchKernelGGL(de_rank, rgrid, dim3(256), 0, stream_, d_, c_, 0);
-        BBO_HIP(hipGetLastError());
+        launch_rank(0, c.npinit);
         BBO_HIP(hipStreamSynchronize(stream_));
         return count;
     }

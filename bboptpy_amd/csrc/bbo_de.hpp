@@ -70,7 +70,7 @@ public:
 
 private:
     void generation(bool honor_stop);
-    void evaluate_initial();
+    void launch_rank(int which_next, int np_bound);
     void host_evaluate(int which, int rows);
     bool all_stopped();
 

@@ -16,6 +16,7 @@
 #include "bbo_de.hpp"
 #include "bbo_objectives.hpp"
 #include "bbo_rng.hpp"
+#include "bbo_rank.hpp"
 
 namespace bbo {
 
@@ -84,24 +85,32 @@ __global__ __launch_bounds__(256) void de_rank(DeDev d, DeConst c, int which_nex
     const int p = blockIdx.y;
     const DeScal *sc = d.scal + p;
     if (de_frozen(c, sc)) return;
+    __shared__ __attribute__((aligned(16))) double tile[RANK_TILE];
     const int np = sc->np;
     const int which = which_next ? (sc->cur ^ 1) : sc->cur;
     const int tid = threadIdx.x;
     const int cand = blockIdx.x * 32 + (tid >> 3), slice = tid & 7;
     const double *f = d.f[which] + (size_t) p * c.npinit;
-    const bool live = cand < np;
-    const double fi = live ? f[cand] : BBO_INF_D;
-    int cnt = 0;
-    for (int j = slice; j < np; j += 8) {
-        const double fj = f[j];
-        cnt += (fj < fi) || (fj == fi && j < cand);
-    }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 8);
-    if (live && slice == 0) {
+    const int cnt = rank_by_counting(f, np, cand, slice, tile);
+    if (cand < np && slice == 0) {
         d.rank[(size_t) p * c.npinit + cand] = cnt;
         d.order[(size_t) p * c.npinit + cnt] = cand;
     }
+}
+
+// in-LDS bitonic sort per population (np <= SORT_LDS_MAX): grid (P), 1024 threads
+__global__ __launch_bounds__(1024) void de_rank_sort(DeDev d, DeConst c, int which_next, int m)
+{
+    const int p = blockIdx.x;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double sortbuf[];
+    double *keys = sortbuf;
+    int *idx = reinterpret_cast<int*>(sortbuf + m);
+    const int which = which_next ? (sc->cur ^ 1) : sc->cur;
+    const double *f = d.f[which] + (size_t) p * c.npinit;
+    bitonic_sort_lds(f, sc->np, m, keys, idx, d.order + (size_t) p * c.npinit,
+            d.rank + (size_t) p * c.npinit);
 }
 
 // ---------------------------------------------------------------------------

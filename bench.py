@@ -37,14 +37,41 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix peak (AMD datashe
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.)),
-    "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.)),
-    "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12)),
-    "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.)),
+    "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=64),
+    "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=64),
+    "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=64),
+    "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=64),
+    "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
+    "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
 
 CMA_KERNELS = ["cma_sample_eval", "cma_rank", "cma_whiten", "cma_gram", "cma_paths", "cma_cov",
                "cma_eigen", "cma_post", "cma_history_stop"]
+DE_KERNELS = ["de_generation", "de_bookkeep", "de_archive_copy", "de_rank", "de_finish",
+              "de_select"]
+PSO_KERNELS = ["pso_center", "pso_ese", "pso_control", "pso_update", "pso_finish"]
+
+
+def de_kernel_costs(n, np_, P):
+    """40n+16 B per individual for the fused generation"""
+    return {
+        "de_generation": ("hbm", P * np_ * (40 * n + 16)),
+        "de_bookkeep": ("hbm", P * np_ * 32),
+        "de_archive_copy": ("hbm", None),        # 16n B per success: data dependent
+        "de_rank": ("hbm", P * np_ * 16),
+        "de_finish": ("hbm", P * np_ * 12),
+        "de_select": ("hbm", P * np_ * 16 * n),
+    }
+
+
+def pso_kernel_costs(n, np_, P):
+    return {
+        "pso_center": ("hbm", P * np_ * 16 * n),
+        "pso_ese": ("mfma", P * np_ * 2 * n * np_),
+        "pso_control": ("hbm", P * np_ * 16),
+        "pso_update": ("hbm", P * np_ * (40 * n + 16)),
+        "pso_finish": ("hbm", P * np_ * 16),
+    }
 
 
 def cma_kernel_costs(n, lam, P):
@@ -72,8 +99,11 @@ def make_optimizer(bb, wl, P, seed, device):
         return bb.ActiveCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
                               populations=P)
     if a == "SHADE":
+        # npmin = npinit: population-size reduction off, steady-state throughput
         return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
                         device=device, populations=P)
+    if a == "JADE":
+        return bb.JADE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
     if a == "APSO":
         return bb.APSO(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device, populations=P)
     raise ValueError(a)
@@ -113,14 +143,23 @@ def cpu_baseline(wl, budget_s=12.0):
     if lib is None:
         lib = po.oracle()
     n, lam = wl["n"], wl["np"]
+    a = wl["algo"]
+    note = ""
+    if a == "APSO" and lam > 1024:
+        # the reference's APSO generation is O(np^2 n): one generation at np = 65536 takes
+        # about half an hour on one core; sample np = 1024 and say so
+        note = " (np reduced from %d: the reference needs ~%.0f s per generation there)" % (
+            lam, 0.45 * (lam / 1024.) ** 2)
+        lam = 1024
     lo, up = wl["box"][0] * np.ones(n), wl["box"][1] * np.ones(n)
     guess = np.random.default_rng(1).uniform(wl["box"][0], wl["box"][1], n)
     lib.seed(1)
-    a = wl["algo"]
     if a == "ActiveCMAES":
         h = po.cma(lib, "active", 2 ** 31 - 1, 0., lam)
     elif a == "SHADE":
         h = po.shade(lib, 2 ** 31 - 1, lam, 0., npmin=lam)
+    elif a == "JADE":
+        h = po.jade(lib, 2 ** 31 - 1, lam, 0.)
     else:
         h = po.apso(lib, 2 ** 31 - 1, 0., lam)
     h.init(wl["objective"], lo, up, guess)
@@ -135,8 +174,8 @@ def cpu_baseline(wl, budget_s=12.0):
             break
     evals = h.scalar("fev") - fev0
     return {"value": evals / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
-            "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s" % (
-                gens, a, n, lam, wl["objective"], dt)}
+            "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s%s" % (
+                gens, a, n, lam, wl["objective"], dt, note)}
 
 
 def main():
@@ -145,7 +184,8 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="M", choices=sorted(WORKLOADS))
-    ap.add_argument("--populations", type=int, default=64)
+    ap.add_argument("--populations", type=int, default=None,
+                    help="independent populations per GPU (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,7 +206,7 @@ def main():
     import bboptpy_amd as bb
 
     wl = WORKLOADS[args.workload]
-    P = args.populations
+    P = args.populations if args.populations else wl["P"]
     dt, prof, _, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
                              profile=True, barrier=barrier)
     if world > 1:
@@ -180,16 +220,25 @@ def main():
     out = None
     if rank == 0:
         # per-kernel device time (HIP events on the engine's stream) -> roofline
-        names = CMA_KERNELS if wl["algo"] == "ActiveCMAES" else []
+        if wl["algo"] == "ActiveCMAES":
+            names, costs = CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], P)
+        elif wl["algo"] in ("SHADE", "JADE"):
+            names, costs = DE_KERNELS, de_kernel_costs(wl["n"], wl["np"], P)
+        else:
+            names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
         kernels = {}
         if prof is not None and names:
-            costs = cma_kernel_costs(wl["n"], wl["np"], P)
             for i, name in enumerate(names):
                 ms, calls = prof[2 * i], prof[2 * i + 1]
                 if calls <= 0:
                     continue
                 bound, work = costs[name]
                 avg_s = ms * 1e-3 / calls
+                if work is None:
+                    kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
+                                     "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": None}
+                    continue
                 if bound == "mfma":
                     ach, peak, unit = work / avg_s / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
                 else:
