@@ -222,8 +222,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     scal_.upload(sc.data(), P);
 
     // the eigensolver keeps its matrix in LDS when it fits
-    if (!eig_plan(n, c.ld).use_lds) eig_work_.alloc((size_t) P * ld * (ld + 1));
-    else eig_work_.release();
+    // global scratch of the eigensolver: the work matrix when it does not fit LDS, or
+    // (divide and conquer) the Householder matrix and the merge factor
+    eig_work_.alloc((size_t) P * 2 * ld * (ld + 1));
 
     CmaDev &d = d_;
     d = CmaDev {};
@@ -342,7 +343,7 @@ void CmaEngine::launch_eigen()
     static bool attr_done = false;
     if (!attr_done) {
         BBO_HIP(hipFuncSetAttribute((const void*) cma_eigen,
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 768));
         attr_done = true;
     }
     timer_.begin(stream_, K_EIGEN);
@@ -667,12 +668,12 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "profile") return timer_.report(out, cap);
     if (k == "eig_stamps") {
         if (!stamps_.p) return 0;
-        if (out && cap >= 16) {
-            long long t[16];
-            stamps_.download(t, 16);
-            for (int i = 0; i < 16; i++) out[i] = (double) t[i];
+        if (out && cap >= 32) {
+            long long t[32];
+            stamps_.download(t, 32);
+            for (int i = 0; i < 32; i++) out[i] = (double) t[i];
         }
-        return 16;
+        return 32;
     }
     if (k == "best_hist" || k == "kth_hist") {
         if (out && cap >= c.hlen)
@@ -773,7 +774,7 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         return 1;
     }
     if (k == "eig_stamps") {
-        if (stamps_.count != 16) stamps_.alloc(16);
+        if (stamps_.count != 32) stamps_.alloc(32);
         d_.stamps = stamps_.p;
         return 1;
     }

@@ -17,6 +17,7 @@
 #pragma once
 
 #include "bbo_cma.hpp"
+#include "bbo_eig_dc.hpp"
 
 namespace bbo {
 
@@ -27,6 +28,7 @@ constexpr int EIG_MAXSEQ = 64;
 struct EigPlan {
     int use_lds;      // matrix in LDS?
     int reg_path;     // n <= 128: tred2 + accumulation run out of registers
+    int dc;           // tridiagonal stage by divide and conquer (bbo_eig_dc.hpp) instead of QL
     int lda;          // leading dimension of the work matrix
     int rc;           // Givens pairs per chunk buffer
     int vl;           // stride of the LDS vectors (>= 128, includes a 2-element front pad)
@@ -40,6 +42,7 @@ inline EigPlan eig_plan(int n, int ld)
     EigPlan pl {};
     pl.vl = (((n > 128 ? n : 128) + 1) & ~1) + 2;
     pl.reg_path = n <= 128 ? 1 : 0;
+    pl.dc = pl.reg_path;
     const size_t budget = 160 * 1024 - 1024;
     const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
     const size_t vecs = (size_t) (EIG_NVEC + (pl.reg_path ? 0 : 4)) * pl.vl * sizeof(double);
@@ -586,6 +589,15 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     __syncthreads();
     EIG_STAMP(3);
 
+    const bool use_dc = pl.dc && !(d.dbg & 2);
+    if (use_dc) {
+        // divide and conquer on the tridiagonal matrix; writes B (ascending eigenvalues)
+        double *scr = uv;
+        DcMat Qm { A.a, A.ld };
+        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) p * 2 * ld * (ld + 1),
+                d.B + (size_t) p * ld * ld, ld, scr, reinterpret_cast<int*>(scr + 1316), scr,
+                (d.stamps && p == 0) ? d.stamps : nullptr);
+    } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {
         QlState st { 0, 0, 1, 0, 0., 0. };
@@ -627,6 +639,9 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     EIG_STAMP(4);
 
     // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ---------
+    if (use_dc) {
+        for (int j = tid; j < n; j += T) gv[j] = dv[j];   // already ascending
+    } else {
     for (int j = tid; j < n; j += T) {
         const double dj = dv[j];
         int r = 0;
@@ -636,6 +651,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         }
         perm[j] = r;
         gv[r] = dj;   // sorted eigenvalues
+    }
     }
     __syncthreads();
     const double lo = gv[0], hi = gv[n - 1];
@@ -661,8 +677,9 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     double *Dp = d.D + (size_t) p * ld;
     double *Bp = d.B + (size_t) p * ld * ld;
     for (int i = tid; i < ld; i += T) Dp[i] = i < n ? sqrt(gv[i]) : 1.;
-    for (int k = wave; k < n; k += T / 64)
-        for (int j = lane; j < n; j += 64) Bp[(size_t) k * ld + perm[j]] = A(k, j);
+    if (!use_dc)
+        for (int k = wave; k < n; k += T / 64)
+            for (int j = lane; j < n; j += 64) Bp[(size_t) k * ld + perm[j]] = A(k, j);
     if (tid == 0) {
         sc->eigenlastev = sc->fev;
         sc->eigen_done = 1;
