@@ -7,11 +7,13 @@
 // in parallel lanes plus matrix products, and has no long dependent chain:
 //   1. scale T by a power of two (exact) to unit max-norm; tear it into leaves of <= 16 rows
 //      (rank-one tears, d[b-1] -= |e|, d[b] -= |e|);
-//   2. leaves: cyclic Jacobi, one wavefront per leaf;
-//   3. merge pairs bottom-up: sort the poles, deflate (tiny z, or two close poles rotated
-//      together), solve the secular equation 1 + rho sum z_i^2/(d_i - lam) = 0 for all roots in
-//      parallel (4 lanes per root; two-pole rational steps inside a bisection bracket, the
-//      root carried as (origin pole, offset) so d_i - lam is exact), recompute z by Loewner's
+//   2. leaves: the reference's own QL recurrence (bbo_eig_ql.hpp), one wavefront per leaf,
+//      all leaves at once (a 16 x 16 leaf is ~200 Givens steps, not 18 000);
+//   3. merge pairs bottom-up, ALL merges of a level at once (each by its own team of
+//      wavefronts): sort the poles, deflate (tiny z, or two close poles rotated together),
+//      solve the secular equation 1 + rho sum z_i^2/(d_i - lam) = 0 for all roots in parallel
+//      (up to 4 lanes per root; two-pole rational steps inside a bisection bracket, the root
+//      carried as (origin pole, offset) so d_i - lam is exact), recompute z by Loewner's
 //      formula (Gu-Eisenstat: orthogonality to rounding error without extended precision),
 //      form the eigenvectors of the rank-one update and multiply them into Q on the matrix
 //      cores (v_mfma_f64_16x16x4_f64), in place, 16 rows at a time;
@@ -22,6 +24,7 @@
 #pragma once
 
 #include "bbo_cma.hpp"
+#include "bbo_eig_ql.hpp"
 
 namespace bbo {
 
@@ -30,6 +33,7 @@ typedef double dc_d4 __attribute__((ext_vector_type(4)));
 constexpr int DC_LEAF = 16;
 constexpr int DC_MAXB = 16;          // max leaves (n <= 128 -> 8)
 constexpr double DC_EPS = 0x1.0p-53;
+constexpr int DC_KSTEPS = 32;        // k-steps of a 128-deep MFMA contraction
 
 struct DcMat {
     double *a;
@@ -43,106 +47,47 @@ __device__ inline void dc_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// ---- leaf: cyclic Jacobi on the s x s tridiagonal block, one wavefront -------------------
-// A (s x s, leading dimension 16) lives in LDS scratch, the eigenvectors at Q(a + r, a + c)
-__device__ inline void dc_leaf_jacobi(const DcMat &Q, int a, int s, double *A, double *dv,
-        const double *ev, int lane)
+// 1/x to (nearly) full precision: hardware estimate + two Newton steps
+__device__ inline double dc_rcp(double x)
 {
-    for (int q = lane; q < s * s; q += 64) {
-        const int r = q / s, c = q - r * s;
-        double v = 0.;
-        if (r == c) v = dv[a + r];
-        else if (c == r + 1) v = ev[a + r];
-        else if (r == c + 1) v = ev[a + c];
-        A[r * 16 + c] = v;
-        Q(a + r, a + c) = r == c ? 1. : 0.;
-    }
-    dc_wave_sync();
-    const int mp = (s + 1) & ~1;          // players, padded to even
-    const int pairidx = lane >> 3, sub = lane & 7;
-    for (int sweep = 0; sweep < 12; sweep++) {
-        double off = 0., dia = 0.;
-        for (int q = lane; q < s * s; q += 64) {
-            const int r = q / s, c = q - r * s;
-            const double v = A[r * 16 + c];
-            if (r == c) dia += v * v;
-            else off += v * v;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            off += __shfl_xor(off, o, 64);
-            dia += __shfl_xor(dia, o, 64);
-        }
-        if (off <= 1e-34 * dia || off == 0.) break;
-        for (int round = 0; round < mp - 1; round++) {
-            int p, q;
-            if (pairidx == 0) {
-                p = mp - 1;
-                q = round;
-            } else {
-                p = (round + pairidx) % (mp - 1);
-                q = (round - pairidx + (mp - 1)) % (mp - 1);
-            }
-            if (p > q) {
-                const int t = p;
-                p = q;
-                q = t;
-            }
-            const bool valid = pairidx < (mp >> 1) && q < s;
-            double cth = 1., sth = 0.;
-            if (valid) {
-                const double app = A[p * 16 + p], aqq = A[q * 16 + q], apq = A[p * 16 + q];
-                if (apq != 0.) {
-                    const double tau = (aqq - app) / (2. * apq);
-                    const double t = (tau >= 0. ? 1. : -1.) / (fabs(tau) + sqrt(1. + tau * tau));
-                    cth = 1. / sqrt(1. + t * t);
-                    sth = t * cth;
-                }
-            }
-            dc_wave_sync();
-            if (valid) {   // columns p, q of A and of the eigenvector block
-                for (int r = sub; r < s; r += 8) {
-                    const double x = A[r * 16 + p], y = A[r * 16 + q];
-                    A[r * 16 + p] = cth * x - sth * y;
-                    A[r * 16 + q] = sth * x + cth * y;
-                    const double vx = Q(a + r, a + p), vy = Q(a + r, a + q);
-                    Q(a + r, a + p) = cth * vx - sth * vy;
-                    Q(a + r, a + q) = sth * vx + cth * vy;
-                }
-            }
-            dc_wave_sync();
-            if (valid) {   // rows p, q of A
-                for (int c = sub; c < s; c += 8) {
-                    const double x = A[p * 16 + c], y = A[q * 16 + c];
-                    A[p * 16 + c] = cth * x - sth * y;
-                    A[q * 16 + c] = sth * x + cth * y;
-                }
-            }
-            dc_wave_sync();
-        }
-    }
-    for (int r = lane; r < s; r += 64) dv[a + r] = A[r * 16 + r];
-    dc_wave_sync();
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
 }
 
-// LDS work area of one merge
-struct DcWork {
-    double *dS, *zS;      // [m] poles / z in ascending pole order (modified by deflation)
-    double *dl, *w;       // [k] non-deflated poles (ascending) and their z
-    double *mu, *what;    // [k] root offsets, Loewner z
-    double *lam;          // [m] all eigenvalues of the merged block (unsorted)
-    double *ninv;         // [k] 1 / column norm
-    double *rotc, *rots;  // [m] deflation rotations
-    int *srcS;            // [m] sorted position -> original column
-    int *kp, *dp;         // [k] kept / [m-k] deflated sorted positions
-    int *org;             // [k] origin pole of root j
-    int *outpos;          // [m] output column of eigenvalue q
-    int *rotp, *rotj;     // [m] rotation row pairs
-    int *cnt;             // [4]: k, ndefl, nrot, flag
-    double *red;          // [16] reduction scratch
+// the team of wavefronts that works on one merge
+struct DcTeam {
+    int active;       // has a merge at this level
+    int ttid;         // thread index inside the team
+    int tthreads;     // threads of the team
+    int wave0, nwaves, twave;
+    int id;
 };
 
-__device__ inline double dc_block_sum(double v, double *red)
+// LDS work area shared by all merges of a level: every array is indexed by the block's
+// global column range [a, b), so concurrent merges use disjoint slices
+struct DcWork {
+    double *dS, *zS;      // poles / z in ascending pole order (modified by deflation)
+    double *dl, *w2;      // non-deflated poles (ascending), squared z
+    double *ws;           // sign carrier: z of the non-deflated poles
+    double *mu, *what;    // root offsets, Loewner z
+    double *lam;          // all eigenvalues of the merged block (unsorted)
+    double *ninv;         // 1 / column norm
+    double *rotc, *rots;  // deflation rotations
+    int *srcS;            // sorted position -> original column
+    int *kp, *dp;         // kept / deflated sorted positions
+    int *org;             // origin pole of root j
+    int *outpos;          // output column of eigenvalue q
+    int *rotp, *rotj;     // rotation row pairs
+    int *rowmap;          // original column -> kept index i, or -(1 + output column)
+    int *colroot;         // output column -> root j, or -1
+    int *cnt;             // [team][4]: k, ndefl, nrot
+    double *red;          // [16] reduction scratch (one slot per wavefront)
+    int *maxnr;           // [1]
+};
+
+__device__ inline double dc_team_sum(double v, double *red, const DcTeam &tm)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -150,75 +95,94 @@ __device__ inline double dc_block_sum(double v, double *red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.;
-    for (int w = 0; w < (int) (blockDim.x >> 6); w++) s += red[w];
+    for (int w = 0; w < tm.nwaves; w++) s += red[tm.wave0 + w];
     return s;
 }
 
-__device__ inline double dc_block_max(double v, double *red)
+__device__ inline double dc_team_max(double v, double *red, const DcTeam &tm)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    double s = red[0];
-    for (int w = 1; w < (int) (blockDim.x >> 6); w++) s = fmax(s, red[w]);
+    double s = red[tm.wave0];
+    for (int w = 1; w < tm.nwaves; w++) s = fmax(s, red[tm.wave0 + w]);
     return s;
 }
 
-// merge the blocks [a, mid) and [mid, b): Q (LDS) holds their eigenvectors on the diagonal
-// blocks (zeros elsewhere inside [a,b)^2), dv their eigenvalues; rho = coupling e[mid-1].
-// F (global, m x m) is scratch for the eigenvector factor.
-__device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rho_in, double *dv,
-        double *F, const DcWork &W, long long *stamps)
+template<int LPR>
+__device__ inline double dc_quad_sum(double v)
 {
-#define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a == 128) stamps[slot] = wall_clock64(); } while (0)
+#pragma unroll
+    for (int s = 1; s < LPR; s <<= 1) v += __shfl_xor(v, s, LPR);
+    return v;
+}
+
+// One level of merges: the team `tm` merges the blocks [a, mid) and [mid, b) (inactive teams
+// walk through the same barriers).  Q (LDS) holds the blocks' eigenvectors on its diagonal
+// blocks (zeros elsewhere inside [a,b)^2), dv their eigenvalues, rho_in = e[mid-1].
+// Fg (global) is scratch for the eigenvector factor of this merge (m x m).
+template<int LPR>
+__device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
+        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps)
+{
+#define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a > 64) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const int m = b - a;
+    const int lane = threadIdx.x & 63;
+    const int ttid = tm.ttid, TT = tm.tthreads;
+    const bool on = tm.active != 0;
+    const int m = on ? b - a : 0;
     const double sgn = rho_in >= 0. ? 1. : -1.;
+    // this merge's slices of the shared work arrays
+    DcWork W = W0;
+    W.dS += a; W.zS += a; W.dl += a; W.w2 += a; W.ws += a; W.mu += a; W.what += a; W.lam += a;
+    W.ninv += a; W.rotc += a; W.rots += a; W.srcS += a; W.kp += a; W.dp += a; W.org += a;
+    W.outpos += a; W.rotp += a; W.rotj += a; W.rowmap += a; W.colroot += a;
+    W.cnt += 4 * tm.id;
 
     // ---- poles and z, ascending -------------------------------------------------------
     double zi = 0., di = 0.;
-    if (tid < m) {
-        const int col = a + tid;
+    if (ttid < m) {
+        const int col = a + ttid;
         di = dv[col];
         zi = col < mid ? Q(mid - 1, col) : sgn * Q(mid, col);
     }
-    const double zn2 = dc_block_sum(tid < m ? zi * zi : 0., W.red);
+    const double zn2 = dc_team_sum(ttid < m ? zi * zi : 0., W.red, tm);
     const double zn = sqrt(zn2);
     const double rho = fabs(rho_in) * zn2;
-    if (tid < m) {
+    if (ttid < m) {
         zi /= zn;
-        W.lam[tid] = di;          // unsorted copies for the ranking below
-        W.what[tid] = zi;
+        W.lam[ttid] = di;          // unsorted copies for the ranking below
+        W.what[ttid] = zi;
     }
     __syncthreads();
-    if (tid < m) {
+    if (ttid < m) {
         int r = 0;
         for (int j = 0; j < m; j++) {
             const double dj = W.lam[j];
-            r += (dj < di) || (dj == di && j < tid);
+            r += (dj < di) || (dj == di && j < ttid);
         }
         W.dS[r] = di;
         W.zS[r] = zi;
-        W.srcS[r] = a + tid;
+        W.srcS[r] = a + ttid;
     }
-    const double dmax = dc_block_max(tid < m ? fabs(di) : 0., W.red);
-    const double zmax = dc_block_max(tid < m ? fabs(zi) : 0., W.red);
+    const double dmax = dc_team_max(ttid < m ? fabs(di) : 0., W.red, tm);
+    const double zmax = dc_team_max(ttid < m ? fabs(zi) : 0., W.red, tm);
     const double tol = 8. * DC_EPS * fmax(dmax, zmax);
     __syncthreads();
 
     MG_STAMP(25);
     // ---- deflation (sequential scan, LAPACK dlaed2's rules) ---------------------------
-    if (tid == 0) {
+    if (on && ttid == 0) {
         int k = 0, nd = 0, nr = 0;
         if (rho * zmax <= tol) {
             for (int j = 0; j < m; j++) W.dp[nd++] = j;
         } else {
             int pj = -1;
             for (int j = 0; j < m; j++) {
-                if (rho * fabs(W.zS[j]) <= tol) {
+                const double zj = W.zS[j];
+                if (rho * fabs(zj) <= tol) {
                     W.dp[nd++] = j;
                     continue;
                 }
@@ -226,12 +190,13 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
                     pj = j;
                     continue;
                 }
-                double s = W.zS[pj], cth = W.zS[j];
-                const double tau = hypot(cth, s);
+                // |t c s| <= tol with c = z_j / tau, s = -z_pj / tau, tau^2 = z_j^2 + z_pj^2,
+                // tested without forming tau
+                const double zp = W.zS[pj];
                 const double t = W.dS[j] - W.dS[pj];
-                cth /= tau;
-                s = -s / tau;
-                if (fabs(t * cth * s) <= tol) {
+                if (fabs(t * zj * zp) <= tol * (zj * zj + zp * zp)) {
+                    const double tau = hypot(zj, zp);
+                    const double cth = zj / tau, s = -zp / tau;
                     W.zS[j] = tau;
                     W.zS[pj] = 0.;
                     W.rotp[nr] = pj;
@@ -254,43 +219,41 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
         W.cnt[0] = k;
         W.cnt[1] = nd;
         W.cnt[2] = nr;
+        atomicMax(W.maxnr, nr);
     }
     __syncthreads();
-    const int k = W.cnt[0], nd = W.cnt[1], nr = W.cnt[2];
+    const int k = on ? W.cnt[0] : 0, nd = on ? W.cnt[1] : 0, nr = on ? W.cnt[2] : 0;
+    const int maxnr = *W.maxnr;
 
     // kept poles ascending (a rotation may perturb the order by rounding)
-    if (tid < k) {
-        const int pos = W.kp[tid];
+    if (ttid < k) {
+        const int pos = W.kp[ttid];
         const double dk = W.dS[pos];
         int r = 0;
         for (int j = 0; j < k; j++) {
             const double dj = W.dS[W.kp[j]];
-            r += (dj < dk) || (dj == dk && j < tid);
+            r += (dj < dk) || (dj == dk && j < ttid);
         }
+        const double z = W.zS[pos];
         W.dl[r] = dk;
-        W.w[r] = W.zS[pos];
+        W.ws[r] = z;
+        W.w2[r] = z * z;
         W.org[r] = pos;            // temporarily: sorted position of kept pole r
     }
     __syncthreads();
-    if (tid < k) W.kp[tid] = W.org[tid];
+    if (ttid < k) W.kp[ttid] = W.org[ttid];
     __syncthreads();
 
     MG_STAMP(26);
-    // ---- secular equation: 4 lanes per root ---------------------------------------------
-    if (k == 1) {
-        if (tid == 0) {
-            W.mu[0] = rho * W.w[0] * W.w[0];
-            W.org[0] = 0;
-        }
-    } else if (k > 1) {
-        const int j = tid >> 2, sub = tid & 3;
-        const bool act = j < k;
+    // ---- secular equation: LPR lanes per root -------------------------------------------
+    {
+        const int j = ttid / LPR, sub = ttid % LPR;
+        const bool act = on && k > 1 && j < k;
         const bool last = j == k - 1;
         double wsum = 0.;
         if (act && last)
-            for (int i = sub; i < k; i += 4) wsum += W.w[i] * W.w[i];
-        wsum += __shfl_xor(wsum, 1, 4);
-        wsum += __shfl_xor(wsum, 2, 4);
+            for (int i = sub; i < k; i += LPR) wsum += W.w2[i];
+        wsum = dc_quad_sum<LPR>(wsum);
         const double dj = act ? W.dl[j] : 0.;
         const double dn = act ? (last ? dj + rho * wsum : W.dl[j + 1]) : 1.;
         // origin: the sign of f at the midpoint
@@ -298,27 +261,24 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
         {
             const double midp = 0.5 * (dj + dn);
             if (act)
-                for (int i = sub; i < k; i += 4) fm += W.w[i] * W.w[i] / (W.dl[i] - midp);
-            fm += __shfl_xor(fm, 1, 4);
-            fm += __shfl_xor(fm, 2, 4);
-            fm = 1. + rho * fm;
+                for (int i = sub; i < k; i += LPR) fm += W.w2[i] * dc_rcp(W.dl[i] - midp);
+            fm = 1. + rho * dc_quad_sum<LPR>(fm);
         }
         const bool left = fm > 0. || last;
-        const int o = left ? j : j + 1;
-        const double dorg = act ? W.dl[min(o, k - 1)] : 0.;
+        const int o = act ? min(left ? j : j + 1, k - 1) : 0;
+        const double dorg = act ? W.dl[o] : 0.;
         const double gap = dn - dj;
         double lo = left ? 0. : -0.5 * gap;
         double hi = left ? (last ? gap : 0.5 * gap) : 0.;
         double mu = 0.5 * (lo + hi);
         bool done = !act;
         for (int it = 0; it < 64; it++) {
-            double f = 0., fp = 0., psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;
+            double psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;
             if (!done) {
-                for (int i = sub; i < k; i += 4) {
-                    const double den = (W.dl[i] - dorg) - mu;
-                    const double wi = W.w[i];
-                    const double t = wi * wi / den;
-                    const double tp = t / den;
+                for (int i = sub; i < k; i += LPR) {
+                    const double r = dc_rcp((W.dl[i] - dorg) - mu);
+                    const double t = W.w2[i] * r;
+                    const double tp = t * r;
                     fabs_ += fabs(t);
                     if (i <= j) {
                         psi += t;
@@ -329,18 +289,14 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
                     }
                 }
             }
-#pragma unroll
-            for (int s = 1; s < 4; s <<= 1) {
-                psi += __shfl_xor(psi, s, 4);
-                dpsi += __shfl_xor(dpsi, s, 4);
-                phi += __shfl_xor(phi, s, 4);
-                dphi += __shfl_xor(dphi, s, 4);
-                fabs_ += __shfl_xor(fabs_, s, 4);
-            }
+            psi = dc_quad_sum<LPR>(psi);
+            dpsi = dc_quad_sum<LPR>(dpsi);
+            phi = dc_quad_sum<LPR>(phi);
+            dphi = dc_quad_sum<LPR>(dphi);
+            fabs_ = dc_quad_sum<LPR>(fabs_);
             if (!done) {
                 psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho;
-                f = 1. + psi + phi;
-                fp = dpsi + dphi;
+                const double f = 1. + psi + phi;
                 const double err = 8. * DC_EPS * (1. + rho * fabs_ * (1. + k));
                 if (fabs(f) <= err) {
                     done = true;
@@ -373,97 +329,105 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
                     if (!(hi - lo > 4. * DC_EPS * fmax(fabs(lo), fabs(hi)))) done = true;
                     else mu = nmu;
                 }
-                (void) fp;
             }
             if (__syncthreads_count(done ? 0 : 1) == 0) break;
         }
         if (act && sub == 0) {
             W.mu[j] = mu;
-            W.org[j] = min(o, k - 1);
+            W.org[j] = o;
+        }
+        if (on && k == 1 && ttid == 0) {
+            W.mu[0] = rho * W.w2[0];
+            W.org[0] = 0;
         }
     }
     __syncthreads();
 
     MG_STAMP(27);
     // ---- Loewner z and column norms -------------------------------------------------------
-    if (k > 1) {
-        const int i = tid >> 2, sub = tid & 3;
+    {
+        const int i = ttid / LPR, sub = ttid % LPR;
         double prod = 1.;
-        if (i < k) {
+        if (on && k > 1 && i < k) {
             const double di2 = W.dl[i];
-            for (int jj = sub; jj < k; jj += 4) {
-                // lam_jj - d_i = (d_org - d_i) + mu
+            for (int jj = sub; jj < k; jj += LPR) {
+                // lam_jj - d_i = (d_org - d_i) + mu, paired with a denominator d_jj - d_i
                 const double num = (W.dl[W.org[jj]] - di2) + W.mu[jj];
-                // pair it with a denominator d_j' - d_i, j' != i
-                if (jj < i) prod *= num / (W.dl[jj] - di2);
-                else if (jj == i) prod *= num;
-                else prod *= num / (W.dl[jj] - di2);
+                prod *= jj == i ? num : num * dc_rcp(W.dl[jj] - di2);
             }
         }
-        prod *= __shfl_xor(prod, 1, 4);
-        prod *= __shfl_xor(prod, 2, 4);
-        if (i < k && sub == 0) {
+#pragma unroll
+        for (int s = 1; s < LPR; s <<= 1) prod *= __shfl_xor(prod, s, LPR);
+        if (on && k > 1 && i < k && sub == 0) {
             const double v = sqrt(fabs(prod));
-            W.what[i] = W.w[i] >= 0. ? v : -v;
+            W.what[i] = W.ws[i] >= 0. ? v : -v;
         }
-        __syncthreads();
-        const int j = tid >> 2;
-        double ss = 0.;
-        if (j < k)
-            for (int ii = sub; ii < k; ii += 4) {
-                const double del = (W.dl[ii] - W.dl[W.org[j]]) - W.mu[j];
-                const double s = W.what[ii] / del;
-                ss += s * s;
-            }
-        ss += __shfl_xor(ss, 1, 4);
-        ss += __shfl_xor(ss, 2, 4);
-        if (j < k && sub == 0) W.ninv[j] = 1. / sqrt(ss);
-    } else if (k == 1) {
-        if (tid == 0) {
+        if (on && k == 1 && ttid == 0) {
             W.what[0] = 1.;
             W.ninv[0] = 1.;
         }
+        __syncthreads();
+        const int j = i;
+        double ss = 0.;
+        if (on && k > 1 && j < k)
+            for (int ii = sub; ii < k; ii += LPR) {
+                const double s = W.what[ii] * dc_rcp((W.dl[ii] - W.dl[W.org[j]]) - W.mu[j]);
+                ss += s * s;
+            }
+        ss = dc_quad_sum<LPR>(ss);
+        if (on && k > 1 && j < k && sub == 0) W.ninv[j] = 1. / sqrt(ss);
     }
     __syncthreads();
 
     MG_STAMP(28);
-    // ---- all eigenvalues, their output order ------------------------------------------------
-    if (tid < k) W.lam[tid] = W.dl[W.org[tid]] + W.mu[tid];
-    if (tid < nd) W.lam[k + tid] = W.dS[W.dp[tid]];
+    // ---- all eigenvalues, their output order, the row / column maps of F ---------------------
+    if (ttid < k) W.lam[ttid] = W.dl[W.org[ttid]] + W.mu[ttid];
+    if (ttid < nd) W.lam[k + ttid] = W.dS[W.dp[ttid]];
     __syncthreads();
-    if (tid < m) {
-        const double v = W.lam[tid];
+    if (ttid < m) {
+        const double v = W.lam[ttid];
         int r = 0;
         for (int j = 0; j < m; j++) {
             const double u = W.lam[j];
-            r += (u < v) || (u == v && j < tid);
+            r += (u < v) || (u == v && j < ttid);
         }
-        W.outpos[tid] = r;
+        W.outpos[ttid] = r;
     }
     __syncthreads();
-
-    // ---- F = (deflation rotations) x (eigenvector factor), rows in ORIGINAL column order ---
-    for (int q = tid; q < m * m; q += T) F[q] = 0.;
-    __syncthreads();
-    if (k == 1) {
-        if (tid == 0) F[(size_t) (W.srcS[W.kp[0]] - a) * m + W.outpos[0]] = 1.;
-    } else {
-        for (int q = tid; q < k * k; q += T) {
-            const int i = q / k, j = q - i * k;
-            const double del = (W.dl[i] - W.dl[W.org[j]]) - W.mu[j];
-            F[(size_t) (W.srcS[W.kp[i]] - a) * m + W.outpos[j]] = W.what[i] / del * W.ninv[j];
-        }
+    if (ttid < k) {
+        W.rowmap[W.srcS[W.kp[ttid]] - a] = ttid;
+        W.colroot[W.outpos[ttid]] = ttid;
     }
-    if (tid < nd) F[(size_t) (W.srcS[W.dp[tid]] - a) * m + W.outpos[k + tid]] = 1.;
+    if (ttid < nd) {
+        W.rowmap[W.srcS[W.dp[ttid]] - a] = -(1 + W.outpos[k + ttid]);
+        W.colroot[W.outpos[k + ttid]] = -1;
+    }
     __syncthreads();
-    for (int r = nr - 1; r >= 0; r--) {
-        // Q G with G = [[c, -s], [s, c]] on sorted columns (p, j): rows p, j of F mix
-        const int rp = W.srcS[W.rotp[r]] - a, rj = W.srcS[W.rotj[r]] - a;
-        const double cth = W.rotc[r], s = W.rots[r];
-        for (int cidx = tid; cidx < m; cidx += T) {
-            const double x = F[(size_t) rp * m + cidx], y = F[(size_t) rj * m + cidx];
-            F[(size_t) rp * m + cidx] = cth * x - s * y;
-            F[(size_t) rj * m + cidx] = s * x + cth * y;
+    // F (rows in ORIGINAL column order), written in one pass
+    for (int q = ttid; q < m * m; q += TT) {
+        const int r = q / m, cidx = q - r * m;
+        const int i = W.rowmap[r], j = W.colroot[cidx];
+        double v = 0.;
+        if (i >= 0) {
+            if (j >= 0)
+                v = k == 1 ? 1.
+                           : W.what[i] * dc_rcp((W.dl[i] - W.dl[W.org[j]]) - W.mu[j]) * W.ninv[j];
+        } else if (-(1 + i) == cidx) {
+            v = 1.;
+        }
+        Fg[q] = v;
+    }
+    __syncthreads();
+    // deflation rotations, in reverse: Q G with G = [[c, -s], [s, c]] on sorted columns (p, j)
+    for (int r = maxnr - 1; r >= 0; r--) {
+        if (r < nr) {
+            const int rp = W.srcS[W.rotp[r]] - a, rj = W.srcS[W.rotj[r]] - a;
+            const double cth = W.rotc[r], s = W.rots[r];
+            for (int cidx = ttid; cidx < m; cidx += TT) {
+                const double x = Fg[(size_t) rp * m + cidx], y = Fg[(size_t) rj * m + cidx];
+                Fg[(size_t) rp * m + cidx] = cth * x - s * y;
+                Fg[(size_t) rj * m + cidx] = s * x + cth * y;
+            }
         }
         __syncthreads();
     }
@@ -471,78 +435,138 @@ __device__ inline void dc_merge(const DcMat &Q, int a, int mid, int b, double rh
     __syncthreads();
 
     MG_STAMP(29);
-    // ---- Q[a:b, a:b] <- Q[a:b, a:b] F on the matrix cores, 16 rows at a time, in place:
-    // every wavefront finishes reading the 16 old rows (all k) before any of them is stored
+    // ---- Q[a:b, a:b] <- Q[a:b, a:b] F on the matrix cores, 16 rows at a time, in place.
+    // A wavefront keeps the F fragments of its column tile(s) in registers for the whole
+    // merge; every wavefront finishes reading the 16 old rows before any of them is stored.
     const int fr = lane & 15, fk = lane >> 4;
     const int ntile = (m + 15) >> 4;
-    const int kpad = (m + 3) & ~3;
-    for (int rt = 0; rt < ntile; rt++) {
-        const int ct = wave;              // m <= 128: at most 8 column tiles, 8 wavefronts
-        dc_d4 acc = { 0., 0., 0., 0. };
+    const int ksteps = (m + 3) >> 2;
+    double bfrag[2][DC_KSTEPS];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int ct = tm.twave + u * tm.nwaves;
         const int col = ct * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < DC_KSTEPS; ks++) {
+            const int kk = 4 * ks + fk;
+            bfrag[u][ks] = (on && ct < ntile && kk < m && col < m) ? Fg[(size_t) kk * m + col] : 0.;
+        }
+    }
+    // every team walks the same number of row tiles (the widest merge of the level)
+    for (int rt = 0; rt < (DC_KSTEPS * 4) / 16; rt++) {
+        dc_d4 acc[2] = { { 0., 0., 0., 0. }, { 0., 0., 0., 0. } };
         const int arow = rt * 16 + fr;
-        if (ct < ntile) {
-            for (int ks = 0; ks < (kpad >> 2); ks++) {
-                const int kk = 4 * ks + fk;
-                const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
-                const double bv = (kk < m && col < m) ? F[(size_t) kk * m + col] : 0.;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        if (rt < ntile) {
+#pragma unroll
+            for (int ks = 0; ks < DC_KSTEPS; ks++) {
+                if (ks < ksteps) {
+                    const int kk = 4 * ks + fk;
+                    const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[1][ks], acc[1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
-        if (ct < ntile) {
+        if (rt < ntile) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = rt * 16 + (lane >> 4) + 4 * r;
-                if (row < m && col < m) Q(a + row, a + col) = acc[r];
+            for (int u = 0; u < 2; u++) {
+                const int col = (tm.twave + u * tm.nwaves) * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = rt * 16 + (lane >> 4) + 4 * r;
+                    if (row < m && col < m) Q(a + row, a + col) = acc[u][r];
+                }
             }
         }
     }
     __syncthreads();
-    if (tid < m) dv[a + W.outpos[tid]] = W.lam[tid];
+    if (ttid < m) dv[a + W.outpos[ttid]] = W.lam[ttid];
     __syncthreads();
     MG_STAMP(30);
 #undef MG_STAMP
 }
 
+// ---- leaf: the QL recurrence on the s x s tridiagonal block, one wavefront --------------
+// ws: per-wavefront LDS scratch, >= 2 * 20 doubles + 64 double2 + 3 * 64 ints
+__device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv_in,
+        const double *ev_in, double *dv_out, double *ws, int lane, long long *dbgout)
+{
+    double *dl = ws + 2;                  // front pads: the producer prefetches index -1
+    double *el = ws + 22;
+    double2 *rot = reinterpret_cast<double2*>(ws + 42);
+    int *desc = reinterpret_cast<int*>(ws + 42 + 128);
+    if (lane < 20) {
+        ws[lane] = 0.;
+        ws[20 + lane] = 0.;
+    }
+    dc_wave_sync();
+    if (lane < s) {
+        dl[lane] = dv_in[a + lane];
+        el[lane] = lane + 1 < s ? ev_in[a + lane] : 0.;
+    }
+    for (int q = lane; q < s * s; q += 64) {
+        const int r = q / s, c = q - r * s;
+        Q(a + r, a + c) = r == c ? 1. : 0.;
+    }
+    dc_wave_sync();
+    EigMat blk { &Q(a, a), Q.ld };
+    QlState st { 0, 0, 1, 0, 0., 0. };
+    // QL has no iteration limit in the reference either; the guard only bounds a run on
+    // non-finite input (30 sweeps per eigenvalue is far beyond anything observed)
+    for (int guard = 0; guard < 30 * s && !st.done; guard++) {
+        const int ns = ql_produce(st, s, dl, el, rot, desc, 64, lane);
+        dc_wave_sync();
+        if (lane < s) ql_apply_row(blk, lane, rot, desc, ns);
+        dc_wave_sync();
+        if (dbgout && lane == 0) dbgout[0] = guard + 1;
+    }
+    if (lane < s) dv_out[a + lane] = dl[lane];
+    dc_wave_sync();
+}
+
 // D&C driver.  On entry: dv = diagonal, ev[i] = coupling (i, i+1) (ev[n-1] = 0), Q (LDS) =
 // Householder matrix Q_house.  On exit: dv = eigenvalues ascending, Bout (global, ld) =
 // Q_house * Q_T, i.e. the eigenvectors of the original matrix in columns.
-// G (global): 2 * n * n doubles of scratch.  LDS: scratch >= 10 * 130 + 16 doubles, iscratch >=
-// 7 * 130 + 4 ints, leafA >= 16 * 256 doubles (may overlap scratch/iscratch: used before them... no:
-// the block reduction that sets the scale uses W.red, so leafA must not overlap W.red).
+// G (global): 2 * n * n doubles of scratch.  scratch (LDS): >= 3400 doubles.
 __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
-        double *Bout, int ldb, double *scratch, int *iscratch, double *leafA,
-        long long *stamps)
+        double *Bout, int ldb, double *scratch, long long *stamps, int dbg)
 {
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = T >> 6;
     double *Qh = G;                       // Q_house, n x n row-major
-    double *F = G + (size_t) n * n;       // merge factor
+    double *F = G + (size_t) n * n;       // merge factors (one m x m slab per merge)
     __shared__ int bounds[DC_MAXB + 1];
     __shared__ int nblk_s;
+    __shared__ int maxnr_s;
     __shared__ double scale_s;
 
     for (int q = tid; q < n * n; q += T) {
         const int r = q / n, c = q - r * n;
         Qh[q] = Q(r, c);
     }
-    // scale to unit max-norm by a power of two
-    double am = 0.;
-    for (int i = tid; i < n; i += T) am = fmax(am, fmax(fabs(dv[i]), fabs(ev[i])));
     DcWork W;
     {
         double *p = scratch;
         const int M = 130;
-        W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w = p; p += M;
+        W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
         W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
         W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
-        int *ip = iscratch;
+        int *ip = reinterpret_cast<int*>(p);
         W.srcS = ip; ip += M; W.kp = ip; ip += M; W.dp = ip; ip += M; W.org = ip; ip += M;
-        W.outpos = ip; ip += M; W.rotp = ip; ip += M; W.rotj = ip; ip += M; W.cnt = ip;
+        W.outpos = ip; ip += M; W.rotp = ip; ip += M; W.rotj = ip; ip += M;
+        W.rowmap = ip; ip += M; W.colroot = ip; ip += M; W.cnt = ip; ip += 4 * 8;
+        W.maxnr = &maxnr_s;
     }
-    am = dc_block_max(am, W.red);
+    // scale to unit max-norm by a power of two
+    double am = 0.;
+    for (int i = tid; i < n; i += T) am = fmax(am, fmax(fabs(dv[i]), fabs(ev[i])));
+    {
+        DcTeam all { 1, tid, T, 0, NW, wave, 0 };
+        am = dc_team_max(am, W.red, all);
+    }
     __syncthreads();
     if (tid == 0) {
         int ex = 0;
@@ -588,31 +612,53 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     __syncthreads();
 
     DC_STAMP(17);
-    // ---- leaves: one wavefront each, its 16 x 16 work matrix in LDS scratch (the merge work
-    // area is not in use yet).  W.red sits behind the first 8 leaf slots' worth? No: the leaf
-    // slots start at `leafA`, past the reduction scratch used above.
-    for (int blk = wave; blk < nblk; blk += (T >> 6)) {
+    // ---- leaves: one wavefront each; the merge work area is not in use yet ------------------
+    if (!(dbg & 8))
+    for (int blk = wave; blk < nblk; blk += NW) {
         const int a = bounds[blk], s = bounds[blk + 1] - a;
-        dc_leaf_jacobi(Q, a, s, leafA + (size_t) blk * 256, dv, ev, lane);
+        dc_leaf_ql(Q, a, s, dv, ev, dv, scratch + (size_t) wave * 272, lane,
+                stamps ? stamps + 12 + (blk & 3) : nullptr);
     }
     __syncthreads();
 
     DC_STAMP(18);
-    // ---- merges, bottom-up ---------------------------------------------------------------------
-    // level structure = the halving above run backwards: adjacent blocks pair up while the
-    // block list is walked left to right
+    // ---- merges, bottom-up; all merges of a level run at once, each by its own team --------
     int cur[DC_MAXB + 1];
     int nc = nblk;
     for (int i = 0; i <= nblk; i++) cur[i] = bounds[i];
-    while (nc > 1) {
+    while (nc > 1 && !(dbg & 4)) {
+        const int nm = nc >> 1;                       // merges at this level
+        int teams = 1;
+        while (teams < nm) teams <<= 1;               // 1, 2, 4, 8
+        const int wpt = NW / teams > 0 ? NW / teams : 1;   // wavefronts per team
+        DcTeam tm;
+        tm.id = wave / wpt;
+        tm.active = tm.id < nm;
+        tm.wave0 = tm.id * wpt;
+        tm.nwaves = wpt;
+        tm.twave = wave - tm.wave0;
+        tm.ttid = tid - 64 * tm.wave0;
+        tm.tthreads = 64 * wpt;
+        if (tid == 0) maxnr_s = 0;
+        __syncthreads();
+        const int q = tm.active ? tm.id : 0;
+        const int a = cur[2 * q], mid = cur[2 * q + 1], b = cur[2 * q + 2];
+        double *Fg = F + (size_t) a * n;
+        const double rho = ev[mid - 1];
+        // lanes per secular root: as many as every team of this level can give its poles
+        // (chosen from the WIDEST merge so that all teams run the same code path)
+        int m = 0;
+        for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
+        if (4 * m <= tm.tthreads)
+            dc_merge_level<4>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+        else if (2 * m <= tm.tthreads)
+            dc_merge_level<2>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+        else
+            dc_merge_level<1>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
         int nxt[DC_MAXB + 1];
         int nn = 0;
         nxt[nn++] = cur[0];
-        for (int i = 0; i + 1 < nc; i += 2) {
-            const int a = cur[i], mid = cur[i + 1], b = cur[i + 2];
-            dc_merge(Q, a, mid, b, ev[mid - 1], dv, F, W, stamps);
-            nxt[nn++] = b;
-        }
+        for (int i = 0; i + 1 < nc; i += 2) nxt[nn++] = cur[i + 2];
         if (nc & 1) nxt[nn++] = cur[nc];
         nc = nn - 1;
         for (int i = 0; i <= nc; i++) cur[i] = nxt[i];
@@ -641,25 +687,36 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     __syncthreads();
 
     DC_STAMP(22);
-    // ---- B = Q_house * Q_T on the matrix cores ------------------------------------------------
+    // ---- B = Q_house * Q_T on the matrix cores: a wavefront keeps the Q_house fragments of
+    // its row tile in registers and sweeps the column tiles ---------------------------------
     const int ntile = (n + 15) >> 4;
-    const int kpad = (n + 3) & ~3;
+    const int ksteps = (n + 3) >> 2;
     const int fr = lane & 15, fk = lane >> 4;
-    for (int t = wave; t < ntile * ntile; t += (T >> 6)) {
-        const int rt = t / ntile, ct = t - rt * ntile;
-        dc_d4 acc = { 0., 0., 0., 0. };
-        const int arow = rt * 16 + fr, col = ct * 16 + fr;
-        for (int ks = 0; ks < (kpad >> 2); ks++) {
-            const int kk = 4 * ks + fk;
-            const double av = (arow < n && kk < n) ? Qh[(size_t) arow * n + kk] : 0.;
-            const double bv = (kk < n && col < n) ? Q(kk, col) : 0.;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
+    for (int rt = wave; rt < ntile; rt += NW) {
+        double afrag[DC_KSTEPS];
+        const int arow = rt * 16 + fr;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = rt * 16 + (lane >> 4) + 4 * r;
-            if (row < n && col < n)
-                Bout[(size_t) row * ldb + (single ? W.outpos[col] : col)] = acc[r];
+        for (int ks = 0; ks < DC_KSTEPS; ks++) {
+            const int kk = 4 * ks + fk;
+            afrag[ks] = (arow < n && kk < n) ? Qh[(size_t) arow * n + kk] : 0.;
+        }
+        for (int ct = 0; ct < ntile; ct++) {
+            dc_d4 acc = { 0., 0., 0., 0. };
+            const int col = ct * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < DC_KSTEPS; ks++) {
+                if (ks < ksteps) {
+                    const int kk = 4 * ks + fk;
+                    const double bv = (kk < n && col < n) ? Q(kk, col) : 0.;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[ks], bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rt * 16 + (lane >> 4) + 4 * r;
+                if (row < n && col < n)
+                    Bout[(size_t) row * ldb + (single ? W.outpos[col] : col)] = acc[r];
+            }
         }
     }
     __syncthreads();

@@ -1,0 +1,214 @@
+// bbo_eig_ql.hpp -- the implicit-shift QL recurrence of the reference (tql2, cmaes.cpp:383-456)
+// split into a producer (scalar recurrence on (d, e), records Givens pairs) and a consumer
+// (applies recorded pairs to one row of the eigenvector matrix).  Used by cma_eigen's QL path
+// (bbo_eig.hpp) and by the leaves of the divide-and-conquer path (bbo_eig_dc.hpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace bbo {
+
+constexpr int EIG_MAXSEQ = 64;
+
+struct EigMat {
+    double *a;
+    int ld;
+    __device__ double& operator()(int i, int j) const { return a[(size_t) i * ld + j]; }
+};
+
+// wavefront sum on the cross-lane data path (DPP row rotations, then one readlane per
+// 16-lane row) instead of LDS permutes; every lane gets the same total, and the fixed
+// order makes it identical in every wavefront that sums the same values
+template<int CTRL>
+__device__ inline double eig_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double eig_readlane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double eig_wave_sum(double v)
+{
+    v += eig_dpp<0x128>(v);   // row_ror:8
+    v += eig_dpp<0x124>(v);   // row_ror:4
+    v += eig_dpp<0x122>(v);   // row_ror:2
+    v += eig_dpp<0x121>(v);   // row_ror:1
+    return ((eig_readlane(v, 0) + eig_readlane(v, 16)) + eig_readlane(v, 32))
+            + eig_readlane(v, 48);
+}
+
+// Lanes of one wavefront talk through LDS here (lane 0 walks the recurrence, the others shift
+// the diagonal and search for the split).  The hardware keeps a wavefront's LDS operations in
+// order, but the COMPILER reasons per thread: on the path that skips the `if (lane == 0)` block
+// it may hoist a later load above the block and so read what lane 0 is about to overwrite.
+// Every hand-over point therefore carries a wavefront-scope fence.
+__device__ inline void ql_wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// state of the QL recurrence, uniform across the producer wavefront
+struct QlState {
+    int l, m, need_m, done;
+    double f, tst1;
+};
+
+// Producer: advances the QL recurrence on (dv, ev), recording up to `rc` Givens pairs of
+// whole sweeps into `rot` (pair for column i of sweep q at rot[off_q + i - l_q]) and their
+// descriptors (l, m, off) into `desc`.  Executed by all 64 lanes of wavefront 0; lane 0
+// walks the recurrence, the other lanes help with the O(n) shift and the split search.
+__device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, double2 *rot,
+        int *desc, int rc, int lane)
+{
+    const double eps = 0x1.0p-52;
+    int count = 0, ns = 0;
+    while (!st.done) {
+        ql_wave_fence();
+        if (st.need_m) {
+            const double dl = dv[st.l], el = ev[st.l];
+            st.tst1 = fmax(st.tst1, fabs(dl) + fabs(el));
+            const double thr = eps * st.tst1;
+            int m = n;
+            for (int base = st.l; base < n; base += 64) {
+                const int idx = base + lane;
+                const bool ok = idx < n && fabs(ev[idx]) <= thr;
+                const unsigned long long mask = __ballot(ok);
+                if (mask) {
+                    m = base + __builtin_ctzll(mask);
+                    break;
+                }
+            }
+            st.m = m;
+            st.need_m = 0;
+            if (m >= n) {   // unreachable for finite input: e[n-1] == 0
+                st.done = 1;
+                break;
+            }
+            if (m == st.l) {
+                if (lane == 0) {
+                    dv[st.l] = dl + st.f;
+                    ev[st.l] = 0.;
+                }
+                st.l++;
+                st.need_m = 1;
+                if (st.l >= n) st.done = 1;
+                continue;
+            }
+        }
+        const int l = st.l, m = st.m, len = m - l;
+        if (count + len > rc || ns >= EIG_MAXSEQ) break;
+        const double thr = eps * st.tst1;
+
+        // implicit shift (cmaes.cpp:405-417)
+        const double g0 = dv[l], d1 = dv[l + 1], el = ev[l];
+        const double p0 = (d1 - g0) / (2. * el);
+        double r0 = hypot(p0, 1.);
+        r0 = p0 >= 0. ? fabs(r0) : -fabs(r0);
+        const double dl_new = el / (p0 + r0);
+        const double dl1 = el * (p0 + r0);
+        const double h0 = g0 - dl_new;
+        ql_wave_fence();
+        for (int i = l + 2 + lane; i < n; i += 64) dv[i] -= h0;
+        st.f += h0;
+        ql_wave_fence();
+
+        if (lane == 0) {
+            dv[l] = dl_new;
+            dv[l + 1] = dl1;
+            // implicit QL sweep (cmaes.cpp:419-449)
+            double pp = dv[m];
+            double cth = 1., c2 = 1., c3 = 1., s = 0., s2 = 0.;
+            const double el1 = ev[l + 1];
+            double ei = ev[m - 1], di = dv[m - 1];
+            double2 *out = rot + count;
+            for (int i = m - 1; i >= l; i--) {
+                // next column's (e, d): always a legal address (the vectors carry a front pad)
+                const double ein = ev[i - 1], din = dv[i - 1];
+                c3 = c2;
+                c2 = cth;
+                s2 = s;
+                const double g = cth * ei;
+                const double h = cth * pp;
+                const double t = fma(pp, pp, ei * ei);
+                // 1/sqrt(t): hardware estimate + one third-order correction (full fp64)
+                double y = __builtin_amdgcn_rsq(t);
+                const double err = fma(-t * y, y, 1.);
+                y = fma(y * err, fma(err, 0.375, 0.5), y);
+                const double r = t * y;             // = hypot(pp, ei) to rounding
+                ev[i + 1] = s * r;
+                s = ei * y;
+                cth = pp * y;
+                pp = fma(cth, di, -(s * g));
+                dv[i + 1] = h + s * fma(cth, g, s * di);
+                out[i - l] = make_double2(cth, s);
+                ei = ein;
+                di = din;
+            }
+            pp = -s * s2 * c3 * el1 * ev[l] / dl1;
+            ev[l] = s * pp;
+            dv[l] = cth * pp;
+        }
+        ql_wave_fence();
+        desc[3 * ns + 0] = l;
+        desc[3 * ns + 1] = m;
+        desc[3 * ns + 2] = count;
+        count += len;
+        ns++;
+        const double el_new = ev[l];
+        if (!(fabs(el_new) > thr)) {
+            if (lane == 0) {
+                dv[l] += st.f;
+                ev[l] = 0.;
+            }
+            st.l++;
+            st.need_m = 1;
+            if (st.l >= n) st.done = 1;
+        }
+    }
+    return ns;
+}
+
+// Consumer: applies the recorded sweeps to row k of the eigenvector matrix
+// (the inner k-loop of cmaes.cpp:438-443, one lane per k)
+__device__ inline void ql_apply_row(const EigMat &A, int k, const double2 *rot,
+        const int *desc, int ns)
+{
+    for (int q = 0; q < ns; q++) {
+        const int l = desc[3 * q], m = desc[3 * q + 1];
+        const int cb = desc[3 * q + 2] - l;               // rot[cb + i] = pair of column i
+        double hcur = A(k, m);
+        int i = m - 1;
+        for (; i - 3 >= l; i -= 4) {
+            const double x0 = A(k, i), x1 = A(k, i - 1), x2 = A(k, i - 2), x3 = A(k, i - 3);
+            const double2 r0 = rot[cb + i], r1 = rot[cb + i - 1], r2 = rot[cb + i - 2],
+                    r3 = rot[cb + i - 3];
+            A(k, i + 1) = r0.y * x0 + r0.x * hcur;
+            hcur = r0.x * x0 - r0.y * hcur;
+            A(k, i) = r1.y * x1 + r1.x * hcur;
+            hcur = r1.x * x1 - r1.y * hcur;
+            A(k, i - 1) = r2.y * x2 + r2.x * hcur;
+            hcur = r2.x * x2 - r2.y * hcur;
+            A(k, i - 2) = r3.y * x3 + r3.x * hcur;
+            hcur = r3.x * x3 - r3.y * hcur;
+        }
+        for (; i >= l; i--) {
+            const double x = A(k, i);
+            const double2 r = rot[cb + i];
+            A(k, i + 1) = r.y * x + r.x * hcur;
+            hcur = r.x * x - r.y * hcur;
+        }
+        A(k, l) = hcur;
+    }
+}
+
+
+} // namespace bbo
