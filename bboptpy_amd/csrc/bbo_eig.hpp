@@ -69,11 +69,14 @@ inline EigPlan eig_plan(int n, int ld)
 // tred2 + reflector accumulation for n <= 128 with the matrix in REGISTERS: thread
 // (row j = tid >> 2, class q = tid & 3) owns A(j, k) for k = 32a + 8q + b (a < 4, b < 8);
 // LDS carries only the O(n) vectors (zero-padded beyond the active block, so the inner
-// loops need no bounds tests) and the stashed Householder vectors (column i of Astash).
-// Phase 2 rebuilds Q column-tiled (thread owns Q(k, j) for its 32 rows k of column j).
+// loops need no bounds tests) and the stashed Householder vectors (ROW i of Astash holds the
+// vector of step i).  Phase 2 rebuilds Q column-tiled (thread owns Q(k, j) for its 32 rows k
+// of column j) and needs no barrier at all: a column only reads the stashed vectors.
+// Against cmaes.cpp:293-381 the Householder vectors are left unscaled (the reference divides
+// by sum|d| first): the reflector I - u u^T / h is the same, one reduction per step is saved.
 __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, const EigMat &As,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
-        double *uh0, double *uh1, int tid)
+        int tid, long long *stamps)
 {
     const int T = EIG_THREADS, lane = tid & 63;
     const int j = tid >> 2, q = tid & 3;
@@ -95,12 +98,12 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         __syncthreads();
         const double d0 = lane < i ? dv[lane] : 0.;
         const double d1 = lane + 64 < i ? dv[lane + 64] : 0.;
-        const double scale = eig_wave_sum(fabs(d0) + fabs(d1));
-        if (scale == 0.) {
-            const double dprev = dv[i - 1];
+        const double h0 = eig_wave_sum(d0 * d0 + d1 * d1);
+        const double f = dv[i - 1];
+        if (h0 == 0.) {
             __syncthreads();
             if (tid == 0) {
-                ev[i] = dprev;
+                ev[i] = f;
                 hvec[i] = 0.;
             }
             if (j == i - 1) {
@@ -111,17 +114,14 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
             }
             continue;
         }
-        const double u0 = d0 / scale, u1 = d1 / scale;
-        double h = eig_wave_sum(u0 * u0 + u1 * u1);
-        {
-            const double f = dv[i - 1] / scale;
-            double g = sqrt(h);
-            if (f > 0) g = -g;
-            h = h - f * g;
-            uv[lane] = lane < i ? (lane == i - 1 ? f - g : u0) : 0.;
-            uv[lane + 64] = lane + 64 < i ? (lane + 64 == i - 1 ? f - g : u1) : 0.;
-            if (tid == 0) ev[i] = scale * g;
-        }
+        double g = sqrt(h0);
+        if (f > 0) g = -g;
+        const double h = h0 - f * g;
+        // every wavefront writes the SAME u (one store per element), so a wavefront may read
+        // what it wrote without waiting for the others
+        uv[lane] = lane < i ? (lane == i - 1 ? f - g : d0) : 0.;
+        uv[lane + 64] = lane + 64 < i ? (lane + 64 == i - 1 ? f - g : d1) : 0.;
+        if (tid == 0) ev[i] = g;
         // g = A u (no bounds tests: u is zero beyond the active block); this thread's 32
         // entries of u stay in registers for the rank-2 update below
         double ur[4][8];
@@ -134,16 +134,20 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
                 ur[a][b + 1] = t2.y;
             }
         {
-            double acc = 0.;
+            double acc0 = 0., acc1 = 0.;
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 8; b++) acc += a_[a][b] * ur[a][b];
+                for (int b = 0; b < 8; b += 2) {
+                    acc0 += a_[a][b] * ur[a][b];
+                    acc1 += a_[a][b + 1] * ur[a][b + 1];
+                }
+            double acc = acc0 + acc1;
             acc += __shfl_xor(acc, 1, 4);
             acc += __shfl_xor(acc, 2, 4);
             if (q == 0 && j < i) {
                 gv[j] = acc;
-                As(j, i) = uv[j];
+                As(i, j) = uv[j];          // stash: row i = the Householder vector of step i
             }
         }
         __syncthreads();
@@ -175,6 +179,7 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         if (tid == 0) hvec[i] = h;
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[1] = wall_clock64();
     // diagonal of the tridiagonal matrix: A(j, j) as it stands
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -182,36 +187,39 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         for (int b = 0; b < 8; b++)
             if (32 * a + 8 * q + b == j && j < n) td[j] = a_[a][b];
 
-    // ---- phase 2: Q = H(n-1) ... H(1), column-tiled in registers, starting from I ----------
+    // ---- phase 2: Q = H(n-1) ... H(1), column-tiled in registers, starting from I.  Column
+    // j only needs the stashed vectors (read-only now): no barrier inside the loop ------------
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 8; b++) a_[a][b] = (32 * a + 8 * q + b == j) ? 1. : 0.;
     for (int i = 0; i < n - 1; i++) {
         const double h = hvec[i + 1];
-        double *uh = (i & 1) ? uh1 : uh0;
-        if (h != 0. && tid < 128) uh[tid] = tid < n ? As(tid, i + 1) / h : 0.;
-        __syncthreads();
         if (h != 0.) {
-            double acc = 0.;
+            double ur[4][8];
+            double acc0 = 0., acc1 = 0.;
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
                     const int k = 32 * a + 8 * q + b;
-                    const double uk = k < n ? As(k, i + 1) : 0.;
-                    acc += uk * a_[a][b];
+                    ur[a][b] = k < n ? As(i + 1, k) : 0.;
                 }
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
                 for (int b = 0; b < 8; b += 2) {
-                    const double2 h2 = *reinterpret_cast<const double2*>(&uh[32 * a + 8 * q + b]);
-                    a_[a][b] -= acc * h2.x;
-                    a_[a][b + 1] -= acc * h2.y;
+                    acc0 += ur[a][b] * a_[a][b];
+                    acc1 += ur[a][b + 1] * a_[a][b + 1];
                 }
+            double acc = acc0 + acc1;
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            const double gq = acc / h;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) a_[a][b] -= gq * ur[a][b];
         }
     }
     __syncthreads();
@@ -268,7 +276,8 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         ev[-1 - tid] = 0.;
     }
     if (pl.reg_path) {
-        eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, uh0, uh1, tid);
+        eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
+                (d.stamps && p == 0) ? d.stamps : nullptr);
     } else {
     for (int i = wave; i < n; i += T / 64)
         for (int j = lane; j < n; j += 64) A(i, j) = C[(size_t) i * ld + j];
