@@ -252,14 +252,32 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
 void CmaEngine::launch_sample_eval()
 {
     const CmaConst &c = c_;
-    dim3 grid(c.lambda_pad / 16, c.npop);
-    const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
     timer_.begin(stream_, K_SAMPLE);
-    switch (pick_maxt(c.ld)) {
-    case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
-    case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;
-    case 4: hipLaunchKernelGGL(cma_sample_eval<4>, grid, dim3(256), lds, stream_, d_, c_); break;
-    default: hipLaunchKernelGGL(cma_sample_eval<8>, grid, dim3(256), lds, stream_, d_, c_); break;
+    if (c.ld <= 128) {
+        // 64 candidates per workgroup, packed operand held in registers
+        dim3 grid((c.lambda_pad + 63) / 64, c.npop);
+        const size_t lds = (size_t) 64 * (c.ld + 2) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval64<1>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval64<2>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr_done = true;
+        }
+        if (c.ld <= 64)
+            hipLaunchKernelGGL(cma_sample_eval64<1>, grid, dim3(256), lds, stream_, d_, c_);
+        else
+            hipLaunchKernelGGL(cma_sample_eval64<2>, grid, dim3(256), lds, stream_, d_, c_);
+    } else {
+        dim3 grid(c.lambda_pad / 16, c.npop);
+        const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
+        switch (pick_maxt(c.ld)) {
+        case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
+        case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;
+        case 4: hipLaunchKernelGGL(cma_sample_eval<4>, grid, dim3(256), lds, stream_, d_, c_); break;
+        default: hipLaunchKernelGGL(cma_sample_eval<8>, grid, dim3(256), lds, stream_, d_, c_); break;
+        }
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
@@ -309,8 +327,9 @@ void CmaEngine::launch_update()
     {
         const int NT = c.ld / 16, LT = NT * (NT + 1) / 2;
         const int ldy = gram_ldy(c.ld);
-        dim3 grid(c.splits, (LT + 31) / 32, c.npop);
-        const size_t lds = (size_t) (c.rps * ldy + 2 * c.rps) * sizeof(double);
+        dim3 grid(c.splits, (LT + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW), c.npop);
+        const int rpp = 256 / (c.ld / 4) > 0 ? 256 / (c.ld / 4) : 1;
+        const size_t lds = (size_t) (c.rps * ldy + 2 * c.rps + (size_t) rpp * c.ld) * sizeof(double);
         static bool attr_done = false;
         if (!attr_done) {
             BBO_HIP(hipFuncSetAttribute((const void*) cma_gram,

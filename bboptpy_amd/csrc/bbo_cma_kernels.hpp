@@ -140,6 +140,120 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
 }
 
 // ---------------------------------------------------------------------------
+// sample + evaluate for ld <= 128: 64 candidates per workgroup.  A wavefront loads the
+// (B D) fragments of its column tiles ONCE into registers and sweeps four 16-row tiles of
+// normals with them, so the packed operand is read once per 64 candidates instead of once
+// per 16.  grid (ceil(lambda_pad/64), P), 256 threads; dynamic LDS 64*(ld+2) doubles
+// ---------------------------------------------------------------------------
+template<int MAXT>
+__global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y, row0 = blockIdx.x * 64;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ld = c.ld, ldz = ld + 2;
+    const int gen = sc->it;
+    const int NT = ld >> 4, KS = ld >> 2;
+
+    // (B D) fragments of this wavefront's column tiles
+    const double *bdp = d.BDp + (size_t) p * ld * ld;
+    double bfr[MAXT][32];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int nt = wave + 4 * t;
+#pragma unroll
+        for (int ks = 0; ks < 32; ks++)
+            bfr[t][ks] = (nt < NT && ks < KS) ? bdp[((size_t) nt * KS + ks) * 64 + lane] : 0.;
+    }
+
+    // standard normals of the 64 candidates (Box-Muller pairs)
+    const int npairs = ld >> 1;
+    for (int q = tid; q < 64 * npairs; q += 256) {
+        const int r = q / npairs, pj = q - r * npairs;
+        const int row = row0 + r, j = 2 * pj;
+        double z0 = 0., z1 = 0.;
+        if (row < c.lambda && j < c.n) {
+            if (d.zinject) {
+                const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
+                z0 = zi[j];
+                z1 = (j + 1 < c.n) ? zi[j + 1] : 0.;
+            } else {
+                normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
+                        stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
+                if (j + 1 >= c.n) z1 = 0.;
+            }
+            if (d.zrecord) {
+                double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
+                zr[j] = z0;
+                if (j + 1 < c.n) zr[j + 1] = z1;
+            }
+        }
+        *reinterpret_cast<double2*>(&lds[r * ldz + j]) = make_double2(z0, z1);
+    }
+    __syncthreads();
+
+    d4_t acc[4][MAXT];
+    const int ar = lane & 15, ak = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) acc[mt][t] = d4_t { 0., 0., 0., 0. };
+#pragma unroll
+        for (int ks = 0; ks < 32; ks++) {
+            if (ks < KS) {
+                const double a = lds[(mt * 16 + ar) * ldz + 4 * ks + ak];
+#pragma unroll
+                for (int t = 0; t < MAXT; t++)
+                    acc[mt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfr[t][ks], acc[mt][t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    const double sigma = sc->sigma;
+    const double *xm = d.xmean + (size_t) p * ld;
+    double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) {
+            const int nt = wave + 4 * t;
+            if (nt < NT) {
+                const int col = nt * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int rl = mt * 16 + (lane >> 4) + 4 * r;
+                    double v = 0.;
+                    if (col < c.n) {
+                        v = xm[col] + sigma * acc[mt][t][r];
+                        if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+                    }
+                    lds[rl * ldz + col] = v;
+                    if (row0 + rl < c.lambda_pad) Xp[((size_t) row0 + rl) * ld + col] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (c.obj >= 0) {
+        const int g = tid & 15;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int r = (tid >> 4) + 16 * rr;
+            double f = eval_row_group<16>(c.obj, c.n, &lds[r * ldz], d.aux, g);
+            const int row = row0 + r;
+            if (g == 0 && row < c.lambda_pad) {
+                if (!(row < c.lambda) || f != f) f = BBO_INF;
+                d.f[(size_t) p * c.lambda_pad + row] = f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // rank: rank[i] = #{ j : f_j < f_i  or (f_j == f_i and j < i) }, order[rank[i]] = i
 // grid (ceil(lambda/32), P), 256 threads = 32 candidates x 8 slices of the population
 // ---------------------------------------------------------------------------
@@ -294,21 +408,24 @@ __device__ inline void tri_tile(int q, int &ti, int &tj)
     tj = q - ti * (ti + 1) / 2;
 }
 
+constexpr int GRAM_TPW = 9;   // lower 16x16 tiles per wavefront (36 per workgroup)
+
 __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
 {
     const int p = blockIdx.z, s = blockIdx.x, tg = blockIdx.y;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c.ld, rps = c.rps;
     double *Y = lds;                 // [rps][ldy]   y = (x - xold) / sigma
     double *V = lds + rps * ldy;     // [rps]        gram coefficient of the row
     double *W = V + rps;             // [rps]        recombination weight of the row
+    double *R = W + rps;             // [rows per pass][ld] partial sums of the mean
     const double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
     const double *xold = d.xmean + (size_t) p * ld;
     const int *rank = d.rank + (size_t) p * c.lambda_pad;
-    const double sigma = sc->sigma;
+    const double isig = 1. / sc->sigma;
     const int row0 = s * rps;
 
     if (tid < rps) {
@@ -319,31 +436,52 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
         W[tid] = wm;
     }
     __syncthreads();
-    // stage the slab; the same pass accumulates this slab's share of the mean
-    for (int col = tid; col < ld; col += 256) {
-        double msum = 0.;
-        const double xo = xold[col];
-        for (int r = 0; r < rps; r++) {
+    // stage the slab: 4 columns per thread, `rpp` rows per pass, all loads independent;
+    // the same pass accumulates this slab's share of the weighted mean
+    const int tpr = ld >> 2, rpp = 256 / tpr;
+    const int c4 = (tid % tpr) * 4, r0 = tid / tpr;
+    if (r0 < rpp) {
+        double m0 = 0., m1 = 0., m2 = 0., m3 = 0.;
+        const double2 xo01 = *reinterpret_cast<const double2*>(&xold[c4]);
+        const double2 xo23 = *reinterpret_cast<const double2*>(&xold[c4 + 2]);
+        for (int r = r0; r < rps; r += rpp) {
             const int row = row0 + r;
-            double x = 0., y = 0.;
-            if (row < c.lambda && col < c.n) {
-                x = Xp[(size_t) row * ld + col];
-                y = (x - xo) / sigma;
+            double2 a01 = make_double2(0., 0.), a23 = make_double2(0., 0.);
+            if (row < c.lambda) {
+                a01 = *reinterpret_cast<const double2*>(&Xp[(size_t) row * ld + c4]);
+                a23 = *reinterpret_cast<const double2*>(&Xp[(size_t) row * ld + c4 + 2]);
             }
-            Y[r * ldy + col] = y;
-            msum += W[r] * x;
+            const double wr = W[r];
+            m0 += wr * a01.x; m1 += wr * a01.y; m2 += wr * a23.x; m3 += wr * a23.y;
+            const bool in = row < c.lambda;
+            double2 y01, y23;
+            y01.x = (in && c4 < c.n) ? (a01.x - xo01.x) * isig : 0.;
+            y01.y = (in && c4 + 1 < c.n) ? (a01.y - xo01.y) * isig : 0.;
+            y23.x = (in && c4 + 2 < c.n) ? (a23.x - xo23.x) * isig : 0.;
+            y23.y = (in && c4 + 3 < c.n) ? (a23.y - xo23.y) * isig : 0.;
+            *reinterpret_cast<double2*>(&Y[r * ldy + c4]) = y01;
+            *reinterpret_cast<double2*>(&Y[r * ldy + c4 + 2]) = y23;
         }
-        if (tg == 0) d.mean_part[((size_t) p * c.splits + s) * ld + col] = msum;
+        if (tg == 0) {
+            double *rr = R + r0 * ld + c4;
+            rr[0] = m0; rr[1] = m1; rr[2] = m2; rr[3] = m3;
+        }
     }
     __syncthreads();
+    if (tg == 0)
+        for (int col = tid; col < ld; col += 256) {
+            double msum = 0.;
+            for (int g = 0; g < rpp; g++) msum += R[g * ld + col];
+            d.mean_part[((size_t) p * c.splits + s) * ld + col] = msum;
+        }
 
     const int NT = ld >> 4, LT = NT * (NT + 1) / 2;
-    d4_t acc[8];
-    int ti[8], tj[8];
+    d4_t acc[GRAM_TPW];
+    int ti[GRAM_TPW], tj[GRAM_TPW];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < GRAM_TPW; t++) {
         acc[t] = d4_t { 0., 0., 0., 0. };
-        const int q = tg * 32 + wave + 4 * t;
+        const int q = tg * (4 * GRAM_TPW) + wave + 4 * t;
         ti[t] = tj[t] = 0;
         if (q < LT) tri_tile(q, ti[t], tj[t]);
     }
@@ -353,8 +491,8 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
         const double vk = V[k];
         const double *yk = Y + k * ldy;
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int q = tg * 32 + wave + 4 * t;
+        for (int t = 0; t < GRAM_TPW; t++) {
+            const int q = tg * (4 * GRAM_TPW) + wave + 4 * t;
             if (q < LT) {
                 const double a = vk * yk[ti[t] * 16 + fr];
                 const double b = yk[tj[t] * 16 + fr];
@@ -364,8 +502,8 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
     }
     double *G = d.gram_part + ((size_t) p * c.splits + s) * ld * ld;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int q = tg * 32 + wave + 4 * t;
+    for (int t = 0; t < GRAM_TPW; t++) {
+        const int q = tg * (4 * GRAM_TPW) + wave + 4 * t;
         if (q < LT) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
