@@ -137,6 +137,12 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
 
     // Gram split-K geometry
     c.rps = 64;
+    if (c.ld == 128) {
+        // cma_gram128 streams its slab: size the slabs for ~1024 workgroups over all populations
+        int want = std::max(1, std::min(32, (1024 + P - 1) / P));
+        want = std::min(want, (c.lambda_pad + G128_CH - 1) / G128_CH);
+        c.rps = ((c.lambda_pad + want - 1) / want + G128_CH - 1) / G128_CH * G128_CH;
+    }
     c.splits = (c.lambda_pad + c.rps - 1) / c.rps;
 
     // ---- HBM state ------------------------------------------------------------
@@ -324,7 +330,19 @@ void CmaEngine::launch_update()
         timer_.end(stream_);
         BBO_HIP(hipGetLastError());
     }
-    {
+    if (c.ld == 128) {
+        const size_t lds = (size_t) (2 * G128_CH * G128_LDY + 4 * G128_CH) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_gram128,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr_done = true;
+        }
+        timer_.begin(stream_, K_GRAM);
+        hipLaunchKernelGGL(cma_gram128, dim3(c.splits, c.npop), dim3(256), lds, stream_, d_, c_);
+        timer_.end(stream_);
+        BBO_HIP(hipGetLastError());
+    } else {
         const int NT = c.ld / 16, LT = NT * (NT + 1) / 2;
         const int ldy = gram_ldy(c.ld);
         dim3 grid(c.splits, (LT + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW), c.npop);

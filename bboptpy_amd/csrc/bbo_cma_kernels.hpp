@@ -397,7 +397,7 @@ __device__ inline void rank_coefficients(const CmaDev &d, const CmaConst &c, int
 }
 
 // ---------------------------------------------------------------------------
-// gram: slab s of  G = sum_k v_k y_k y_k^T  (lower 16x16 tiles) and of the weighted mean
+// gram: slab s of  G = sum_k v_k y_k y_k^T  (lower 16x16 tiles) and of sum_k w_k y_k
 // grid (splits, tile_groups, P), 256 threads; dynamic LDS rps*ldy + rps doubles
 // ---------------------------------------------------------------------------
 __device__ inline void tri_tile(int q, int &ti, int &tj)
@@ -452,13 +452,13 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
                 a23 = *reinterpret_cast<const double2*>(&Xp[(size_t) row * ld + c4 + 2]);
             }
             const double wr = W[r];
-            m0 += wr * a01.x; m1 += wr * a01.y; m2 += wr * a23.x; m3 += wr * a23.y;
             const bool in = row < c.lambda;
             double2 y01, y23;
             y01.x = (in && c4 < c.n) ? (a01.x - xo01.x) * isig : 0.;
             y01.y = (in && c4 + 1 < c.n) ? (a01.y - xo01.y) * isig : 0.;
             y23.x = (in && c4 + 2 < c.n) ? (a23.x - xo23.x) * isig : 0.;
             y23.y = (in && c4 + 3 < c.n) ? (a23.y - xo23.y) * isig : 0.;
+            m0 += wr * y01.x; m1 += wr * y01.y; m2 += wr * y23.x; m3 += wr * y23.y;
             *reinterpret_cast<double2*>(&Y[r * ldy + c4]) = y01;
             *reinterpret_cast<double2*>(&Y[r * ldy + c4 + 2]) = y23;
         }
@@ -516,6 +516,184 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
 }
 
 // ---------------------------------------------------------------------------
+// gram for ld == 128 (the n = 128 headline shape): the slab streams through LDS in 32-row
+// chunks, double buffered, the next chunk's global loads in flight while the matrix cores
+// work on the current one.  The 36 lower tiles are dealt to the four wavefronts as
+// rectangular blocks, so a k-step costs 5-6 LDS reads for 9 MFMAs:
+//     wave 0: tile rows 5-7 x cols 0-2        wave 1: tile rows 2-4 x cols 0-2
+//     wave 2: rows 5-7 x cols 3-4, (3,3) (4,3) (4,4)
+//     wave 3: (0,0) (1,0) (1,1), lower triangle of rows 5-7 x cols 5-7
+// grid (splits, P), 256 threads, 2 workgroups per CU
+// ---------------------------------------------------------------------------
+constexpr int G128_CH = 32;          // rows per chunk
+constexpr int G128_LDY = 128 + 16;
+constexpr int G128_TI[4][9] = { { 5, 5, 5, 6, 6, 6, 7, 7, 7 }, { 2, 2, 2, 3, 3, 3, 4, 4, 4 },
+        { 5, 5, 6, 6, 7, 7, 3, 4, 4 }, { 0, 1, 1, 5, 6, 6, 7, 7, 7 } };
+constexpr int G128_TJ[4][9] = { { 0, 1, 2, 0, 1, 2, 0, 1, 2 }, { 0, 1, 2, 0, 1, 2, 0, 1, 2 },
+        { 3, 4, 3, 4, 3, 4, 3, 3, 4 }, { 0, 0, 1, 5, 5, 6, 5, 6, 7 } };
+
+constexpr bool g128_mean(int wv, int i) { return (wv == 1 && i <= 4) || (wv == 2 && i >= 5); }
+constexpr bool g128_needs_a(int wv, int i)
+{
+    for (int t = 0; t < 9; t++) if (G128_TI[wv][t] == i) return true;
+    return false;
+}
+constexpr bool g128_needs_y(int wv, int i)
+{
+    for (int t = 0; t < 9; t++) if (G128_TI[wv][t] == i || G128_TJ[wv][t] == i) return true;
+    return g128_mean(wv, i);
+}
+
+template<int WV>
+__device__ inline void gram128_chunk(const double *Yb, const double *Vb, const double *Wb,
+        d4_t (&acc)[9], double (&macc)[8], int fr, int fk)
+{
+#pragma unroll
+    for (int ks = 0; ks < G128_CH / 4; ks++) {
+        const int k = 4 * ks + fk;
+        const double vk = Vb[k];
+        const double *yk = Yb + k * G128_LDY + fr;
+        double y[8], a[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            y[i] = a[i] = 0.;
+            if (g128_needs_y(WV, i)) y[i] = yk[i * 16];
+            if (g128_needs_a(WV, i)) a[i] = vk * y[i];
+        }
+        if (WV == 1 || WV == 2) {
+            const double wk = Wb[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (g128_mean(WV, i)) macc[i] = fma(wk, y[i], macc[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[G128_TI[WV][t]], y[G128_TJ[WV][t]],
+                    acc[t], 0, 0, 0);
+    }
+}
+
+template<int WV>
+__device__ inline void gram128_store(double *G, double *mp, const d4_t (&acc)[9],
+        double (&macc)[8], int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = G128_TI[WV][t] * 16 + (lane >> 4) + 4 * r;
+            const int j = G128_TJ[WV][t] * 16 + (lane & 15);
+            G[(size_t) i * 128 + j] = acc[t][r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (g128_mean(WV, i)) {
+            double m = macc[i];
+            m += __shfl_xor(m, 16, 64);
+            m += __shfl_xor(m, 32, 64);
+            if (lane < 16) mp[i * 16 + lane] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y, s = blockIdx.x;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double (*Y)[G128_CH * G128_LDY] = reinterpret_cast<double (*)[G128_CH * G128_LDY]>(lds);
+    double (*V)[G128_CH] = reinterpret_cast<double (*)[G128_CH]>(lds + 2 * G128_CH * G128_LDY);
+    double (*W)[G128_CH] = V + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    const double *xold = d.xmean + (size_t) p * 128;
+    const int *rank = d.rank + (size_t) p * c.lambda_pad;
+    const double isig = 1. / sc->sigma;
+    const int row0 = s * c.rps;
+    const int nch = (min(c.rps, c.lambda_pad - row0) + G128_CH - 1) / G128_CH;
+
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+    const double2 xo01 = *reinterpret_cast<const double2*>(&xold[c4]);
+    const double2 xo23 = *reinterpret_cast<const double2*>(&xold[c4 + 2]);
+    const bool in0 = c4 < c.n, in1 = c4 + 1 < c.n, in2 = c4 + 2 < c.n, in3 = c4 + 3 < c.n;
+    double2 pf[4][2];
+    double pv = 0., pw = 0.;
+
+    auto fetch = [&](int ch) {
+        const int base = row0 + ch * G128_CH;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = base + r0 + 8 * i;
+            const double *src = Xp + (size_t) row * 128 + c4;
+            pf[i][0] = pf[i][1] = make_double2(0., 0.);
+            if (row < c.lambda_pad) {
+                pf[i][0] = *reinterpret_cast<const double2*>(src);
+                pf[i][1] = *reinterpret_cast<const double2*>(src + 2);
+            }
+        }
+        if (tid < G128_CH) {
+            const int row = base + tid;
+            pv = pw = 0.;
+            if (row < c.lambda) rank_coefficients(d, c, p, rank[row], pw, pv);
+        }
+    };
+    auto stash = [&](int ch, int buf) {
+        const int base = row0 + ch * G128_CH;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + 8 * i;
+            const bool in = base + r < c.lambda;
+            double2 y01, y23;
+            y01.x = (in && in0) ? (pf[i][0].x - xo01.x) * isig : 0.;
+            y01.y = (in && in1) ? (pf[i][0].y - xo01.y) * isig : 0.;
+            y23.x = (in && in2) ? (pf[i][1].x - xo23.x) * isig : 0.;
+            y23.y = (in && in3) ? (pf[i][1].y - xo23.y) * isig : 0.;
+            *reinterpret_cast<double2*>(&Y[buf][r * G128_LDY + c4]) = y01;
+            *reinterpret_cast<double2*>(&Y[buf][r * G128_LDY + c4 + 2]) = y23;
+        }
+        if (tid < G128_CH) {
+            V[buf][tid] = pv;
+            W[buf][tid] = pw;
+        }
+    };
+
+    d4_t acc[9];
+    double macc[8];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+#pragma unroll
+    for (int i = 0; i < 8; i++) macc[i] = 0.;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch++) {
+        const int buf = ch & 1;
+        if (ch + 1 < nch) fetch(ch + 1);
+        switch (wave) {
+        case 0: gram128_chunk<0>(Y[buf], V[buf], W[buf], acc, macc, fr, fk); break;
+        case 1: gram128_chunk<1>(Y[buf], V[buf], W[buf], acc, macc, fr, fk); break;
+        case 2: gram128_chunk<2>(Y[buf], V[buf], W[buf], acc, macc, fr, fk); break;
+        default: gram128_chunk<3>(Y[buf], V[buf], W[buf], acc, macc, fr, fk); break;
+        }
+        if (ch + 1 < nch) stash(ch + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    double *G = d.gram_part + ((size_t) p * c.splits + s) * 128 * 128;
+    double *mp = d.mean_part + ((size_t) p * c.splits + s) * 128;
+    switch (wave) {
+    case 0: gram128_store<0>(G, mp, acc, macc, lane); break;
+    case 1: gram128_store<1>(G, mp, acc, macc, lane); break;
+    case 2: gram128_store<2>(G, mp, acc, macc, lane); break;
+    default: gram128_store<3>(G, mp, acc, macc, lane); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
@@ -536,6 +714,7 @@ __global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
         for (int s = 0; s < c.splits; s++)
             sum += d.mean_part[((size_t) p * c.splits + s) * ld + j];
         const double xo = xmean[j];
+        sum = xo + sigma * sum;   // the slabs hold sum_k w_k (x_k - xold) / sigma
         double xn = 0.;
         if (j < c.n) {
             xn = c.variant == 1 ? xo * (1. - c.cm) + sum * c.cm : sum;

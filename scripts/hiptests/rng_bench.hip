@@ -1,0 +1,81 @@
+// dev microbenchmark: where does normal_pair's time go?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../../bboptpy_amd/csrc/bbo_rng.hpp"
+using namespace bbo;
+
+template<int V>
+__global__ __launch_bounds__(256) void k(double *out, int reps)
+{
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.;
+    for (int i = 0; i < reps; i++) {
+        if (V == 0) {
+            const u32x4 w = philox4x32_10(1234, tid, i, 7, 1 << 24);
+            acc += (double) (w.x ^ w.y ^ w.z ^ w.w);
+        } else if (V == 1) {
+            const u32x4 w = philox4x32_10(1234, tid, i, 7, 1 << 24);
+            const double u1 = u01_open0(w.x, w.y), u2 = u01(w.z, w.w);
+            acc += sqrt(-2. * log(u1)) + u2;
+        } else if (V == 2) {
+            double a, b;
+            normal_pair(1234, tid, i, 7, 1 << 24, a, b);
+            acc += a + b;
+        } else if (V == 3) {
+            const u32x4 w = philox4x32_10(1234, tid, i, 7, 1 << 24);
+            const double u1 = u01_open0(w.x, w.y), u2 = u01(w.z, w.w);
+            const double r = sqrt(-2. * log(u1));
+            double s, c;
+            sincospi(2. * u2, &s, &c);
+            acc += r * c + r * s;
+        } else if (V == 4) {
+            // log + sqrt only, no philox
+            const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
+            acc += sqrt(-2. * log(u1));
+        } else if (V == 5) {
+            const double u2 = (tid * 977u + i * 31u) * 0x1.0p-32;
+            double s, c;
+            sincos(6.283185307179586 * u2, &s, &c);
+            acc += s + c;
+        } else if (V == 6) {
+            const double u2 = (tid * 977u + i * 31u) * 0x1.0p-32;
+            double s, c;
+            sincospi(2. * u2, &s, &c);
+            acc += s + c;
+        }
+    }
+    out[tid] = acc;
+}
+
+template<int V>
+void run(const char *name, double *out)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    const int reps = 64, blocks = 8192;
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    const double calls = (double) reps * blocks * 256;
+    // cycles per wave-call per SIMD: 1024 SIMDs at 2.4 GHz
+    printf("%-28s %8.3f ms  %7.1f Gcalls/s  ~%6.0f SIMD-cycles per wave-call\n", name, ms,
+            calls / ms * 1e-6, ms * 1e-3 * 2.4e9 * 1024 / (calls / 64));
+}
+
+int main()
+{
+    double *out;
+    hipMalloc(&out, 8192 * 256 * 8);
+    run<0>("philox", out);
+    run<1>("philox+log+sqrt", out);
+    run<2>("normal_pair (sincos)", out);
+    run<3>("normal_pair (sincospi)", out);
+    run<4>("log+sqrt", out);
+    run<5>("sincos", out);
+    run<6>("sincospi", out);
+    return 0;
+}
