@@ -259,7 +259,20 @@ void CmaEngine::launch_sample_eval()
 {
     const CmaConst &c = c_;
     timer_.begin(stream_, K_SAMPLE);
-    if (c.ld <= 128) {
+    if (c.ld == 128 && (long) c.npop * c.lambda_pad >= 256 * 128
+            && (c.obj < 0 || frag_objective_ok(c.obj))) {
+        // whole populations in flight: packed operand in LDS, normals drawn into the A fragments
+        int rw = (int) ((long) c.npop * c.lambda_pad / 256) / 128 * 128;
+        rw = std::max(128, std::min(512, rw));
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval128,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_done = true;
+        }
+        dim3 grid((c.lambda_pad + rw - 1) / rw, c.npop);
+        hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw);
+    } else if (c.ld <= 128) {
         // 64 candidates per workgroup, packed operand held in registers
         dim3 grid((c.lambda_pad + 63) / 64, c.npop);
         const size_t lds = (size_t) 64 * (c.ld + 2) * sizeof(double);

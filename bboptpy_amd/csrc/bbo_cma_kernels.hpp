@@ -60,26 +60,26 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     const int npairs = ld >> 1;
     for (int q = tid; q < 16 * npairs; q += 256) {
         const int r = q / npairs, pj = q - r * npairs;
-        const int row = mt * 16 + r, j = 2 * pj;
+        const int row = mt * 16 + r, j0 = cma_pair_col0(pj), j1 = j0 + 4;
         double z0 = 0., z1 = 0.;
-        if (row < c.lambda && j < c.n) {
+        if (row < c.lambda && j0 < c.n) {
             if (d.zinject) {
                 const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                z0 = zi[j];
-                z1 = (j + 1 < c.n) ? zi[j + 1] : 0.;
+                z0 = zi[j0];
+                z1 = (j1 < c.n) ? zi[j1] : 0.;
             } else {
                 normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
                         stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
-                if (j + 1 >= c.n) z1 = 0.;
+                if (j1 >= c.n) z1 = 0.;
             }
             if (d.zrecord) {
                 double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                zr[j] = z0;
-                if (j + 1 < c.n) zr[j + 1] = z1;
+                zr[j0] = z0;
+                if (j1 < c.n) zr[j1] = z1;
             }
         }
-        lds[r * ldz + j] = z0;
-        lds[r * ldz + j + 1] = z1;
+        lds[r * ldz + j0] = z0;
+        lds[r * ldz + j1] = z1;
     }
     __syncthreads();
 
@@ -172,25 +172,26 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
     const int npairs = ld >> 1;
     for (int q = tid; q < 64 * npairs; q += 256) {
         const int r = q / npairs, pj = q - r * npairs;
-        const int row = row0 + r, j = 2 * pj;
+        const int row = row0 + r, j0 = cma_pair_col0(pj), j1 = j0 + 4;
         double z0 = 0., z1 = 0.;
-        if (row < c.lambda && j < c.n) {
+        if (row < c.lambda && j0 < c.n) {
             if (d.zinject) {
                 const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                z0 = zi[j];
-                z1 = (j + 1 < c.n) ? zi[j + 1] : 0.;
+                z0 = zi[j0];
+                z1 = (j1 < c.n) ? zi[j1] : 0.;
             } else {
                 normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
                         stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
-                if (j + 1 >= c.n) z1 = 0.;
+                if (j1 >= c.n) z1 = 0.;
             }
             if (d.zrecord) {
                 double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                zr[j] = z0;
-                if (j + 1 < c.n) zr[j + 1] = z1;
+                zr[j0] = z0;
+                if (j1 < c.n) zr[j1] = z1;
             }
         }
-        *reinterpret_cast<double2*>(&lds[r * ldz + j]) = make_double2(z0, z1);
+        lds[r * ldz + j0] = z0;
+        lds[r * ldz + j1] = z1;
     }
     __syncthreads();
 
@@ -248,6 +249,115 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
             if (g == 0 && row < c.lambda_pad) {
                 if (!(row < c.lambda) || f != f) f = BBO_INF;
                 d.f[(size_t) p * c.lambda_pad + row] = f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sample + evaluate for ld == 128 (the headline shape), whole populations in flight:
+// the packed (B D) operand of the population sits in LDS (128 KB, loaded once per
+// workgroup), each wavefront owns whole 16-candidate tiles: it DRAWS the normals straight
+// into its MFMA A fragments (the Philox column layout is the fragment layout, see
+// cma_pair_col0), sweeps the 8 column tiles, and evaluates the objective on the
+// accumulators.  No LDS traffic besides the B fragments, no barrier after the fill; two
+// wavefronts per SIMD let one's Box-Muller (VALU) overlap the other's MFMA sweep.
+// grid (ceil(lambda_pad / rows_per_wg), P), 512 threads, dynamic LDS 128 KB
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst c, int rows_per_wg)
+{
+    const int p = blockIdx.y, row0 = blockIdx.x * rows_per_wg;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double bd[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const double2 *src = reinterpret_cast<const double2*>(d.BDp + (size_t) p * 128 * 128);
+        double2 *dst = reinterpret_cast<double2*>(bd);
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
+    }
+    __syncthreads();
+
+    const int gen = sc->it;
+    const double sigma = sc->sigma;
+    const int tiles = min(rows_per_wg, c.lambda_pad - row0) >> 4;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double *xm = d.xmean + (size_t) p * 128;
+    double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+
+    for (int tile = wave; tile < tiles; tile += 8) {
+        const int rowbase = row0 + tile * 16;
+        const int row = rowbase + fr;
+        d4_t acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+        // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk], then sweep them
+#pragma unroll 1
+        for (int kc = 0; kc < 4; kc++) {
+            double a[8];
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int q = 4 * kc + qq;
+                const int j0 = 8 * q + fk, j1 = j0 + 4;
+                double z0 = 0., z1 = 0.;
+                if (row < c.lambda && j0 < c.n) {
+                    if (d.zinject) {
+                        const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
+                        z0 = zi[j0];
+                        z1 = (j1 < c.n) ? zi[j1] : 0.;
+                    } else {
+                        normal_pair(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk), (uint32_t) gen,
+                                sw, z0, z1);
+                        if (j1 >= c.n) z1 = 0.;
+                    }
+                    if (d.zrecord) {
+                        double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
+                        zr[j0] = z0;
+                        if (j1 < c.n) zr[j1] = z1;
+                    }
+                }
+                a[2 * qq] = z0;
+                a[2 * qq + 1] = z1;
+            }
+            const double *bk = bd + kc * 8 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bk[(t * 32 + i) * 64],
+                            acc[t], 0, 0, 0);
+            }
+        }
+
+        double x[8][4];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int col = t * 16 + fr;
+            const double xmc = xm[col];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = 0.;
+                if (col < c.n) {
+                    v = xmc + sigma * acc[t][r];
+                    if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+                }
+                x[t][r] = v;
+                Xp[((size_t) rowbase + fk + 4 * r) * 128 + col] = v;
+            }
+        }
+        if (c.obj >= 0) {
+            double f[4];
+            eval_frag_rows<8>(c.obj, c.n, x, d.aux, lane, f);
+            if (fr == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int rr = rowbase + fk + 4 * r;
+                    double fv = f[r];
+                    if (!(rr < c.lambda) || fv != fv) fv = BBO_INF;
+                    d.f[(size_t) p * c.lambda_pad + rr] = fv;
+                }
             }
         }
     }

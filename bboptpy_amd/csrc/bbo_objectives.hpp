@@ -119,4 +119,122 @@ __device__ inline double eval_row_group(int obj, int n, const double *x, const d
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same objectives on a tile that is still in MFMA accumulator layout: x[t][r] is
+// column 16 t + (lane & 15) of row (lane >> 4) + 4 r.  The 16 lanes that share a row are
+// one DPP row, so sums, products, neighbours and prefix sums stay on the cross-lane data
+// path (no LDS round trip).  Every lane of a row returns the row's f in f[r].  Only the
+// objectives without transcendental terms are offered here (frag_objective_ok): 32 inlined
+// cos/pow bodies per lane do not fit the register budget next to the accumulators, those
+// objectives go through eval_row_group from LDS instead.
+// ---------------------------------------------------------------------------
+template<int CTRL>
+__device__ inline double row16_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double row16_sum(double v)
+{
+    v += row16_dpp<0x128>(v);   // row_ror:8
+    v += row16_dpp<0x124>(v);   // row_ror:4
+    v += row16_dpp<0x122>(v);   // row_ror:2
+    v += row16_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+
+__device__ inline double row16_prod(double v)
+{
+    v *= row16_dpp<0x128>(v);
+    v *= row16_dpp<0x124>(v);
+    v *= row16_dpp<0x122>(v);
+    v *= row16_dpp<0x121>(v);
+    return v;
+}
+
+// lane i <- lane (i + 1) mod 16 of the same row
+__device__ inline double row16_next(double v) { return row16_dpp<0x12F>(v); }   // row_ror:15
+
+// inclusive prefix sum over the 16 lanes of a row (row_shr:1,2,4,8; lanes shifted in read 0)
+__device__ inline double row16_scan(double v)
+{
+    v += row16_dpp<0x111>(v);
+    v += row16_dpp<0x112>(v);
+    v += row16_dpp<0x114>(v);
+    v += row16_dpp<0x118>(v);
+    return v;
+}
+
+__host__ __device__ inline bool frag_objective_ok(int obj)
+{
+    return obj == OBJ_SPHERE || obj == OBJ_ROSENBROCK || obj == OBJ_ELLIPSOID || obj == OBJ_CIGAR
+            || obj == OBJ_DISCUS || obj == OBJ_SCHWEFEL12;
+}
+
+template<int NT>
+__device__ inline void eval_frag_rows(int obj, int n, const double (&x)[NT][4], const double *aux,
+        int lane, double (&f)[4])
+{
+    const int c0 = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double a = 0.;
+        switch (obj) {
+        case OBJ_SPHERE:
+#pragma unroll
+            for (int t = 0; t < NT; t++) a += (16 * t + c0 < n) ? x[t][r] * x[t][r] : 0.;
+            f[r] = row16_sum(a);
+            break;
+        case OBJ_ROSENBROCK:
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const double xj = x[t][r];
+                const double same = row16_next(xj);
+                const double wrap = row16_next(x[t + 1 < NT ? t + 1 : t][r]);
+                const double xn = c0 < 15 ? same : wrap;
+                const double tt = xn - xj * xj;
+                const double u = 1. - xj;
+                a += (16 * t + c0 + 1 < n) ? 100. * (tt * tt) + u * u : 0.;
+            }
+            f[r] = row16_sum(a);
+            break;
+        case OBJ_ELLIPSOID:
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                a += (16 * t + c0 < n) ? aux[16 * t + c0] * (x[t][r] * x[t][r]) : 0.;
+            f[r] = row16_sum(a);
+            break;
+        case OBJ_CIGAR:
+        case OBJ_DISCUS: {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int j = 16 * t + c0;
+                a += (j > 0 && j < n) ? x[t][r] * x[t][r] : 0.;
+            }
+            a = row16_sum(a);
+            const double x0 = row16_sum(c0 == 0 ? x[0][r] : 0.);
+            f[r] = obj == OBJ_CIGAR ? x0 * x0 + 1.0e6 * a : 1.0e6 * (x0 * x0) + a;
+            break;
+        }
+        case OBJ_SCHWEFEL12: {
+            double carry = 0.;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const double v = (16 * t + c0 < n) ? x[t][r] : 0.;
+                const double run = carry + row16_scan(v);
+                a += (16 * t + c0 < n) ? run * run : 0.;
+                carry += row16_sum(v);
+            }
+            f[r] = row16_sum(a);
+            break;
+        }
+        default:
+            f[r] = 0.;
+        }
+    }
+}
+
 } // namespace bbo

@@ -75,19 +75,86 @@ __host__ __device__ inline int uint_below(uint32_t w, int range)
     return (int) (((uint64_t) w * (uint64_t) (uint32_t) range) >> 32);
 }
 
-// one Philox call -> two standard normals (Box-Muller)
+// ln(u) for u in [2^-53, 1].  Only +, *, /, fma -- oracle/philox.h (bbo_log_unit) states the
+// same arithmetic on the CPU and gets the same bits.  u = m 2^e, m in [sqrt(1/2), sqrt(2)),
+// ln m = 2 atanh(s), s = (m - 1)/(m + 1), odd series to s^23.  About a third of ocml's log.
+__device__ inline double log_unit(double u)
+{
+    const uint64_t b = (uint64_t) __double_as_longlong(u);
+    int e = (int) (b >> 52) - 1023;
+    double m = __longlong_as_double((long long) ((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    const bool big = m > 0x1.6a09e667f3bcdp+0;
+    m = big ? m * 0.5 : m;
+    e += big ? 1 : 0;
+    const double s = (m - 1.) / (m + 1.);
+    const double z = s * s;
+    double p = 1. / 23.;
+    p = __builtin_fma(p, z, 1. / 21.);
+    p = __builtin_fma(p, z, 1. / 19.);
+    p = __builtin_fma(p, z, 1. / 17.);
+    p = __builtin_fma(p, z, 1. / 15.);
+    p = __builtin_fma(p, z, 1. / 13.);
+    p = __builtin_fma(p, z, 1. / 11.);
+    p = __builtin_fma(p, z, 1. / 9.);
+    p = __builtin_fma(p, z, 1. / 7.);
+    p = __builtin_fma(p, z, 1. / 5.);
+    p = __builtin_fma(p, z, 1. / 3.);
+    const double s2 = s + s;
+    const double lm = __builtin_fma(s2 * z, p, s2);
+    const double de = (double) e;
+    return __builtin_fma(de, 0x1.62e42fee00000p-1, __builtin_fma(de, 0x1.a39ef35793c76p-33, lm));
+}
+
+// sin and cos of 2 pi t, t in [0, 1) a multiple of 2^-53: exact octant reduction, then the
+// fdlibm kernel polynomials on [0, pi/4] (oracle twin: bbo_sincos_turn)
+__device__ inline void sincos_turn(double t, double &sn, double &cs)
+{
+    const double v = t * 8.;
+    const int k = (int) v;
+    double f = v - (double) k;
+    const bool odd = (k & 1) != 0;
+    f = odd ? 1. - f : f;
+    const double x = f * 0x1.921fb54442d18p-1;
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sx = __builtin_fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cx = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.));
+    const int q = ((k + 1) >> 1) & 3;
+    const double sy = odd ? -sx : sx;
+    const double s_even = (q & 2) ? -sy : sy, c_even = (q & 2) ? -cx : cx;   // q = 0, 2
+    const double s_odd = (q & 2) ? -cx : cx, c_odd = (q & 2) ? sy : -sy;     // q = 1, 3
+    sn = (q & 1) ? s_odd : s_even;
+    cs = (q & 1) ? c_odd : c_even;
+}
+
+// one Philox call -> two standard normals (Box-Muller), bit-identical to bbo_normal_pair
+// of oracle/philox.h
 __device__ inline void normal_pair(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
         uint32_t c3, double &z0, double &z1)
 {
     const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
     const double u1 = u01_open0(w.x, w.y);
     const double u2 = u01(w.z, w.w);
-    const double r = sqrt(-2. * log(u1));
-    const double a = 6.283185307179586476925286766559 * u2;
+    const double r = sqrt(-2. * log_unit(u1));
     double s, c;
-    sincos(a, &s, &c);
+    sincos_turn(u2, s, c);
     z0 = r * c;
     z1 = r * s;
 }
+
+// CMA-ES sampling: pair pj of a candidate fills columns 8 (pj >> 2) + (pj & 3) and that + 4,
+// i.e. exactly the two k-steps lane group (pj & 3) feeds to the MFMA A operand
+__host__ __device__ inline int cma_pair_col0(int pj) { return 8 * (pj >> 2) + (pj & 3); }
 
 } // namespace bbo

@@ -402,11 +402,11 @@ struct Cma {
     {
         if (rng_mode == RNG_MT) return Z.draw();
         if (rng_mode == RNG_INJECT) return zinject[(size_t) k * n + j];
-        /* RNG_PHILOX: pair (j/2) of candidate k in generation `it` */
+        /* RNG_PHILOX: column j of candidate k in generation `it` (layout: philox.h) */
         double z0, z1;
-        bbo_normal_pair(seed, (uint32_t) k, (uint32_t) (j >> 1), (uint32_t) it,
+        bbo_normal_pair(seed, (uint32_t) k, (uint32_t) bbo_cma_pair_of_column(j), (uint32_t) it,
                 bbo_stream(BBO_STREAM_CMA_NORMAL, 0), &z0, &z1);
-        return (j & 1) ? z1 : z0;
+        return bbo_cma_half_of_column(j) ? z1 : z0;
     }
 
     /* cmaes.cpp:65-80 */
@@ -940,15 +940,16 @@ void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 {
     bbo_philox(seed, c0, c1, c2, c3, out);
 }
+double orc_log_unit(double u) { return bbo_log_unit(u); }
+void orc_sincos_turn(double t, double *s, double *c) { bbo_sincos_turn(t, s, c); }
 void orc_philox_normals(uint64_t seed, int gen, int rows, int n, double *out)
 {
     for (int k = 0; k < rows; k++)
-        for (int j = 0; j < n; j += 2) {
+        for (int j = 0; j < n; j++) {
             double z0, z1;
-            bbo_normal_pair(seed, (uint32_t) k, (uint32_t) (j >> 1), (uint32_t) gen,
-                    bbo_stream(BBO_STREAM_CMA_NORMAL, 0), &z0, &z1);
-            out[(size_t) k * n + j] = z0;
-            if (j + 1 < n) out[(size_t) k * n + j + 1] = z1;
+            bbo_normal_pair(seed, (uint32_t) k, (uint32_t) bbo_cma_pair_of_column(j),
+                    (uint32_t) gen, bbo_stream(BBO_STREAM_CMA_NORMAL, 0), &z0, &z1);
+            out[(size_t) k * n + j] = bbo_cma_half_of_column(j) ? z1 : z0;
         }
 }
 

@@ -87,6 +87,78 @@ static inline int bbo_uint_below(uint32_t w, int range)
     return (int) (((uint64_t) w * (uint64_t) (uint32_t) range) >> 32);
 }
 
+/*
+ * ln(u) for u in [2^-53, 1].  Written out in +, *, /, fma so that the device twin
+ * (bbo_rng.hpp: log_unit) produces the same bits: u = m 2^e with m in [sqrt(1/2), sqrt(2)),
+ * ln m = 2 atanh(s), s = (m - 1)/(m + 1), odd series to s^23 (|s| <= 0.1716).
+ */
+static inline double bbo_log_unit(double u)
+{
+    union { double d; uint64_t b; } v;
+    v.d = u;
+    int e = (int) (v.b >> 52) - 1023;
+    v.b = (v.b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = v.d;
+    if (m > 0x1.6a09e667f3bcdp+0) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double s = (m - 1.) / (m + 1.);
+    const double z = s * s;
+    double p = 1. / 23.;
+    p = fma(p, z, 1. / 21.);
+    p = fma(p, z, 1. / 19.);
+    p = fma(p, z, 1. / 17.);
+    p = fma(p, z, 1. / 15.);
+    p = fma(p, z, 1. / 13.);
+    p = fma(p, z, 1. / 11.);
+    p = fma(p, z, 1. / 9.);
+    p = fma(p, z, 1. / 7.);
+    p = fma(p, z, 1. / 5.);
+    p = fma(p, z, 1. / 3.);
+    const double s2 = s + s;
+    const double lm = fma(s2 * z, p, s2);
+    const double de = (double) e;
+    return fma(de, 0x1.62e42fee00000p-1, fma(de, 0x1.a39ef35793c76p-33, lm));
+}
+
+/*
+ * sin and cos of 2 pi t for t in [0, 1) a multiple of 2^-53: exact reduction to an octant,
+ * then the fdlibm kernel polynomials on [0, pi/4] (device twin: sincos_turn).
+ */
+static inline void bbo_sincos_turn(double t, double *sn, double *cs)
+{
+    const double v = t * 8.;
+    const int k = (int) v;
+    double f = v - (double) k;
+    if (k & 1) f = 1. - f;
+    const double x = f * 0x1.921fb54442d18p-1;
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sx = fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cx = fma(z * z, pc, fma(z, -0.5, 1.));
+    /* angle = q pi/2 + y, y = +x (even octant) or -x (odd octant) */
+    const int q = ((k + 1) >> 1) & 3;
+    const double sy = (k & 1) ? -sx : sx;
+    switch (q) {
+    case 0: *sn = sy; *cs = cx; break;
+    case 1: *sn = cx; *cs = -sy; break;
+    case 2: *sn = -sy; *cs = -cx; break;
+    default: *sn = -cx; *cs = sy; break;
+    }
+}
+
 /* one Philox call -> two standard normals (Box-Muller) */
 static inline void bbo_normal_pair(uint64_t seed, uint32_t c0, uint32_t c1,
         uint32_t c2, uint32_t c3, double *z0, double *z1)
@@ -95,10 +167,19 @@ static inline void bbo_normal_pair(uint64_t seed, uint32_t c0, uint32_t c1,
     bbo_philox(seed, c0, c1, c2, c3, w);
     const double u1 = bbo_u01_open0(w[0], w[1]);
     const double u2 = bbo_u01(w[2], w[3]);
-    const double r = sqrt(-2. * log(u1));
-    const double a = 6.283185307179586476925286766559 * u2;
-    *z0 = r * cos(a);
-    *z1 = r * sin(a);
+    const double r = sqrt(-2. * bbo_log_unit(u1));
+    double sn, cs;
+    bbo_sincos_turn(u2, &sn, &cs);
+    *z0 = r * cs;
+    *z1 = r * sn;
 }
+
+/*
+ * CMA-ES sampling: which columns of a candidate the pair `pj` fills.  The layout follows the
+ * MFMA A-fragment of the device kernel (lane k-group kk = pj & 3 of k-block pair q = pj >> 2
+ * holds columns 8q + kk and 8q + 4 + kk), so a lane draws exactly the normals it multiplies.
+ */
+static inline int bbo_cma_pair_of_column(int j) { return ((j >> 3) << 2) | (j & 3); }
+static inline int bbo_cma_half_of_column(int j) { return (j >> 2) & 1; }
 
 #endif /* BBO_ORACLE_PHILOX_H_ */

@@ -131,6 +131,12 @@ class _Lib:
             f("philox").restype = None
             f("philox_normals").argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, _dp]
             f("philox_normals").restype = None
+            if hasattr(L, p + "log_unit"):
+                f("log_unit").argtypes = [C.c_double]
+                f("log_unit").restype = C.c_double
+                f("sincos_turn").argtypes = [C.c_double, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double)]
+                f("sincos_turn").restype = None
             if hasattr(L, p + "pop_set_mode"):
                 f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
                 f("pop_set_mode").restype = None

@@ -123,3 +123,46 @@ def test_philox_known_answers(oracle_lib):
         oracle_lib.f("philox")(seed, *ctr, out)
         assert tuple(out) == want
         assert philox4x32_10(seed, *ctr) == want
+
+
+def test_device_normal_arithmetic_is_accurate(oracle_lib):
+    """The Box-Muller pieces shared bit-for-bit by oracle/philox.h and bbo_rng.hpp (hand-rolled
+    ln on (0, 1] and sin/cos of 2 pi t) against long-double libm: a few ulp."""
+    import ctypes
+    rng = np.random.default_rng(7)
+    b = rng.integers(0, 2 ** 53, 20000, dtype=np.uint64)
+    us = np.concatenate([(b + 1) * 2.0 ** -53, [2.0 ** -53, 1.0, 1 - 2.0 ** -53, 0.5, 2.0 ** -30],
+                         2.0 ** -rng.uniform(0, 53, 5000)])
+    got = np.array([oracle_lib.f("log_unit")(float(u)) for u in us])
+    ref = np.log(us.astype(np.longdouble))
+    rel = np.abs((got - ref) / np.where(ref == 0, 1, ref)).astype(float)
+    assert rel.max() <= 4 * 2.0 ** -53
+    assert oracle_lib.f("log_unit")(1.0) == 0.0
+    s, c = ctypes.c_double(), ctypes.c_double()
+    ts = np.concatenate([b * 2.0 ** -53, np.arange(8) / 8.0, [1 - 2.0 ** -53]])
+    S, Cc = [], []
+    for t in ts:
+        oracle_lib.f("sincos_turn")(float(t), ctypes.byref(s), ctypes.byref(c))
+        S.append(s.value)
+        Cc.append(c.value)
+    ang = 8 * np.arctan(np.longdouble(1)) * ts.astype(np.longdouble)
+    assert float(np.abs(np.array(S) - np.sin(ang)).max()) <= 4 * 2.0 ** -53
+    assert float(np.abs(np.array(Cc) - np.cos(ang)).max()) <= 4 * 2.0 ** -53
+
+
+def test_philox_normals_are_standard_normal(oracle_lib):
+    """Distribution check of the generator the device uses (mean, variance, KS distance) and of
+    the CMA column layout (every column of a row is filled exactly once)."""
+    from scipy import stats
+    rows, n = 400, 128
+    out = np.zeros(rows * n)
+    oracle_lib.f("philox_normals")(2024, 3, rows, n, out)
+    assert abs(out.mean()) < 4 / np.sqrt(out.size)
+    assert abs(out.var() - 1) < 0.02
+    assert stats.kstest(out, "norm").pvalue > 1e-3
+    z = out.reshape(rows, n)
+    assert abs(np.corrcoef(z[:, :-4].ravel(), z[:, 4:].ravel())[0, 1]) < 0.02
+    # ragged n: the first n columns do not depend on how far the row extends
+    out2 = np.zeros(rows * 37)
+    oracle_lib.f("philox_normals")(2024, 3, rows, 37, out2)
+    np.testing.assert_array_equal(out2.reshape(rows, 37), z[:, :37])

@@ -116,6 +116,67 @@ def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
         assert int(g.get_state("flag")[0]) == o.converged()
 
 
+@pytest.mark.parametrize("n,lam", [(10, 20), (37, 50), (128, 256), (128, 4096), (200, 64)])
+def test_device_normals_bit_identical_to_oracle(hip, oracle_lib, n, lam):
+    """The sampling normals are a pure function of (seed, candidate, column, generation): the
+    device draws (bbo_rng.hpp) and the CPU statement (oracle/philox.h) agree to the last bit,
+    through every sampling kernel variant (n <= 128 register path, n = 128 / 4096 streaming
+    path, n > 128 generic path)."""
+    from bboptpy_amd import _ffi
+    g = hip.CMAES(mfev=10 ** 7, tol=1e-12, np=lam, seed=987654321)
+    g.initialize(hip.objectives.sphere, -5. * np.ones(n), 5. * np.ones(n), np.ones(n))
+    g.set_state("record_normals", [1.0])
+    for gen in range(2):
+        it = int(g.get_state("it")[0])
+        g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+        z = g.get_state("zlast")
+        want = np.zeros(lam * n)
+        oracle_lib.f("philox_normals")(987654321, it, lam, n, want)
+        np.testing.assert_array_equal(z, want)
+        for ph in (_ffi.PHASE_RANK, _ffi.PHASE_UPDATE, _ffi.PHASE_EIGEN, _ffi.PHASE_HISTORY_STOP):
+            g.phase(ph)
+
+
+@pytest.mark.parametrize("obj", ["sphere", "rosenbrock", "ellipsoid", "cigar", "discus",
+                                 "schwefel12", "rastrigin", "ackley", "griewank", "diffpow"])
+def test_many_population_sampling_matches_oracle(hip, oracle_lib, obj):
+    """n = 128, 8 populations x 4096 candidates: the whole-population sampling kernel (normals
+    drawn into the MFMA fragments, objective evaluated on the accumulators) against the oracle:
+    x = m + sigma B D z from the oracle's own normals of the same (seed, candidate, column),
+    f from the oracle's objective."""
+    from bboptpy_amd import _ffi
+    n, lam, P, seed = 128, 4096, 8, 4242
+    rng = np.random.default_rng(3)
+    lo, up = -2. * np.ones(n), 3. * np.ones(n)
+    guess = rng.uniform(-1, 2, (P, n))
+    g = hip.ActiveCMAES(mfev=10 ** 9, tol=1e-12, np=lam, seed=seed, populations=P, sigma0=0.3,
+                        bound=True)
+    g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+    # a non-trivial basis: run one full generation first
+    for ph in range(5):
+        g.phase(ph)
+    it = int(g.get_state("it")[0])
+    B = g.get_state("B").reshape(n, n)
+    D = g.get_state("D")
+    m = g.get_state("xmean")
+    sigma = g.get_state("sigma")[0]
+    g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+    # population 0: the oracle states its normals (sub-stream 0)
+    z = np.zeros(lam * n)
+    oracle_lib.f("philox_normals")(seed, it, lam, n, z)
+    X = g.get_state("arx").reshape(lam, n)
+    want = np.clip(m + sigma * (z.reshape(lam, n) * D) @ B.T, lo, up)
+    np.testing.assert_allclose(X, want, rtol=0, atol=1e-12)
+    # every population: f is the objective of the x that was stored, x respects the box
+    for p in (0, 3, P - 1):
+        X = g.get_state("arx", p).reshape(lam, n)
+        f = g.get_state("fitness", p)
+        assert np.all(X >= lo) and np.all(X <= up)
+        fo = np.array([oracle_lib.objective(obj, X[i]) for i in range(0, lam, 7)])
+        np.testing.assert_allclose(f[::7], fo, rtol=1e-11, atol=1e-11)
+    assert not np.array_equal(g.get_state("arx", 0), g.get_state("arx", 1))
+
+
 def test_optimize_readme_example(hip):
     """README.md:106-128: ActiveCMAES(mfev=10000, tol=1e-4, np=20) on 10-D Rosenbrock"""
     n = 10
