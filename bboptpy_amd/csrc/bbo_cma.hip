@@ -247,14 +247,31 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.honor_stop = 0;
     inited_ = true;
     {
-        dim3 grid(c.ld / 16, c.ld / 16, P);
-        hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 2);
+        launch_post(2);
         BBO_HIP(hipGetLastError());
         BBO_HIP(hipStreamSynchronize(stream_));
     }
 }
 
 // ---- kernel launches ---------------------------------------------------------------
+void CmaEngine::launch_post(int mode)
+{
+    const CmaConst &c = c_;
+    if (c.ld <= 128) {
+        const size_t lds = (size_t) (c.ld * (c.ld + 2) + c.ld) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(cma_post_mfma, dim3(c.npop), dim3(256), lds, stream_, d_, c_, mode);
+    } else {
+        dim3 grid(c.ld / 16, c.ld / 16, c.npop);
+        hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, mode);
+    }
+}
+
 void CmaEngine::launch_sample_eval()
 {
     const CmaConst &c = c_;
@@ -262,8 +279,9 @@ void CmaEngine::launch_sample_eval()
     if (c.ld == 128 && (long) c.npop * c.lambda_pad >= 256 * 128
             && (c.obj < 0 || frag_objective_ok(c.obj))) {
         // whole populations in flight: packed operand in LDS, normals drawn into the A fragments
-        int rw = (int) ((long) c.npop * c.lambda_pad / 256) / 128 * 128;
-        rw = std::max(128, std::min(512, rw));
+        // one workgroup per CU when the populations allow it: long tile loops amortise the fill
+        int rw = (int) (((long) c.npop * c.lambda_pad / 256 + 127) / 128) * 128;
+        rw = std::max(128, std::min(4096, rw));
         static bool attr_done = false;
         if (!attr_done) {
             BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval128,
@@ -331,14 +349,28 @@ void CmaEngine::launch_update()
 {
     const CmaConst &c = c_;
     if (c.variant == 1) {
+        timer_.begin(stream_, K_WHITEN);
+        if (c.ld == 128 && (long) c.npop * c.mu_pad >= 256 * 128) {
+            int rw = (int) (((long) c.npop * c.mu_pad / 256 + 127) / 128) * 128;
+            rw = std::max(128, std::min(2048, rw));
+            const size_t lds = (size_t) (128 * 128 + 128) * sizeof(double);
+            static bool attr_done = false;
+            if (!attr_done) {
+                BBO_HIP(hipFuncSetAttribute((const void*) cma_whiten128,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
+                attr_done = true;
+            }
+            dim3 grid128((c.mu_pad + rw - 1) / rw, c.npop);
+            hipLaunchKernelGGL(cma_whiten128, grid128, dim3(512), lds, stream_, d_, c_, rw);
+        } else {
         dim3 grid(c.mu_pad / 16, c.npop);
         const size_t lds = (size_t) (16 * (c.ld + 2) + 64) * sizeof(double);
-        timer_.begin(stream_, K_WHITEN);
         switch (pick_maxt(c.ld)) {
         case 1: hipLaunchKernelGGL(cma_whiten<1>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 2: hipLaunchKernelGGL(cma_whiten<2>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 4: hipLaunchKernelGGL(cma_whiten<4>, grid, dim3(256), lds, stream_, d_, c_); break;
         default: hipLaunchKernelGGL(cma_whiten<8>, grid, dim3(256), lds, stream_, d_, c_); break;
+        }
         }
         timer_.end(stream_);
         BBO_HIP(hipGetLastError());
@@ -401,9 +433,8 @@ void CmaEngine::launch_eigen()
             c_, pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
-    dim3 grid(c.ld / 16, c.ld / 16, c.npop);
     timer_.begin(stream_, K_POST);
-    hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 0);
+    launch_post(0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
@@ -464,6 +495,7 @@ void CmaEngine::phase(int which)
     default: throw Error(BBO_ERR_ARG, "unknown CMA phase");
     }
     BBO_HIP(hipStreamSynchronize(stream_));
+    timer_.collect();
 }
 
 void CmaEngine::inject_normals(const double *z, int count)
@@ -809,8 +841,7 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         }
         // refresh C^-1/2 and the packed MFMA operands
         c_.honor_stop = 0;
-        dim3 grid(c.ld / 16, c.ld / 16, c.npop);
-        hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, 1);
+        launch_post(1);
         BBO_HIP(hipGetLastError());
         BBO_HIP(hipStreamSynchronize(stream_));
         return r;

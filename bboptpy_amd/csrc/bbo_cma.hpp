@@ -96,6 +96,7 @@ public:
 private:
     void generation(bool honor_stop);
     void launch_sample_eval();
+    void launch_post(int mode);
     void launch_rank();
     void launch_update();
     void launch_eigen();

@@ -260,10 +260,46 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 // workgroup), each wavefront owns whole 16-candidate tiles: it DRAWS the normals straight
 // into its MFMA A fragments (the Philox column layout is the fragment layout, see
 // cma_pair_col0), sweeps the 8 column tiles, and evaluates the objective on the
-// accumulators.  No LDS traffic besides the B fragments, no barrier after the fill; two
-// wavefronts per SIMD let one's Box-Muller (VALU) overlap the other's MFMA sweep.
+// accumulators.  No LDS traffic besides the B fragments, no barrier after the fill.
 // grid (ceil(lambda_pad / rows_per_wg), P), 512 threads, dynamic LDS 128 KB
 // ---------------------------------------------------------------------------
+__device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, int p, int rowbase,
+        double sigma, const d4_t (&acc)[8], int lane)
+{
+    const int fr = lane & 15, fk = lane >> 4;
+    const double *xm = d.xmean + (size_t) p * 128;
+    double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    double x[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int col = t * 16 + fr;
+        const double xmc = xm[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = 0.;
+            if (col < c.n) {
+                v = xmc + sigma * acc[t][r];
+                if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+            }
+            x[t][r] = v;
+            Xp[((size_t) rowbase + fk + 4 * r) * 128 + col] = v;
+        }
+    }
+    if (c.obj >= 0) {
+        double f[4];
+        eval_frag_rows<8>(c.obj, c.n, x, d.aux, lane, f);
+        if (fr == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rr = rowbase + fk + 4 * r;
+                double fv = f[r];
+                if (!(rr < c.lambda) || fv != fv) fv = BBO_INF;
+                d.f[(size_t) p * c.lambda_pad + rr] = fv;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst c, int rows_per_wg)
 {
     const int p = blockIdx.y, row0 = blockIdx.x * rows_per_wg;
@@ -278,13 +314,14 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
         for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
     }
     __syncthreads();
+    // (fp64 MFMA and fp64 VALU do not overlap on gfx950 -- measured: draw-only + sweep-only
+    // times add up to the full kernel whatever the wave priorities -- so the draw is priced in
+    // VALU cycles next to the sweep, not hidden behind it.)
 
     const int gen = sc->it;
     const double sigma = sc->sigma;
     const int tiles = min(rows_per_wg, c.lambda_pad - row0) >> 4;
     const int fr = lane & 15, fk = lane >> 4;
-    const double *xm = d.xmean + (size_t) p * 128;
-    double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
 
     for (int tile = wave; tile < tiles; tile += 8) {
@@ -308,8 +345,8 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
                         z0 = zi[j0];
                         z1 = (j1 < c.n) ? zi[j1] : 0.;
                     } else {
-                        normal_pair(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk), (uint32_t) gen,
-                                sw, z0, z1);
+                        normal_pair(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk),
+                                (uint32_t) gen, sw, z0, z1);
                         if (j1 >= c.n) z1 = 0.;
                     }
                     if (d.zrecord) {
@@ -330,36 +367,7 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
                             acc[t], 0, 0, 0);
             }
         }
-
-        double x[8][4];
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int col = t * 16 + fr;
-            const double xmc = xm[col];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double v = 0.;
-                if (col < c.n) {
-                    v = xmc + sigma * acc[t][r];
-                    if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
-                }
-                x[t][r] = v;
-                Xp[((size_t) rowbase + fk + 4 * r) * 128 + col] = v;
-            }
-        }
-        if (c.obj >= 0) {
-            double f[4];
-            eval_frag_rows<8>(c.obj, c.n, x, d.aux, lane, f);
-            if (fr == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int rr = rowbase + fk + 4 * r;
-                    double fv = f[r];
-                    if (!(rr < c.lambda) || fv != fv) fv = BBO_INF;
-                    d.f[(size_t) p * c.lambda_pad + rr] = fv;
-                }
-            }
-        }
+        sample128_epilogue(d, c, p, rowbase, sigma, acc, lane);
     }
 }
 
@@ -484,6 +492,78 @@ __global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
         if (wr < c.mu_pad)
             d.S[(size_t) p * c.mu_pad + wr] = part[tid] + part[16 + tid] + part[32 + tid]
                     + part[48 + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// whiten for ld == 128, whole populations in flight: the packed C^-1/2 operand sits in LDS
+// (loaded once per workgroup), a wavefront owns whole 16-row tiles of the mu worst
+// candidates, gathers y = x - xold straight into its MFMA A fragments and reduces the
+// squared norms on the accumulators.  grid (ceil(mu_pad / rows_per_wg), P), 512 threads,
+// dynamic LDS 128 KB + 1 KB
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void cma_whiten128(CmaDev d, CmaConst c, int rows_per_wg)
+{
+    const int p = blockIdx.y, wr0 = blockIdx.x * rows_per_wg;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double is[];
+    double *xo = is + 128 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const double2 *src = reinterpret_cast<const double2*>(d.ISp + (size_t) p * 128 * 128);
+        double2 *dst = reinterpret_cast<double2*>(is);
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
+        if (tid < 128) xo[tid] = d.xmean[(size_t) p * 128 + tid];   // the mean has not moved yet
+    }
+    __syncthreads();
+    const double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    const int *order = d.order + (size_t) p * c.lambda_pad;
+    const int tiles = min(rows_per_wg, c.mu_pad - wr0) >> 4;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    for (int tile = wave; tile < tiles; tile += 8) {
+        const int wr = wr0 + tile * 16 + fr;
+        const bool in = wr < c.mu;
+        const double *xrow = Xp + (size_t) (in ? order[c.lambda - c.mu + wr] : 0) * 128 + fk;
+        d4_t acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+        // eight k-steps at a time; the next chunk's gather is in flight during the sweep
+        double raw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) raw[i] = xrow[4 * i];
+#pragma unroll 1
+        for (int kc = 0; kc < 4; kc++) {
+            double a[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int kk = 4 * (8 * kc + i) + fk;
+                a[i] = (in && kk < c.n) ? raw[i] - xo[kk] : 0.;
+            }
+            if (kc < 3) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) raw[i] = xrow[4 * (8 * (kc + 1) + i)];
+            }
+            const double *bk = is + kc * 8 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bk[(t * 32 + i) * 64],
+                            acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double ss = 0.;
+#pragma unroll
+            for (int t = 0; t < 8; t++) ss += acc[t][r] * acc[t][r];
+            ss = row16_sum(ss);
+            const int orow = wr0 + tile * 16 + fk + 4 * r;
+            if (fr == 0 && orow < c.mu_pad) d.S[(size_t) p * c.mu_pad + orow] = ss;
+        }
     }
 }
 
@@ -952,6 +1032,113 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
     const size_t pk = ((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15);
     d.ISp[(size_t) p * ld * ld + pk] = v;
     d.BDp[(size_t) p * ld * ld + pk] = in ? B[(size_t) i * ld + j] * D[j] : 0.;
+}
+
+// ---------------------------------------------------------------------------
+// post for ld <= 128 on the matrix cores: one workgroup per population stages B in LDS,
+// C^-1/2 = (B diag(1/D)) B^T is 2 x NT tiles per wavefront (A fragment = B[i][k] / D[k], the
+// reference's own term order, cmaes.cpp:277; B fragment = the same rows of B unscaled), then
+// the two packed operands are written.  grid (P), 256 threads, dynamic LDS ld*(ld+2)+ld doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int mode)
+{
+    const int p = blockIdx.x;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    if (mode == 0 && !sc->eigen_done) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ld = c.ld, n = c.n, ldp = ld + 2;
+    double *Bs = lds, *Dv = lds + ld * ldp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *B = d.B + (size_t) p * ld * ld;
+    double *isc = d.isc + (size_t) p * ld * ld;
+    double *ISp = d.ISp + (size_t) p * ld * ld, *BDp = d.BDp + (size_t) p * ld * ld;
+    // eight independent loads in flight per thread, then the LDS stores
+    const int hp = ld >> 1, total = ld * hp;
+    for (int q0 = tid; q0 < total; q0 += 8 * 256) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + 256 * u;
+            v[u] = q < total ? reinterpret_cast<const double2*>(B)[q] : make_double2(0., 0.);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + 256 * u;
+            if (q < total) {
+                const int i = q / hp, j = (q - i * hp) * 2;
+                if (!(i < n && j < n)) v[u].x = 0.;
+                if (!(i < n && j + 1 < n)) v[u].y = 0.;
+                *reinterpret_cast<double2*>(&Bs[i * ldp + j]) = v[u];
+            }
+        }
+    }
+    for (int j = tid; j < ld; j += 256) Dv[j] = j < n ? d.D[(size_t) p * ld + j] : 1.;
+    __syncthreads();
+
+    const int NT = ld >> 4, KS = ld >> 2;
+    const int fr = lane & 15, fk = lane >> 4;
+    if (mode != 2) {
+        d4_t acc[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[h][t] = d4_t { 0., 0., 0., 0. };
+        const bool has1 = wave + 4 < NT;
+        if (wave < NT) {
+            for (int ks = 0; ks < KS; ks++) {
+                const int k = 4 * ks + fk;
+                const double dk = Dv[k];
+                double f[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) f[t] = t < NT ? Bs[(t * 16 + fr) * ldp + k] : 0.;
+                const double a0 = Bs[(wave * 16 + fr) * ldp + k] / dk;
+                const double a1 = has1 ? Bs[((wave + 4) * 16 + fr) * ldp + k] / dk : 0.;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    if (t < NT) {
+                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f[t], acc[0][t], 0, 0, 0);
+                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f[t], acc[1][t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int ti = wave + 4 * h;
+                if (ti < NT) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        if (t < NT) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int i = ti * 16 + fk + 4 * r, j = t * 16 + fr;
+                                const double v = acc[h][t][r];   // 0 outside n: B is staged as 0 there
+                                isc[(size_t) i * ld + j] = v;
+                                ISp[((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15)] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // packed operands: element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
+#pragma unroll 4
+    for (int q = tid; q < ld * ld; q += 256) {
+        const int t4 = q >> 6, l = q & 63;             // t4 = nt * KS + ks
+        const int nt = t4 / KS, ks = t4 - nt * KS;
+        const int i = nt * 16 + (l & 15), j = 4 * ks + (l >> 4);
+        const bool in = i < n && j < n;
+        BDp[q] = in ? Bs[i * ldp + j] * Dv[j] : 0.;
+    }
+    if (mode == 2) {
+        for (int q = tid; q < ld * ld; q += 256) {
+            const int t4 = q >> 6, l = q & 63;
+            const int nt = t4 / KS, ks = t4 - nt * KS;
+            const int i = nt * 16 + (l & 15), j = 4 * ks + (l >> 4);
+            ISp[q] = (i < n && j < n) ? isc[(size_t) i * ld + j] : 0.;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
