@@ -37,8 +37,8 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix peak (AMD datashe
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=64),
-    "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=64),
+    "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
+    "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=256),
     "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=64),
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=64),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
@@ -81,7 +81,7 @@ def cma_kernel_costs(n, lam, P):
     return {
         "cma_sample_eval": ("mfma", P * lam * (2 * n * n + 8 * n)),
         "cma_whiten": ("mfma", P * mu * 2 * n * n),
-        "cma_gram": ("mfma", P * lam * 2 * n * n),
+        "cma_gram": ("mfma", P * lam * n * (n + 1)),      # lower triangle only, like the reference
         "cma_eigen": ("mfma", P * 9 * n ** 3),
         "cma_post": ("mfma", P * 2 * n ** 3),
         "cma_rank": ("hbm", P * lam * 16),
@@ -89,6 +89,23 @@ def cma_kernel_costs(n, lam, P):
         "cma_cov": ("hbm", P * 8 * 2 * (n * (n + 1) // 2)),
         "cma_history_stop": ("hbm", P * 8 * 4 * n),
     }
+
+
+def measured_traffic(workload, P, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by scripts/collect_traffic.py from separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as the gfx950 note in
+    MI355X_MICROARCH.md prescribes).  None when no pass matches this workload and P."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    e = t.get("%s:P%d" % (workload, P))
+    if not e:
+        return None
+    return e.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def make_optimizer(bb, wl, P, seed, device):
@@ -187,6 +204,9 @@ def main():
     ap.add_argument("--populations", type=int, default=None,
                     help="independent populations per GPU (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true",
+                    help="skip the single-population leg (profiling runs: keeps rocprofv3's "
+                         "per-kernel averages to the P-population launches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,9 +275,10 @@ def main():
             kd = kernels[dom]
             roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"],
                         "peak": kd["peak"], "unit": kd["unit"], "frac": kd["frac"],
-                        "traffic": None, "avg_us": kd["avg_us"], "time_share": kd["share"]}
+                        "traffic": measured_traffic(args.workload, P, dom),
+                        "avg_us": kd["avg_us"], "time_share": kd["share"]}
         single = None
-        if P != 1 and world == 1:
+        if P != 1 and world == 1 and not args.no_single:
             dt1, _, _, _ = measure(bb, wl, 1, max(10, args.steps // 2), 5, 77, local_rank,
                                    profile=False)
             s1 = max(10, args.steps // 2)
