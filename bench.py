@@ -151,6 +151,34 @@ def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
     return dt, prof, fev, alg
 
 
+# generations-to-tol of the reference itself (measured on its C++):
+# the second half of the metric.  flag 5 = TolUpSigma (cmaes.cpp:193), flag 2 = TolHistFun.
+REFERENCE_GENERATIONS_TO_TOL = {
+    "M": {"generations": 2047, "flag": 5, "final_f": 84.4, "seed": 1},
+    "C3": {"generations": 6228, "flag": 2, "final_f": 1.21e-4, "seed": 1},
+}
+
+
+def generations_to_tol(bb, wl, device, pops=8, cap=20000):
+    """Run the SAME stopping rule as the reference (tol = 1e-4, all of cmaes.cpp:151-227) on
+    `pops` independently seeded populations until each one stops on its own; report when."""
+    n = wl["n"]
+    lo, up = wl["box"][0] * np.ones(n), wl["box"][1] * np.ones(n)
+    guess = np.random.default_rng(11).uniform(wl["box"][0], wl["box"][1], (pops, n))
+    alg = bb.ActiveCMAES(mfev=2 ** 31 - 1, tol=1e-4, np=wl["np"], seed=11, device=device,
+                         populations=pops)
+    alg.initialize(getattr(bb.objectives, wl["objective"]), lo, up, guess)
+    t0 = time.perf_counter()
+    launched = alg.run(cap)
+    dt = time.perf_counter() - t0
+    its = [int(alg.get_state("it", p)[0]) for p in range(pops)]
+    flags = [int(alg.get_state("flag", p)[0]) for p in range(pops)]
+    fbest = [float(alg.get_state("fit_val", p)[0]) for p in range(pops)]
+    return {"tol": 1e-4, "populations": pops, "generations": its, "stop_flag": flags,
+            "best_f_at_stop": fbest, "generations_median": float(np.median(its)),
+            "all_stopped": bool(launched < cap), "wall_s": dt}
+
+
 def cpu_baseline(wl, budget_s=12.0):
     """the same workload on ONE host core: the real reference when oracle/_ref travelled
     here, else the oracle restatement (a port)"""
@@ -204,6 +232,8 @@ def main():
     ap.add_argument("--populations", type=int, default=None,
                     help="independent populations per GPU (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true",
+                    help="skip the generations-to-tol leg")
     ap.add_argument("--no-single", action="store_true",
                     help="skip the single-population leg (profiling runs: keeps rocprofv3's "
                          "per-kernel averages to the P-population launches)")
@@ -284,6 +314,11 @@ def main():
             s1 = max(10, args.steps // 2)
             single = {"value": wl["np"] * s1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
                       "unit": "candidate-evals/s"}
+        conv = None
+        if (world == 1 and wl["algo"] == "ActiveCMAES" and not args.no_convergence
+                and not args.no_single):
+            conv = generations_to_tol(bb, wl, local_rank)
+            conv["reference"] = REFERENCE_GENERATIONS_TO_TOL.get(args.workload)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(wl)
@@ -298,6 +333,7 @@ def main():
                        "populations_per_gpu": P, "n": wl["n"], "np": wl["np"],
                        "objective": wl["objective"], "box": list(wl["box"])},
             "single_population": single,
+            "generations_to_tol": conv,
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

@@ -28,6 +28,23 @@ __global__ __launch_bounds__(256) void k(double *out, int reps)
             double s, c;
             sincospi(2. * u2, &s, &c);
             acc += r * c + r * s;
+        } else if (V == 7) {
+            const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
+            acc += log_unit(u1);
+        } else if (V == 8) {
+            const double u2 = (tid * 977u + i * 31u) * 0x1.0p-32;
+            double s, c;
+            sincos_turn(u2, s, c);
+            acc += s + c;
+        } else if (V == 9) {
+            const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
+            acc += sqrt(u1);
+        } else if (V == 10) {
+            const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
+            acc += 1.0 / (u1 + 1.0);
+        } else if (V == 11) {
+            const u32x4 w = philox4x32_10(1234, tid, i, 7, 1 << 24);
+            acc += u01_open0(w.x, w.y) + u01(w.z, w.w);
         } else if (V == 4) {
             // log + sqrt only, no philox
             const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
@@ -77,5 +94,10 @@ int main()
     run<4>("log+sqrt", out);
     run<5>("sincos", out);
     run<6>("sincospi", out);
+    run<7>("log_unit", out);
+    run<8>("sincos_turn", out);
+    run<9>("sqrt", out);
+    run<10>("division", out);
+    run<11>("philox+u01 x2", out);
     return 0;
 }
