@@ -66,6 +66,79 @@ inline EigPlan eig_plan(int n, int ld)
     return pl;
 }
 
+// Straight-line pieces of the register-resident tred2, specialised on how many 32-column
+// groups the active block still covers (a guard inside the unrolled loops would split them into
+// basic blocks and serialise the LDS reads they issue).
+template<int AMAX>
+__device__ inline double tred_matvec(const double (&a_)[4][8], double (&ur)[4][8], const double *uv,
+        int q)
+{
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            const double2 t2 = *reinterpret_cast<const double2*>(&uv[32 * a + 8 * q + b]);
+            ur[a][b] = t2.x;
+            ur[a][b + 1] = t2.y;
+        }
+    double acc0 = 0., acc1 = 0.;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            acc0 += a_[a][b] * ur[a][b];
+            acc1 += a_[a][b + 1] * ur[a][b + 1];
+        }
+    double acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1, 4);
+    acc += __shfl_xor(acc, 2, 4);
+    return acc;
+}
+
+template<int AMAX>
+__device__ inline void tred_rank2(double (&a_)[4][8], const double (&ur)[4][8], const double *wv,
+        double uj, double wj, int q)
+{
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            const double2 w2 = *reinterpret_cast<const double2*>(&wv[32 * a + 8 * q + b]);
+            a_[a][b] = a_[a][b] - (ur[a][b] * wj + w2.x * uj);
+            a_[a][b + 1] = a_[a][b + 1] - (ur[a][b + 1] * wj + w2.y * uj);
+        }
+}
+
+template<int AMAX>
+__device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row, double h, int q,
+        int n)
+{
+    double ur[4][8];
+    double acc0 = 0., acc1 = 0.;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int k = 32 * a + 8 * q + b;
+            ur[a][b] = k < n ? As(row, k) : 0.;
+        }
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) {
+            acc0 += ur[a][b] * a_[a][b];
+            acc1 += ur[a][b + 1] * a_[a][b + 1];
+        }
+    double acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1, 4);
+    acc += __shfl_xor(acc, 2, 4);
+    const double gq = acc / h;
+#pragma unroll
+    for (int a = 0; a < AMAX; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) a_[a][b] -= gq * ur[a][b];
+}
+
 // tred2 + reflector accumulation for n <= 128 with the matrix in REGISTERS: thread
 // (row j = tid >> 2, class q = tid & 3) owns A(j, k) for k = 32a + 8q + b (a < 4, b < 8);
 // LDS carries only the O(n) vectors (zero-padded beyond the active block, so the inner
@@ -125,26 +198,8 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         // g = A u (no bounds tests: u is zero beyond the active block); this thread's 32
         // entries of u stay in registers for the rank-2 update below
         double ur[4][8];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 8; b += 2) {
-                const double2 t2 = *reinterpret_cast<const double2*>(&uv[32 * a + 8 * q + b]);
-                ur[a][b] = t2.x;
-                ur[a][b + 1] = t2.y;
-            }
         {
-            double acc0 = 0., acc1 = 0.;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b += 2) {
-                    acc0 += a_[a][b] * ur[a][b];
-                    acc1 += a_[a][b + 1] * ur[a][b + 1];
-                }
-            double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
+            const double acc = tred_matvec<4>(a_, ur, uv, q);
             if (q == 0 && j < i) {
                 gv[j] = acc;
                 As(i, j) = uv[j];          // stash: row i = the Householder vector of step i
@@ -161,14 +216,7 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         // A -= u w^T + w u^T; rows >= i and columns >= i see zeros and do not move
         {
             const double uj = uv[j], wj = wv[j];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b += 2) {
-                    const double2 w2 = *reinterpret_cast<const double2*>(&wv[32 * a + 8 * q + b]);
-                    a_[a][b] = a_[a][b] - (ur[a][b] * wj + w2.x * uj);
-                    a_[a][b + 1] = a_[a][b + 1] - (ur[a][b + 1] * wj + w2.y * uj);
-                }
+            tred_rank2<4>(a_, ur, wv, uj, wj, q);
             if (j == i - 1) {
 #pragma unroll
                 for (int a = 0; a < 4; a++)
@@ -193,33 +241,19 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 8; b++) a_[a][b] = (32 * a + 8 * q + b == j) ? 1. : 0.;
-    for (int i = 0; i < n - 1; i++) {
+    // H(i+1) touches rows k <= i only, and columns j > i of Q are still columns of I there
+    // (zero in those rows): a wavefront joins at the first step that reaches its columns, and
+    // 32-row groups beyond the vector are skipped
+    for (int i = (tid >> 6) * 16 > 0 ? (tid >> 6) * 16 - 1 : 0; i < n - 1; i++) {
         const double h = hvec[i + 1];
         if (h != 0.) {
-            double ur[4][8];
-            double acc0 = 0., acc1 = 0.;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const int k = 32 * a + 8 * q + b;
-                    ur[a][b] = k < n ? As(i + 1, k) : 0.;
-                }
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b += 2) {
-                    acc0 += ur[a][b] * a_[a][b];
-                    acc1 += ur[a][b + 1] * a_[a][b + 1];
-                }
-            double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
-            const double gq = acc / h;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 8; b++) a_[a][b] -= gq * ur[a][b];
+            // rows 0..i; the stash rows are zero beyond the vector and beyond n
+            switch ((i + 32) >> 5) {
+            case 1: accum_step<1>(a_, As, i + 1, h, q, n); break;
+            case 2: accum_step<2>(a_, As, i + 1, h, q, n); break;
+            case 3: accum_step<3>(a_, As, i + 1, h, q, n); break;
+            default: accum_step<4>(a_, As, i + 1, h, q, n); break;
+            }
         }
     }
     __syncthreads();

@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 WORKLOADS = {
     "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=256),
-    "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=64),
-    "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=64),
+    "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=256),
+    "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
     "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
