@@ -86,8 +86,8 @@ __device__ inline double tred_matvec(const double (&a_)[4][8], double (&ur)[4][8
     for (int a = 0; a < AMAX; a++)
 #pragma unroll
         for (int b = 0; b < 8; b += 2) {
-            acc0 += a_[a][b] * ur[a][b];
-            acc1 += a_[a][b + 1] * ur[a][b + 1];
+            acc0 = __builtin_fma(a_[a][b], ur[a][b], acc0);
+            acc1 = __builtin_fma(a_[a][b + 1], ur[a][b + 1], acc1);
         }
     double acc = acc0 + acc1;
     acc += __shfl_xor(acc, 1, 4);
@@ -104,8 +104,8 @@ __device__ inline void tred_rank2(double (&a_)[4][8], const double (&ur)[4][8], 
 #pragma unroll
         for (int b = 0; b < 8; b += 2) {
             const double2 w2 = *reinterpret_cast<const double2*>(&wv[32 * a + 8 * q + b]);
-            a_[a][b] = a_[a][b] - (ur[a][b] * wj + w2.x * uj);
-            a_[a][b + 1] = a_[a][b + 1] - (ur[a][b + 1] * wj + w2.y * uj);
+            a_[a][b] = __builtin_fma(-ur[a][b], wj, __builtin_fma(-w2.x, uj, a_[a][b]));
+            a_[a][b + 1] = __builtin_fma(-ur[a][b + 1], wj, __builtin_fma(-w2.y, uj, a_[a][b + 1]));
         }
 }
 
@@ -126,17 +126,17 @@ __device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row,
     for (int a = 0; a < AMAX; a++)
 #pragma unroll
         for (int b = 0; b < 8; b += 2) {
-            acc0 += ur[a][b] * a_[a][b];
-            acc1 += ur[a][b + 1] * a_[a][b + 1];
+            acc0 = __builtin_fma(ur[a][b], a_[a][b], acc0);
+            acc1 = __builtin_fma(ur[a][b + 1], a_[a][b + 1], acc1);
         }
     double acc = acc0 + acc1;
     acc += __shfl_xor(acc, 1, 4);
     acc += __shfl_xor(acc, 2, 4);
-    const double gq = acc / h;
+    const double gq = -(acc / h);
 #pragma unroll
     for (int a = 0; a < AMAX; a++)
 #pragma unroll
-        for (int b = 0; b < 8; b++) a_[a][b] -= gq * ur[a][b];
+        for (int b = 0; b < 8; b++) a_[a][b] = __builtin_fma(gq, ur[a][b], a_[a][b]);
 }
 
 // tred2 + reflector accumulation for n <= 128 with the matrix in REGISTERS: thread
