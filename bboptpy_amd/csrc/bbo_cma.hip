@@ -150,6 +150,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     const bool same_shape = keep_bc_ && last_n_ == n && C_.count == P * ld2;
     X_.alloc((size_t) P * c.lambda_pad * ld);
     f_.alloc((size_t) P * c.lambda_pad);
+    zn2_.alloc((size_t) P * c.lambda_pad);
     rank_.alloc((size_t) P * c.lambda_pad);
     order_.alloc((size_t) P * c.lambda_pad);
     xmean_.alloc(P * ld);
@@ -224,6 +225,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         s.fbest = -std::numeric_limits<double>::infinity();
         s.fworst = std::numeric_limits<double>::infinity();
         s.hist_head = -1;
+        // a re-initialised object keeps the off-diagonals of B (cmaes.cpp:53-59) while C^-1/2
+        // restarts from I: the two disagree until the first decomposition
+        s.basis_ok = same_shape ? 0 : 1;
     }
     scal_.upload(sc.data(), P);
 
@@ -237,7 +241,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     d.X = X_.p; d.f = f_.p; d.rank = rank_.p; d.order = order_.p;
     d.xmean = xmean_.p; d.xold = xold_.p; d.pc = pc_.p; d.ps = ps_.p;
     d.C = C_.p; d.B = B_.p; d.D = D_.p; d.isc = isc_.p; d.BDp = BDp_.p; d.ISp = ISp_.p;
-    d.S = S_.p; d.gram_part = gram_part_.p; d.mean_part = mean_part_.p;
+    d.S = S_.p; d.zn2 = zn2_.p; d.gram_part = gram_part_.p; d.mean_part = mean_part_.p;
     d.hist_best = hist_best_.p; d.hist_kth = hist_kth_.p; d.eig_work = eig_work_.p;
     d.weights = weights_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.zinject = nullptr; d.zrecord = nullptr; d.scal = scal_.p;
@@ -275,6 +279,7 @@ void CmaEngine::launch_post(int mode)
 void CmaEngine::launch_sample_eval()
 {
     const CmaConst &c = c_;
+    bool zn_valid = false;
     timer_.begin(stream_, K_SAMPLE);
     if (c.ld == 128 && (long) c.npop * c.lambda_pad >= 256 * 128
             && (c.obj < 0 || frag_objective_ok(c.obj))) {
@@ -290,6 +295,7 @@ void CmaEngine::launch_sample_eval()
         }
         dim3 grid((c.lambda_pad + rw - 1) / rw, c.npop);
         hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw);
+        zn_valid = true;
     } else if (c.ld <= 128) {
         // 64 candidates per workgroup, packed operand held in registers
         dim3 grid((c.lambda_pad + 63) / 64, c.npop);
@@ -318,6 +324,8 @@ void CmaEngine::launch_sample_eval()
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
+    // ||z||^2 stands in for the whitened norm only if this launch wrote it and no x was clamped
+    c_.use_zn = (zn_valid && !c.bound) ? 1 : 0;
 }
 
 void CmaEngine::launch_rank()

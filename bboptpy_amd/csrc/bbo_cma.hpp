@@ -23,7 +23,7 @@ struct CmaScal {
     int hsig;
     int eigenlastev, eigen_done;
     int hist_head, hist_len;
-    int pad_;
+    int basis_ok;             // C^-1/2 = B D^-1 B^T for the (B, D) the sampler uses (see cma_whiten128)
 };
 
 // strategy constants, passed to every kernel by value
@@ -33,6 +33,7 @@ struct CmaConst {
     int mu, mu_pad;
     int variant;              // 0 plain (cmaes.cpp), 1 active (active_cmaes.cpp)
     int bound, obj;
+    int use_zn;               // this generation's zn2 is valid and x was not clamped
     int mfev, mit, hlen, ik;
     int honor_stop;           // 1 inside run()/optimize(): stopped populations are frozen
     int splits, rps;          // Gram split-K: number of row slabs, rows per slab
@@ -54,6 +55,7 @@ struct CmaDev {
     double *BDp;        // [P][ld*ld]   (B diag D) in MFMA B-fragment order
     double *ISp;        // [P][ld*ld]   C^-1/2   in MFMA B-fragment order
     double *S;          // [P][mu_pad]  whitened squared norms of the worst mu
+    double *zn2;        // [P][lambda_pad] ||z||^2 of every candidate (cma_sample_eval128 only)
     double *gram_part;  // [P][splits][ld][ld]
     double *mean_part;  // [P][splits][ld]
     double *hist_best, *hist_kth;     // [P][hlen]
@@ -115,6 +117,7 @@ private:
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;
 
+    DevBuf<double> zn2_;
     DevBuf<double> X_, f_, xmean_, xold_, pc_, ps_, C_, B_, D_, isc_, BDp_, ISp_, S_,
             gram_part_, mean_part_, hist_best_, hist_kth_, eig_work_, weights_, lower_,
             upper_, aux_, zinject_, zrecord_;

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
         d4_t acc[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+        double zz = 0.;
         // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk], then sweep them
 #pragma unroll 1
         for (int kc = 0; kc < 4; kc++) {
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
                 }
                 a[2 * qq] = z0;
                 a[2 * qq + 1] = z1;
+                zz += z0 * z0 + z1 * z1;
             }
             const double *bk = bd + kc * 8 * 64 + lane;
 #pragma unroll
@@ -367,6 +369,10 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
                             acc[t], 0, 0, 0);
             }
         }
+        // ||z||^2 of the row: the four k-groups of a row sit 16 lanes apart
+        zz += __shfl_xor(zz, 16, 64);
+        zz += __shfl_xor(zz, 32, 64);
+        if (fk == 0) d.zn2[(size_t) p * c.lambda_pad + row] = zz;
         sample128_epilogue(d, c, p, rowbase, sigma, acc, lane);
     }
 }
@@ -510,6 +516,21 @@ __global__ __launch_bounds__(512, 1) void cma_whiten128(CmaDev d, CmaConst c, in
     extern __shared__ __attribute__((aligned(16))) double is[];
     double *xo = is + 128 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (c.use_zn && sc->basis_ok) {
+        // x - m = sigma B D z and C^-1/2 = B D^-1 B^T from the same (B, D), so
+        // C^-1/2 (x - m) = sigma B z and the squared norm is sigma^2 ||z||^2: the sampler's own
+        // by-product.  (Not so for clamped x, nor before the first decomposition of a
+        // re-initialised object: those take the GEMM below.)
+        const double s2 = sc->sigma * sc->sigma;
+        const int *ord = d.order + (size_t) p * c.lambda_pad;
+        const int rows = min(rows_per_wg, c.mu_pad - wr0);
+        for (int r = tid; r < rows; r += 512) {
+            const int wr = wr0 + r;
+            d.S[(size_t) p * c.mu_pad + wr] = wr < c.mu
+                    ? s2 * d.zn2[(size_t) p * c.lambda_pad + ord[c.lambda - c.mu + wr]] : 0.;
+        }
+        return;
+    }
     {
         const double2 *src = reinterpret_cast<const double2*>(d.ISp + (size_t) p * 128 * 128);
         double2 *dst = reinterpret_cast<double2*>(is);
@@ -1027,6 +1048,7 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
     double v = in ? sum : 0.;
     if (mode == 2) v = in ? d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] : 0.;
     else d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] = v;
+    if (mode != 2 && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) d.scal[p].basis_ok = 1;
     // packed B-operand element (row i -> column tile/lane, col j -> k index)
     const int KS = ld >> 2;
     const size_t pk = ((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15);
@@ -1122,6 +1144,7 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
             }
         }
     }
+    if (mode != 2 && tid == 0) d.scal[p].basis_ok = 1;
     // packed operands: element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
 #pragma unroll 4
     for (int q = tid; q < ld * ld; q += 256) {

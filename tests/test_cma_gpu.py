@@ -177,6 +177,31 @@ def test_many_population_sampling_matches_oracle(hip, oracle_lib, obj):
     assert not np.array_equal(g.get_state("arx", 0), g.get_state("arx", 1))
 
 
+def test_whitened_norm_shortcut_matches_gemm(hip):
+    """Active CMA's negative-update coefficients need ||C^-1/2 (x - m)||^2 of the worst mu
+    candidates.  With an unclamped x = m + sigma B D z and C^-1/2 from the same (B, D) that is
+    sigma^2 ||z||^2, which the n = 128 sampling kernel hands over; bound=True (here with a box
+    no sample reaches, so X is identical) disables the shortcut and takes the reference's GEMM.
+    Both must agree, and keep agreeing while C moves away from I."""
+    n, lam, P = 128, 4096, 8
+    rng = np.random.default_rng(9)
+    guess = rng.uniform(-3, 3, (P, n))
+    lo, up = -1e6 * np.ones(n), 1e6 * np.ones(n)
+    a = hip.ActiveCMAES(mfev=10 ** 9, tol=1e-14, np=lam, seed=31, populations=P, bound=False)
+    b = hip.ActiveCMAES(mfev=10 ** 9, tol=1e-14, np=lam, seed=31, populations=P, bound=True)
+    a.initialize(hip.objectives.ellipsoid, lo, up, guess)
+    b.initialize(hip.objectives.ellipsoid, lo, up, guess)
+    for gen in range(8):
+        a.run(1)
+        b.run(1)
+        for p in (0, P - 1):
+            np.testing.assert_allclose(a.get_state("ycoeff", p), b.get_state("ycoeff", p),
+                                       rtol=1e-9, atol=0)
+            np.testing.assert_allclose(a.get_state("C", p), b.get_state("C", p),
+                                       rtol=1e-9, atol=1e-13)
+    assert a.get_state("sigma")[0] == pytest.approx(b.get_state("sigma")[0], rel=1e-9)
+
+
 def test_optimize_readme_example(hip):
     """README.md:106-128: ActiveCMAES(mfev=10000, tol=1e-4, np=20) on 10-D Rosenbrock"""
     n = 10
