@@ -234,7 +234,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     // the eigensolver keeps its matrix in LDS when it fits
     // global scratch of the eigensolver: the work matrix when it does not fit LDS, or
     // (divide and conquer) the Householder matrix and the merge factor
-    eig_work_.alloc((size_t) P * 2 * ld * (ld + 1));
+    eig_work_.alloc((size_t) P * 4 * ld * (ld + 1));
 
     CmaDev &d = d_;
     d = CmaDev {};
@@ -441,6 +441,13 @@ void CmaEngine::launch_eigen()
             c_, pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
+    if (pl.dc && !pl.reg_path) {
+        // 128 < n <= 256: the top merge's two products as whole-GPU kernels
+        dim3 grid((c.n + 63) / 64, (c.n + 63) / 64, c.npop);
+        hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
+        hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
+        BBO_HIP(hipGetLastError());
+    }
     timer_.begin(stream_, K_POST);
     launch_post(0);
     timer_.end(stream_);

@@ -22,6 +22,8 @@
 
 namespace bbo {
 
+typedef double d4_eig __attribute__((ext_vector_type(4)));
+
 constexpr int EIG_THREADS = 512;
 constexpr int EIG_NMAX = 512;
 
@@ -42,7 +44,7 @@ inline EigPlan eig_plan(int n, int ld)
     EigPlan pl {};
     pl.vl = (((n > 128 ? n : 128) + 1) & ~1) + 2;
     pl.reg_path = n <= 128 ? 1 : 0;
-    pl.dc = pl.reg_path;
+    pl.dc = n <= 256 ? 1 : 0;          // 128 < n <= 256: matrix in global memory, top merge external
     const size_t budget = 160 * 1024 - 1024;
     const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
     const size_t vecs = (size_t) (EIG_NVEC + (pl.reg_path ? 0 : 4)) * pl.vl * sizeof(double);
@@ -50,7 +52,7 @@ inline EigPlan eig_plan(int n, int ld)
     const size_t mat = (size_t) n * lda_lds * sizeof(double);
     const size_t fixed = vecs + ints;
     // the chunk buffers need room for at least one full QL sweep (n-1 pairs) each
-    if (fixed + mat + (size_t) 2 * n * 16 <= budget) {
+    if (fixed + mat + (size_t) 2 * n * 16 <= budget && !(pl.dc && !pl.reg_path)) {
         pl.use_lds = 1;
         pl.lda = lda_lds;
         size_t rc = (budget - fixed - mat) / (2 * 16);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     int *sdone = nseq + 2;
     int *perm = reinterpret_cast<int*>(uv);                     // reused after QL
     EigMat A { pl.use_lds ? reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8)
-                          : d.eig_work + (size_t) p * ld * pl.lda, pl.lda };
+                          : d.eig_work + (size_t) p * 4 * ld * (ld + 1), pl.lda };
     double *C = d.C + (size_t) p * ld * ld;
 
 #define EIG_STAMP(slot) do { if (d.stamps && p == 0 && tid == 0) d.stamps[slot] = wall_clock64(); } while (0)
@@ -451,9 +453,10 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         // divide and conquer on the tridiagonal matrix; writes B (ascending eigenvalues)
         double *scr = uv;
         DcMat Qm { A.a, A.ld };
-        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) p * 2 * ld * (ld + 1),
+        // per-population global scratch: [work matrix | Q_house | F | Q F], ld (ld+1) each
+        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * ld * (ld + 1),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg);
+                d.dbg, pl.reg_path ? 0 : 1);
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {
@@ -543,6 +546,64 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     }
     EIG_STAMP(5);
 #undef EIG_STAMP
+}
+
+// ---------------------------------------------------------------------------
+// C = A B (n x n, row-major) on the matrix cores, operands straight from global memory (L2):
+// the two products of the external top merge for 128 < n <= 256, B = Q_house ((Q_1 (+) Q_2) F).
+// which = 0: eig_work[0] (block-diagonal Q) * eig_work[2] (F) -> eig_work[3];
+// which = 1: eig_work[1] (Q_house) * eig_work[3] -> d.B.
+// grid (ceil(n/64), ceil(n/64), P), 256 threads: wavefront w owns rows 16w.. of a 64 x 64 block
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int lda_work, int which)
+{
+    const int p = blockIdx.z;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (!sc->eigen_done) return;
+    const int n = c.n, ld = c.ld;
+    const size_t slab = (size_t) ld * (ld + 1);
+    const double *base = d.eig_work + (size_t) 4 * p * slab;
+    const double *A = which == 0 ? base : base + slab;
+    const int lda = which == 0 ? lda_work : n;
+    const double *Bm = which == 0 ? base + slab + (size_t) n * n : base + 3 * slab;
+    double *Cm = which == 0 ? const_cast<double*>(base) + 3 * slab : d.B + (size_t) p * ld * ld;
+    const int ldc = which == 0 ? n : ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int row = blockIdx.y * 64 + wave * 16 + fr;
+    const int col0 = blockIdx.x * 64 + fr;
+    d4_eig acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = d4_eig { 0., 0., 0., 0. };
+    const int ksteps = (n + 3) >> 2;
+    for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {
+        double av[4], bv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = 4 * (ks0 + u) + fk;
+            av[u] = (row < n && kk < n) ? A[(size_t) row * lda + kk] : 0.;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int col = col0 + 16 * t;
+                bv[u][t] = (kk < n && col < n) ? Bm[(size_t) kk * n + col] : 0.;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int col = col0 + 16 * t;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int orow = blockIdx.y * 64 + wave * 16 + fk + 4 * r;
+            if (orow < n && col < n) Cm[(size_t) orow * ldc + col] = acc[t][r];
+        }
+    }
 }
 
 } // namespace bbo

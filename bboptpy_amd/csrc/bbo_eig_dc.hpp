@@ -31,7 +31,7 @@ namespace bbo {
 typedef double dc_d4 __attribute__((ext_vector_type(4)));
 
 constexpr int DC_LEAF = 16;
-constexpr int DC_MAXB = 16;          // max leaves (n <= 128 -> 8)
+constexpr int DC_MAXB = 16;          // max leaves (n <= 256)
 constexpr double DC_EPS = 0x1.0p-53;
 constexpr int DC_KSTEPS = 32;        // k-steps of a 128-deep MFMA contraction
 
@@ -125,7 +125,7 @@ __device__ inline double dc_quad_sum(double v)
 // Fg (global) is scratch for the eigenvector factor of this merge (m x m).
 template<int LPR>
 __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
-        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps)
+        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps, bool do_gemm)
 {
 #define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a > 64) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
@@ -435,6 +435,9 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     __syncthreads();
 
     MG_STAMP(29);
+    // (the top merge of a matrix wider than 128 leaves F in global memory: the two products
+    // Q F and Q_house (Q F) are separate whole-GPU kernels, cma_eig_gemm)
+    if (do_gemm) {
     // ---- Q[a:b, a:b] <- Q[a:b, a:b] F on the matrix cores, 16 rows at a time, in place.
     // A wavefront keeps the F fragments of its column tile(s) in registers for the whole
     // merge; every wavefront finishes reading the 16 old rows before any of them is stored.
@@ -480,6 +483,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             }
         }
     }
+    }   // do_gemm
     __syncthreads();
     if (ttid < m) dv[a + W.outpos[ttid]] = W.lam[ttid];
     __syncthreads();
@@ -529,8 +533,11 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
 // Householder matrix Q_house.  On exit: dv = eigenvalues ascending, Bout (global, ld) =
 // Q_house * Q_T, i.e. the eigenvectors of the original matrix in columns.
 // G (global): 2 * n * n doubles of scratch.  scratch (LDS): >= 3400 doubles.
+// ext_top != 0 (n > 128, Q in global memory): stop after the scalar part of the top merge; on
+// exit Q = blockdiag(Q_1, Q_2), F (= G + n*n, n x n) = the top merge's eigenvector factor with
+// columns in ascending eigenvalue order, and the caller forms B = Q_house (Q F).
 __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
-        double *Bout, int ldb, double *scratch, long long *stamps, int dbg)
+        double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0)
 {
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
@@ -550,7 +557,7 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     DcWork W;
     {
         double *p = scratch;
-        const int M = 130;
+        const int M = ((n > 128 ? n : 128) + 2);
         W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
         W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
         W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
@@ -649,12 +656,13 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
         // (chosen from the WIDEST merge so that all teams run the same code path)
         int m = 0;
         for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
+        const bool gemm = !(ext_top && nc == 2);
         if (4 * m <= tm.tthreads)
-            dc_merge_level<4>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            dc_merge_level<4>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
         else if (2 * m <= tm.tthreads)
-            dc_merge_level<2>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            dc_merge_level<2>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
         else
-            dc_merge_level<1>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            dc_merge_level<1>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
         int nxt[DC_MAXB + 1];
         int nn = 0;
         nxt[nn++] = cur[0];
@@ -687,6 +695,7 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     __syncthreads();
 
     DC_STAMP(22);
+    if (ext_top) return;
     // ---- B = Q_house * Q_T on the matrix cores: a wavefront keeps the Q_house fragments of
     // its row tile in registers and sweeps the column tiles ---------------------------------
     const int ntile = (n + 15) >> 4;

@@ -244,7 +244,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     barrier = None
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -259,7 +260,7 @@ def main():
     P = args.populations if args.populations else wl["P"]
     dt, prof, _, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
                              profile=True, barrier=barrier)
-    if world > 1:
+    if use_dist:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,7 +340,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

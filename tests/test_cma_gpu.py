@@ -34,6 +34,8 @@ def _lower(m, n):
     ("active", 32, 64, "rastrigin"),
     ("active", 37, 50, "ellipsoid"),      # ragged: n, lambda not multiples of 16
     ("cmaes", 128, 256, "sphere"),
+    ("active", 160, 48, "ellipsoid"),     # 128 < n <= 256: divide and conquer, external top merge
+    ("active", 256, 32, "rosenbrock"),
 ])
 def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
     from bboptpy_amd import _ffi
@@ -228,7 +230,7 @@ def _spd_cases(n, rng):
     yield "repeated", Q @ np.diag(np.where(np.arange(n) % 2 == 0, 1., 3.)) @ Q.T
 
 
-@pytest.mark.parametrize("n", [10, 16, 17, 37, 64, 100, 128])
+@pytest.mark.parametrize("n", [10, 16, 17, 37, 64, 100, 128, 129, 160, 200, 256, 300])
 def test_eigendecomposition_special_matrices(hip, n):
     """the eigensolver alone (QL for n <= 16, Householder + divide and conquer above) on
     matrices that stress deflation, clustering and scaling; checked against numpy.eigh"""
