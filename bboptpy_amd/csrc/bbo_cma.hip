@@ -234,7 +234,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     // the eigensolver keeps its matrix in LDS when it fits
     // global scratch of the eigensolver: the work matrix when it does not fit LDS, or
     // (divide and conquer) the Householder matrix and the merge factor
-    eig_work_.alloc((size_t) P * 4 * ld * (ld + 1));
+    eig_work_.alloc((size_t) P * 4 * eig_slab((int) ld));
 
     CmaDev &d = d_;
     d = CmaDev {};

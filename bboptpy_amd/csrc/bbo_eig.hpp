@@ -39,10 +39,13 @@ struct EigPlan {
 
 constexpr int EIG_NVEC = 9;   // d, e, u, w, g, h, tdiag, uh0, uh1
 
+// one slab of the eigensolver's per-population global scratch ([work | Q_house | F | Q F])
+__host__ __device__ inline size_t eig_slab(int ld) { return (size_t) (ld + 32) * (ld + 32); }
+
 inline EigPlan eig_plan(int n, int ld)
 {
     EigPlan pl {};
-    pl.vl = (((n > 128 ? n : 128) + 1) & ~1) + 2;
+    pl.vl = (((n > 128 ? n : 128) + 31) & ~31) + 2;
     pl.reg_path = n <= 128 ? 1 : 0;
     pl.dc = n <= 256 ? 1 : 0;          // 128 < n <= 256: matrix in global memory, top merge external
     const size_t budget = 160 * 1024 - 1024;
@@ -61,9 +64,15 @@ inline EigPlan eig_plan(int n, int ld)
         pl.lds_bytes = fixed + mat + (size_t) 2 * pl.rc * 16;
     } else {
         pl.use_lds = 0;
-        pl.lda = ld + 1;
-        pl.rc = 2048;
-        pl.lds_bytes = fixed + (size_t) 2 * pl.rc * 16;
+        pl.lda = (n + 31) & ~31;      // global work matrix: rows 256-byte aligned, unguarded 32-column groups
+        if (pl.dc) {
+            // no QL chunk buffers; a 128 x 128 LDS matrix for the register-resident tail
+            pl.rc = 0;
+            pl.lds_bytes = fixed + (size_t) 128 * 128 * sizeof(double);
+        } else {
+            pl.rc = 2048;
+            pl.lds_bytes = fixed + (size_t) 2 * pl.rc * 16;
+        }
     }
     return pl;
 }
@@ -149,9 +158,12 @@ __device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row,
 // of column j) and needs no barrier at all: a column only reads the stashed vectors.
 // Against cmaes.cpp:293-381 the Householder vectors are left unscaled (the reference divides
 // by sum|d| first): the reflector I - u u^T / h is the same, one reduction per step is saved.
+// (C, ld): the n x n matrix to reduce (the covariance, or -- for 128 < n' <= 256 -- the leading
+// 128 x 128 block the global-memory steps have left); As: LDS matrix for the reflector stash;
+// the accumulated Q goes to (qdst, ldq), which may be As itself.
 __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, const EigMat &As,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
-        int tid, long long *stamps)
+        int tid, long long *stamps, double *qdst, int ldq, bool finish)
 {
     const int T = EIG_THREADS, lane = tid & 63;
     const int j = tid >> 2, q = tid & 3;
@@ -265,9 +277,213 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 const int k = 32 * a + 8 * q + b;
-                if (k < n) As(k, j) = a_[a][b];
+                if (k < n) qdst[(size_t) k * ldq + j] = a_[a][b];
             }
     }
+    if (finish)
+        for (int k = tid; k < n; k += T) dv[k] = td[k];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// tred2 + accumulation for n > 128: the matrix does not fit LDS or registers, it lives in
+// global memory (L2-resident: <= 2 MB), row-major with lda a multiple of 32.  Same arithmetic
+// as the register path above (unscaled reflectors, stash of reflector i in ROW i, Q built from
+// I by applying H(1)..H(n-1) to a growing block).  What matters here is memory-level
+// parallelism: one workgroup streams the active block 3x per tred step and 2x per
+// accumulation step, so every inner loop loads a batch of rows/columns into registers before
+// it computes (one L2 round trip per batch), and nothing is bounds-tested: u and w are kept
+// zero beyond the active block.
+// ---------------------------------------------------------------------------
+// hybrid (As != null, 128 < n <= 256): once the active block is 128 x 128 the steps move into
+// the register-resident code above (reflector stash in the LDS matrix As) and only the 128
+// biggest steps of either phase stream from L2.
+__device__ inline void eig_tred_accum_global(const double *C, int ld, int n, const EigMat &A,
+        double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
+        double *part, int nv, int tid, long long *stamps, const EigMat *As)
+{
+    const int NS = As ? 128 : 0;             // steps i < NS run out of registers
+    const int T = EIG_THREADS, lane = tid & 63;
+    const int lda = A.ld;
+    const int nr = (n + 31) & ~31;           // columns touched by the unguarded loops
+    // A = C, zero-padded to nr columns
+    for (int q = tid; q < n * (nr >> 1); q += T) {
+        const int r = q / (nr >> 1), c2 = (q - r * (nr >> 1)) * 2;
+        double2 v;
+        v.x = c2 < n ? C[(size_t) r * ld + c2] : 0.;
+        v.y = c2 + 1 < n ? C[(size_t) r * ld + c2 + 1] : 0.;
+        *reinterpret_cast<double2*>(&A.a[(size_t) r * lda + c2]) = v;
+    }
+    for (int k = tid; k < nr; k += T) {
+        dv[k] = k < n ? C[(size_t) (n - 1) * ld + k] : 0.;
+        hvec[k] = 0.;
+        uv[k] = 0.;
+        wv[k] = 0.;
+    }
+    const int rq = tid & 3, rj0 = tid >> 2;   // 4 lanes per row, lane q owns columns 32a + 8q + b
+    for (int i = n - 1; i > 0 && i >= NS; i--) {
+        __syncthreads();
+        const int ir = (i + 31) & ~31, GA = ir >> 5;
+        double hs = 0.;
+        for (int k = lane; k < i; k += 64) hs += dv[k] * dv[k];
+        const double h0 = eig_wave_sum(hs);
+        const double f = dv[i - 1];
+        if (h0 == 0.) {
+            __syncthreads();
+            if (tid == 0) {
+                ev[i] = f;
+                hvec[i] = 0.;
+            }
+            for (int k = tid; k < ir; k += T) dv[k] = k < i ? A(i - 1, k) : 0.;
+            continue;
+        }
+        double g = sqrt(h0);
+        if (f > 0) g = -g;
+        const double h = h0 - f * g;
+        // every wavefront writes the SAME u, so it may read its own copy without a barrier
+        for (int k = lane; k < ir; k += 64) uv[k] = k < i ? (k == i - 1 ? f - g : dv[k]) : 0.;
+        if (tid == 0) ev[i] = g;
+        // g = A u over rows j < i
+        for (int j = rj0; j < i; j += T / 4) {
+            const double *row = A.a + (size_t) j * lda + 8 * rq;
+            double acc0 = 0., acc1 = 0.;
+            for (int a0 = 0; a0 < GA; a0 += 4) {
+                double2 x[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        x[a][b] = a0 + a < GA
+                                ? *reinterpret_cast<const double2*>(row + 32 * (a0 + a) + 2 * b)
+                                : make_double2(0., 0.);
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+                    if (a0 + a < GA) {
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const double2 u2 = *reinterpret_cast<const double2*>(
+                                    &uv[32 * (a0 + a) + 8 * rq + 2 * b]);
+                            acc0 = __builtin_fma(x[a][b].x, u2.x, acc0);
+                            acc1 = __builtin_fma(x[a][b].y, u2.y, acc1);
+                        }
+                    }
+            }
+            double acc = acc0 + acc1;
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            if (rq == 0) gv[j] = acc;
+        }
+        __syncthreads();
+        const double rh = 1. / h;
+        double fs = 0.;
+        for (int k = lane; k < i; k += 64) fs += (gv[k] * rh) * uv[k];
+        const double hh = eig_wave_sum(fs) * (0.5 * rh);
+        for (int k = lane; k < ir; k += 64) wv[k] = k < i ? gv[k] * rh - hh * uv[k] : 0.;
+        // A -= u w^T + w u^T on rows j < i; row i-1 becomes the next d
+        for (int j = rj0; j < i; j += T / 4) {
+            double *row = A.a + (size_t) j * lda + 8 * rq;
+            const double uj = uv[j], wj = wv[j];
+            for (int a0 = 0; a0 < GA; a0 += 4) {
+                double2 x[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        x[a][b] = a0 + a < GA
+                                ? *reinterpret_cast<const double2*>(row + 32 * (a0 + a) + 2 * b)
+                                : make_double2(0., 0.);
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+                    if (a0 + a < GA) {
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int kk = 32 * (a0 + a) + 8 * rq + 2 * b;
+                            const double2 u2 = *reinterpret_cast<const double2*>(&uv[kk]);
+                            const double2 w2 = *reinterpret_cast<const double2*>(&wv[kk]);
+                            double2 v;
+                            v.x = __builtin_fma(-u2.x, wj, __builtin_fma(-w2.x, uj, x[a][b].x));
+                            v.y = __builtin_fma(-u2.y, wj, __builtin_fma(-w2.y, uj, x[a][b].y));
+                            *reinterpret_cast<double2*>(row + 32 * (a0 + a) + 2 * b) = v;
+                            if (j == i - 1) *reinterpret_cast<double2*>(&dv[kk]) = v;
+                        }
+                    }
+            }
+        }
+        // stash: row i = the Householder vector of step i (read back by the accumulation)
+        for (int k = tid; k < i; k += T) A(i, k) = uv[k];
+        if (tid == 0) hvec[i] = h;
+    }
+    __syncthreads();
+    if (stamps && tid == 0) stamps[2] = wall_clock64();
+    for (int j = NS + tid; j < n; j += T) td[j] = A(j, j);
+    if (As) {
+        // the leading 128 x 128 block: reduce and accumulate in registers, Q block back to A
+        __syncthreads();
+        eig_tred_accum_reg128(A.a, lda, 128, *As, dv, ev, uv, wv, gv, hvec, td, tid, nullptr,
+                A.a, lda, false);
+        for (int k = tid; k < nr; k += T) {
+            uv[k] = 0.;
+            wv[k] = 0.;
+        }
+    }
+    __syncthreads();
+    // ---- Q = H(n-1) ... H(1), in place: the block [0..i]^2 holds the product so far, the rows
+    // below still hold the stashed vectors.  The strict upper triangle must read as zero ------
+    for (int q = tid; q < n * (nr >> 1); q += T) {
+        const int r = q / (nr >> 1), c2 = (q - r * (nr >> 1)) * 2;
+        double2 *cell = reinterpret_cast<double2*>(&A.a[(size_t) r * lda + c2]);
+        double2 v = *cell;
+        // (with the hybrid, rows < NS keep their first NS columns: the accumulated block)
+        if (c2 > r && !(r < NS && c2 < NS)) v.x = 0.;
+        if (c2 + 1 > r && !(r < NS && c2 + 1 < NS)) v.y = 0.;
+        *cell = v;
+    }
+    if (tid == 0 && NS == 0) A(0, 0) = 1.;
+    // column tiling: lane group cq in 0..3 owns the rows k = cq (mod 4) of columns cj, cj+128, ..
+    const int cq = tid >> 7, cj0 = tid & 127;
+    for (int i = NS > 0 ? NS - 1 : 0; i < n - 1; i++) {
+        const double h = hvec[i + 1];
+        __syncthreads();
+        if (h != 0.) {
+            for (int k = tid; k <= i; k += T) uv[k] = A(i + 1, k);
+            __syncthreads();
+            for (int j = cj0; j <= i; j += 128) {
+                double acc0 = 0., acc1 = 0.;
+                const double *col = A.a + j;
+                int k = cq;
+                for (; k + 28 <= i; k += 32) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) x[u] = col[(size_t) (k + 4 * u) * lda];
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        acc0 = __builtin_fma(x[u], uv[k + 4 * u], acc0);
+                        acc1 = __builtin_fma(x[u + 1], uv[k + 4 * u + 4], acc1);
+                    }
+                }
+                for (; k <= i; k += 4) acc0 = __builtin_fma(col[(size_t) k * lda], uv[k], acc0);
+                part[cq * nv + j] = acc0 + acc1;
+            }
+            __syncthreads();
+            for (int j = cj0; j <= i; j += 128) {
+                const double gq = -((part[j] + part[nv + j]) + (part[2 * nv + j] + part[3 * nv + j])) / h;
+                double *col = A.a + j;
+                int k = cq;
+                for (; k + 28 <= i; k += 32) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) x[u] = col[(size_t) (k + 4 * u) * lda];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        col[(size_t) (k + 4 * u) * lda] = __builtin_fma(gq, uv[k + 4 * u], x[u]);
+                }
+                for (; k <= i; k += 4) col[(size_t) k * lda] = __builtin_fma(gq, uv[k], col[(size_t) k * lda]);
+            }
+        }
+        // row i+1 joins the block as a row of I (its stash is spent; column i+1 is already zero)
+        for (int k = tid; k <= i + 1; k += T) A(i + 1, k) = k == i + 1 ? 1. : 0.;
+    }
+    __syncthreads();
     for (int k = tid; k < n; k += T) dv[k] = td[k];
     __syncthreads();
 }
@@ -302,7 +518,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     int *sdone = nseq + 2;
     int *perm = reinterpret_cast<int*>(uv);                     // reused after QL
     EigMat A { pl.use_lds ? reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8)
-                          : d.eig_work + (size_t) p * 4 * ld * (ld + 1), pl.lda };
+                          : d.eig_work + (size_t) p * 4 * eig_slab(ld), pl.lda };
     double *C = d.C + (size_t) p * ld * ld;
 
 #define EIG_STAMP(slot) do { if (d.stamps && p == 0 && tid == 0) d.stamps[slot] = wall_clock64(); } while (0)
@@ -313,132 +529,12 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     }
     if (pl.reg_path) {
         eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
-                (d.stamps && p == 0) ? d.stamps : nullptr);
+                (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true);
     } else {
-    for (int i = wave; i < n; i += T / 64)
-        for (int j = lane; j < n; j += 64) A(i, j) = C[(size_t) i * ld + j];
-    for (int j = tid; j < n; j += T) dv[j] = C[(size_t) (n - 1) * ld + j];
-    EIG_STAMP(1);
-
-    // ---- Householder reduction (cmaes.cpp:293-356) -------------------------------------
-    // row tiling: 4 lanes per row; lane q of a row owns the columns k = 32a + 8q + b,
-    // which keeps the 32 lanes of an LDS access group on 32 different bank pairs
-    const int rq = tid & 3, rj0 = tid >> 2;
-    for (int i = n - 1; i > 0; i--) {
-        __syncthreads();
-        // every wavefront recomputes the norms of d[0..i) (= row i of the active matrix)
-        double sabs = 0.;
-        for (int k = lane; k < i; k += 64) sabs += fabs(dv[k]);
-        const double scale = eig_wave_sum(sabs);
-        if (scale == 0.) {
-            const double dprev = dv[i - 1];
-            __syncthreads();
-            if (tid == 0) {
-                ev[i] = dprev;
-                dv[i] = 0.;
-            }
-            for (int j = tid; j < i; j += T) {
-                dv[j] = A(i - 1, j);
-                A(i, j) = 0.;
-                A(j, i) = 0.;
-            }
-            continue;
-        }
-        double hsum = 0.;
-        for (int k = lane; k < i; k += 64) {
-            const double u = dv[k] / scale;
-            hsum += u * u;
-        }
-        double h = eig_wave_sum(hsum);
-        {
-            // every wavefront writes the SAME u (one store per element, no fix-up pass), so
-            // a wavefront may read what it wrote without waiting for the others
-            const double f = dv[i - 1] / scale;
-            double g = sqrt(h);
-            if (f > 0) g = -g;
-            h = h - f * g;
-            for (int k = lane; k < i; k += 64) uv[k] = (k == i - 1) ? f - g : dv[k] / scale;
-            if (tid == 0) ev[i] = scale * g;
-        }
-        // g = A u on the active block; stash u in column i
-        for (int j = rj0; j < i; j += T / 4) {
-            double acc = 0.;
-            for (int a = 0; a < i; a += 32) {
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const int k = a + 8 * rq + b;
-                    if (k < i) acc += A(j, k) * uv[k];
-                }
-            }
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
-            if (rq == 0) {
-                gv[j] = acc;
-                A(j, i) = uv[j];
-            }
-        }
-        __syncthreads();
-        // w = g/h - (g.u / 2h^2) u, recomputed by every wavefront
-        const double rh = 1. / h;
-        double fsum = 0.;
-        for (int k = lane; k < i; k += 64) fsum += (gv[k] * rh) * uv[k];
-        const double hh = eig_wave_sum(fsum) / (h + h);
-        for (int k = lane; k < i; k += 64) wv[k] = gv[k] * rh - hh * uv[k];
-        // A -= u w^T + w u^T (both halves, bitwise symmetric); row i-1 becomes the next d
-        for (int j = rj0; j < i; j += T / 4) {
-            const double uj = uv[j], wj = wv[j];
-            for (int a = 0; a < i; a += 32) {
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const int k = a + 8 * rq + b;
-                    if (k < i) {
-                        const double v = A(j, k) - (uv[k] * wj + wv[k] * uj);
-                        A(j, k) = v;
-                        if (j == i - 1) dv[k] = v;
-                    }
-                }
-            }
-            if (rq == 0) A(i, j) = 0.;
-        }
-        if (tid == 0) dv[i] = h;
-    }
-    __syncthreads();
-    EIG_STAMP(2);
-
-    // ---- accumulate the transformations (cmaes.cpp:358-381) -----------------------------
-    // column tiling: lane group q in 0..3 owns the rows k = q (mod 4) of column j
-    const int cq = tid >> 7, cj0 = tid & 127;
-    for (int i = 0; i < n - 1; i++) {
-        if (tid == 0) {
-            A(n - 1, i) = A(i, i);
-            A(i, i) = 1.;
-        }
-        const double h = dv[i + 1];
-        __syncthreads();
-        if (h != 0.) {
-            for (int j = cj0; j <= i; j += 128) {
-                double acc = 0.;
-                for (int k = cq; k <= i; k += 4) acc += A(k, i + 1) * A(k, j);
-                part[cq * nv + j] = acc;
-            }
-            if (cj0 == 0)
-                for (int k = cq; k <= i; k += 4) uv[k] = A(k, i + 1) / h;
-            __syncthreads();
-            for (int j = cj0; j <= i; j += 128) {
-                const double g = part[j] + part[nv + j] + part[2 * nv + j] + part[3 * nv + j];
-                for (int k = cq; k <= i; k += 4) A(k, j) -= g * uv[k];
-            }
-        }
-        // column i+1 is dead now (its reads happened before the barrier above)
-        if (cj0 == 127)
-            for (int k = cq; k <= i; k += 4) A(k, i + 1) = 0.;
-    }
-    __syncthreads();
-    for (int j = tid; j < n; j += T) {
-        dv[j] = A(n - 1, j);
-        A(n - 1, j) = (j == n - 1) ? 1. : 0.;
-    }
-    __syncthreads();
+        const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
+        EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
+        eig_tred_accum_global(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, part, nv, tid,
+                (d.stamps && p == 0) ? d.stamps : nullptr, hybrid ? &Ast : nullptr);
     }   // generic path
     {   // tql2 prologue: shift the sub-diagonal down (cmaes.cpp:384-387); T >= n
         const double t = (tid + 1 < n) ? ev[tid + 1] : 0.;
@@ -453,8 +549,8 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         // divide and conquer on the tridiagonal matrix; writes B (ascending eigenvalues)
         double *scr = uv;
         DcMat Qm { A.a, A.ld };
-        // per-population global scratch: [work matrix | Q_house | F | Q F], ld (ld+1) each
-        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * ld * (ld + 1),
+        // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
+        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
                 d.dbg, pl.reg_path ? 0 : 1);
     } else
@@ -562,7 +658,7 @@ __global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int ld
     if (c.honor_stop && sc->stop != 0) return;
     if (!sc->eigen_done) return;
     const int n = c.n, ld = c.ld;
-    const size_t slab = (size_t) ld * (ld + 1);
+    const size_t slab = eig_slab(ld);
     const double *base = d.eig_work + (size_t) 4 * p * slab;
     const double *A = which == 0 ? base : base + slab;
     const int lda = which == 0 ? lda_work : n;
