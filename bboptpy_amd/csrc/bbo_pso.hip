@@ -69,6 +69,8 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     pvec_.alloc(P * ld);
     radius_.alloc(rows);
     colpart_.alloc((size_t) P * parts_ * ld);
+    colpart2_.alloc((size_t) P * ((c.np + 127) / 128) * c.np);
+    rowpart2_.alloc(rows);
     lower_.alloc(ld);
     upper_.alloc(ld);
     aux_.alloc(ld);
@@ -96,7 +98,7 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     d = PsoDev {};
     d.X = X_.p; d.V = V_.p; d.XB = XB_.p; d.f = f_.p; d.fb = fb_.p; d.xbest = xbest_.p;
     d.ws = ws_.p; d.mean = mean_.p; d.nrm = nrm_.p; d.pvec = pvec_.p; d.radius = radius_.p;
-    d.colpart = colpart_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
+    d.colpart = colpart_.p; d.colpart2 = colpart2_.p; d.rowpart2 = rowpart2_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.scal = scal_.p;
     c.honor_stop = 0;
     inited_ = true;
@@ -166,8 +168,19 @@ void PsoEngine::generation(bool honor_stop)
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_ESE);
-    hipLaunchKernelGGL(pso_ese, dim3((c.np + 63) / 64, P), dim3(256),
-            (size_t) 2 * 64 * (ESE_KC + 2) * sizeof(double), stream_, d_, c_);
+    {
+        static bool attr_done = false;
+        const size_t lds = (size_t) (4 * ESE2_TILE + 256) * sizeof(double);
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) pso_ese_sym,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(pso_ese_sym, dim3((c.np + 127) / 128, P), dim3(256), lds, stream_, d_,
+                c_);
+        hipLaunchKernelGGL(pso_ese_finish, dim3((c.np + 255) / 256, P), dim3(256), 0, stream_, d_,
+                c_);
+    }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_CTRL);

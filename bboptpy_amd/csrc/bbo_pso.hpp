@@ -46,6 +46,8 @@ struct PsoDev {
     double *pvec;            // [P][ld] elitist candidate
     double *radius;          // [P][np]
     double *colpart;         // [P][parts][ld] centroid partial sums
+    double *colpart2;        // [P][ceil(np/128)][np] distance column sums of block I (pso_ese_sym)
+    double *rowpart2;        // [P][np] distance row sums inside the swept blocks
     const double *lower, *upper, *aux;
     PsoScal *scal;
 };
@@ -79,6 +81,7 @@ private:
     bool inited_ = false;
     int parts_ = 1;
     std::vector<double> aux_h_;
+    DevBuf<double> colpart2_, rowpart2_;
     DevBuf<double> X_, V_, XB_, f_, fb_, xbest_, ws_, mean_, nrm_, pvec_, radius_, colpart_,
             lower_, upper_, aux_;
     DevBuf<PsoScal> scal_;

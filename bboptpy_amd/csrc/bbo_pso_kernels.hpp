@@ -3,7 +3,7 @@
 //   kernel          reference lines it replaces                            bound
 //   pso_init        apso.cpp:70-97 (uniform swarm, v = 0, pbest = x)        HBM
 //   pso_center/mean/nrm   centring for the distance kernel                  HBM (8n B/particle)
-//   pso_ese         getf, apso.cpp:300-339: d_i = mean_j ||x_i - x_j||      fp64 MFMA, 2 n np flop/particle
+//   pso_ese_sym     getf, apso.cpp:300-339: d_i = mean_j ||x_i - x_j||      fp64 MFMA, n np flop/particle
 //   pso_control_a/b nextState/mu/updatec1c2/updateElitist :200-298,:347-452 latency (1 WG)
 //   pso_update      updateParticle :159-198, fused with the objective       HBM: 3 row reads + 2 row
 //                                                                           writes = 40n+16 B
@@ -198,72 +198,189 @@ __global__ __launch_bounds__(256) void pso_nrm(PsoDev d, PsoConst c)
 }
 
 // ---------------------------------------------------------------------------
-// mean distance of every particle to the others: 64-row panel x all 64-row panels,
-// G = Xi' Xj'^T on v_mfma_f64_16x16x4_f64, d_ij = sqrt(max(0, |xi'|^2 + |xj'|^2 - 2 G_ij)).
-// grid (ceil(np/64), P), 256 threads; LDS 2 * 64 * (KC + 2) doubles
+// mean distance of every particle to the others (getf, apso.cpp:300-339):
+// G = Xi' Xj'^T on v_mfma_f64_16x16x4_f64 over the CENTRED swarm, d_ij = sqrt(max(0, |xi'|^2 +
+// |xj'|^2 - 2 G_ij)), using d_ij = d_ji: workgroup I owns the 128-row block I and sweeps the
+// blocks J >= I only.  A 128 x 128 tile of the Gram matrix lives in the accumulators of four
+// wavefronts (2 x 2, 64 x 64 each: 8 LDS fragment reads feed 16 MFMAs), the operands stream
+// through LDS in 16-column chunks, double buffered, the next chunk's global loads in flight
+// during the sweep.  Row sums stay in registers for the whole sweep; for J > I the tile's COLUMN
+// sums are the contribution of block I to the particles of block J and go to
+// colpart2[I][j] (no atomics: pso_ese_finish adds the slabs in a fixed order, so the result is
+// reproducible).
+// grid (ceil(np/128), P), 256 threads, dynamic LDS 2*2*128*18+512 doubles
 // ---------------------------------------------------------------------------
-constexpr int ESE_KC = 32;
+constexpr int ESE2_KC = 16, ESE2_LT = ESE2_KC + 2, ESE2_TILE = 128 * ESE2_LT;
 
-__global__ __launch_bounds__(256) void pso_ese(PsoDev d, PsoConst c)
+__global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
 {
-    const int p = blockIdx.y;
+    const int p = blockIdx.y, I = blockIdx.x;
     const PsoScal *sc = d.scal + p;
     if (pso_frozen(c, sc)) return;
-    extern __shared__ double lds[];
-    const int ldt = ESE_KC + 2;
-    double *Ai = lds, *Bj = lds + 64 * ldt;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *cs = lds + 4 * ESE2_TILE;        // [2][128] column sums / [2][128] row sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * 64, np = c.np, n = c.n, ld = c.ld;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int np = c.np, n = c.n, ld = c.ld;
+    const int NB = (np + 127) >> 7, NCH = (ld + ESE2_KC - 1) / ESE2_KC;   // ld is even, not padded to 16
     const double *X = d.X + (size_t) p * np * ld;
     const double *mean = d.mean + (size_t) p * ld;
     const double *nrm = d.nrm + (size_t) p * np;
     const int fr = lane & 15, fk = lane >> 4;
-    double rowacc[4] = { 0., 0., 0., 0. };
-    for (int j0 = 0; j0 < np; j0 += 64) {
-        pso_d4 acc[4];
+    const int sr = tid >> 1, sh = (tid & 1) * 8;     // staging: row, first of 8 columns
+
+    double2 pa[4], pb[4];
+    auto fetch = [&](int J, int ch) {
+        const int k0 = ch * ESE2_KC + sh;
+        const int gi = I * 128 + sr, gj = J * 128 + sr;
+        const double *ra = X + (size_t) min(gi, np - 1) * ld;
+        const double *rb = X + (size_t) min(gj, np - 1) * ld;
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = pso_d4 { 0., 0., 0., 0. };
-        for (int k0 = 0; k0 < ld; k0 += ESE_KC) {
-            __syncthreads();
-            for (int q = tid; q < 64 * ESE_KC; q += 256) {
-                const int r = q / ESE_KC, k = q - r * ESE_KC;
-                const int kk = k0 + k;
-                const double m = kk < n ? mean[kk] : 0.;
-                const int gi = i0 + r, gj = j0 + r;
-                Ai[r * ldt + k] = (gi < np && kk < n) ? X[(size_t) gi * ld + kk] - m : 0.;
-                Bj[r * ldt + k] = (gj < np && kk < n) ? X[(size_t) gj * ld + kk] - m : 0.;
+        for (int u = 0; u < 4; u++) {
+            const int kk = min(k0 + 2 * u, ld - 2);    // past the row: any in-row address, masked below
+            pa[u] = *reinterpret_cast<const double2*>(ra + kk);
+            pb[u] = *reinterpret_cast<const double2*>(rb + kk);
+        }
+    };
+    auto stash = [&](int J, int ch, int buf) {
+        const int k0 = ch * ESE2_KC + sh;
+        const bool ia = I * 128 + sr < np, ib = J * 128 + sr < np;
+        double *A = lds + buf * 2 * ESE2_TILE + sr * ESE2_LT + sh;
+        double *B = A + ESE2_TILE;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = k0 + 2 * u;
+            const double2 m = *reinterpret_cast<const double2*>(mean + min(kk, ld - 2));
+            double2 va, vb;
+            va.x = (ia && kk < n) ? pa[u].x - m.x : 0.;
+            va.y = (ia && kk + 1 < n) ? pa[u].y - m.y : 0.;
+            vb.x = (ib && kk < n) ? pb[u].x - m.x : 0.;
+            vb.y = (ib && kk + 1 < n) ? pb[u].y - m.y : 0.;
+            *reinterpret_cast<double2*>(A + 2 * u) = va;
+            *reinterpret_cast<double2*>(B + 2 * u) = vb;
+        }
+    };
+
+    double rowacc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) rowacc[rt][r] = 0.;
+    pso_d4 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) acc[rt][ct] = pso_d4 { 0., 0., 0., 0. };
+
+    // Balanced cover of the unordered block pairs: block I takes the next `half` blocks
+    // cyclically (for even NB the opposite pair {I, I + NB/2} belongs to the smaller index), so
+    // every workgroup sweeps the same number of tiles.
+    const int half = NB >> 1;
+    const int cnt = 1 + ((NB & 1) || I < half ? half : half - 1);
+    const int total = cnt * NCH;
+    fetch(I, 0);
+    stash(I, 0, 0);
+    __syncthreads();
+    for (int it = 0; it < total; it++) {
+        const int t = it / NCH, ch = it - t * NCH;
+        const int J = I + t < NB ? I + t : I + t - NB;
+        const int buf = it & 1;
+        const int nit = it + 1, nt = nit / NCH, nch = nit - nt * NCH;
+        const int nJ = I + nt < NB ? I + nt : I + nt - NB;
+        if (nit < total) fetch(nJ, nch);
+        const double *A = lds + buf * 2 * ESE2_TILE + (64 * wr + fr) * ESE2_LT + fk;
+        const double *B = lds + buf * 2 * ESE2_TILE + ESE2_TILE + (64 * wc + fr) * ESE2_LT + fk;
+#pragma unroll
+        for (int ks = 0; ks < ESE2_KC / 4; ks++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                a[t] = A[16 * t * ESE2_LT + 4 * ks];
+                b[t] = B[16 * t * ESE2_LT + 4 * ks];
             }
-            __syncthreads();
 #pragma unroll
-            for (int ks = 0; ks < ESE_KC / 4; ks++) {
-                const double a = Ai[(16 * wave + fr) * ldt + 4 * ks + fk];
+            for (int rt = 0; rt < 4; rt++)
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const double b = Bj[(16 * t + fr) * ldt + 4 * ks + fk];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                for (int ct = 0; ct < 4; ct++)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct],
+                            0, 0, 0);
+        }
+        if (ch == NCH - 1) {
+            // tile (I, J) complete: distances, row sums, and (J != I) column sums
+            double colsum[4] = { 0., 0., 0., 0. };
+            double nj[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                const int gj = J * 128 + 64 * wc + 16 * ct + fr;
+                nj[ct] = gj < np ? nrm[gj] : 0.;
+            }
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gi = I * 128 + 64 * wr + 16 * rt + fk + 4 * r;
+                    const double ni = gi < np ? nrm[gi] : 0.;   // (re-read per tile: registers are
+                                                                //  spent on the 16 accumulator tiles)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++) {
+                        const int gj = J * 128 + 64 * wc + 16 * ct + fr;
+                        double dist = 0.;
+                        if (gi < np && gj < np && gi != gj)
+                            dist = sqrt(fmax(ni + nj[ct] - 2. * acc[rt][ct][r], 0.));
+                        rowacc[rt][r] += dist;
+                        colsum[ct] += dist;
+                    }
                 }
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                double csum = colsum[ct];
+                csum += __shfl_xor(csum, 16, 64);
+                csum += __shfl_xor(csum, 32, 64);
+                colsum[ct] = csum;
+                acc[0][ct] = acc[1][ct] = acc[2][ct] = acc[3][ct] = pso_d4 { 0., 0., 0., 0. };
+            }
+            if (t > 0) {
+                if (fk == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++) cs[wr * 128 + 64 * wc + 16 * ct + fr] = colsum[ct];
+                }
+                __syncthreads();
+                if (tid < 128 && J * 128 + tid < np)
+                    d.colpart2[((size_t) p * NB + I) * np + J * 128 + tid] = cs[tid] + cs[128 + tid];
             }
         }
+        if (nit < total) stash(nJ, nch, buf ^ 1);
+        __syncthreads();
+    }
+    // row sums of block I over all J >= I: 16 lanes, then the two column-half wavefronts
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int gj = j0 + 16 * t + (lane & 15);
-            const double nj = gj < np ? nrm[gj] : 0.;
+    for (int rt = 0; rt < 4; rt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int gi = i0 + 16 * wave + (lane >> 4) + 4 * r;
-                if (gi < np && gj < np && gi != gj) {
-                    const double d2 = nrm[gi] + nj - 2. * acc[t][r];
-                    rowacc[r] += sqrt(fmax(d2, 0.));
-                }
-            }
+        for (int r = 0; r < 4; r++) {
+            const double s = pso_group_sum<16>(rowacc[rt][r]);
+            if (fr == 0) cs[wc * 128 + 64 * wr + 16 * rt + fk + 4 * r] = s;
         }
+    __syncthreads();
+    if (tid < 128 && I * 128 + tid < np)
+        d.rowpart2[(size_t) p * np + I * 128 + tid] = cs[tid] + cs[128 + tid];
+}
+
+// ws_i = (row sums of i's own block + the column contributions of every earlier block) / (np-1)
+__global__ __launch_bounds__(256) void pso_ese_finish(PsoDev d, PsoConst c)
+{
+    const int p = blockIdx.y;
+    const PsoScal *sc = d.scal + p;
+    if (pso_frozen(c, sc)) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, np = c.np;
+    if (i >= np) return;
+    const int NB = (np + 127) >> 7, Jb = i >> 7, half = NB >> 1;
+    double s = d.rowpart2[(size_t) p * np + i];
+    // the blocks that swept block Jb as one of their partners, in a fixed order
+    for (int t = 1; t <= half; t++) {
+        const int I = Jb - t >= 0 ? Jb - t : Jb - t + NB;
+        if ((NB & 1) || t < half || I < half) s += d.colpart2[((size_t) p * NB + I) * np + i];
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const double s = pso_group_sum<16>(rowacc[r]);
-        const int gi = i0 + 16 * wave + (lane >> 4) + 4 * r;
-        if ((lane & 15) == 0 && gi < np) d.ws[(size_t) p * np + gi] = s / (np - 1.);
-    }
+    d.ws[(size_t) p * np + i] = s / (np - 1.);
 }
 
 // ---------------------------------------------------------------------------

@@ -67,7 +67,7 @@ def de_kernel_costs(n, np_, P):
 def pso_kernel_costs(n, np_, P):
     return {
         "pso_center": ("hbm", P * np_ * 16 * n),
-        "pso_ese": ("mfma", P * np_ * 2 * n * np_),
+        "pso_ese": ("mfma", P * np_ * n * np_),          # d_ij = d_ji: half of the 2 n np^2 products
         "pso_control": ("hbm", P * np_ * 16),
         "pso_update": ("hbm", P * np_ * (40 * n + 16)),
         "pso_finish": ("hbm", P * np_ * 16),
