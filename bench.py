@@ -105,7 +105,12 @@ def measured_traffic(workload, P, kernel):
     e = t.get("%s:P%d" % (workload, P))
     if not e:
         return None
-    return e.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    # the timer slot is named after the phase; the launched kernel may be a shape-specific
+    # variant of it (cma_sample_eval -> cma_sample_eval128, pso_ese -> pso_ese_sym + _finish)
+    hits = [v.get("hbm_bytes_per_launch") for k, v in e.get("kernels", {}).items()
+            if k == kernel or k.startswith(kernel)]
+    hits = [h for h in hits if h is not None]
+    return float(sum(hits)) if hits else None
 
 
 def make_optimizer(bb, wl, P, seed, device):
@@ -226,8 +231,8 @@ def cpu_baseline(wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)    # >= 200 generations ...
+    ap.add_argument("--warmup", type=int, default=20)   # ... after 20 warm-up generations
     ap.add_argument("--workload", default="M", choices=sorted(WORKLOADS))
     ap.add_argument("--populations", type=int, default=None,
                     help="independent populations per GPU (default: per workload)")
