@@ -259,7 +259,7 @@ struct Ranked {
 
 struct Cma {
     /* constructor parameters */
-    int variant = 1;          /* 0 = Cmaes, 1 = ActiveCmaes */
+    int variant = 1;          /* 0 = Cmaes, 1 = ActiveCmaes, 2 = SepCmaes */
     int mfev = 0, lambda = 0;
     double tol = 0., sigma0 = 2., alphacov = 2., eigenrate = 0.25;
     bool bound = false, adaptpop = false, adaptit = false;
@@ -282,6 +282,10 @@ struct Cma {
     /* active-CMA additions */
     double cm = 1., cneg = 0., alphaold = 0.5;
     std::vector<double> ycoeff;
+    /* sep-CMA additions (sep_cmaes.h:36-41): diagonal covariance; D doubles as _diagd */
+    bool adjustlr = false;
+    double ccov = 0.;
+    std::vector<double> csep;
     /* randomness */
     int rng_mode = RNG_MT;
     uint64_t seed = 0;
@@ -357,6 +361,21 @@ struct Cma {
         bbo_objective_aux(obj, n, aux.data());
         init_base(guess);
 
+        if (variant == 2) {
+            /* sep_cmaes.cpp:41-68 */
+            cc = 4. / (n + 4.);
+            cs = (mueff + 2.) / (3. + n + mueff);
+            damps = 1. + cs + 2. * std::max(0., std::sqrt((mueff - 1.) / (n + 1.)) - 1.);
+            ccov = 2. / ((n + std::sqrt(2.)) * (n + std::sqrt(2.)) * mueff);
+            ccov += std::min(1., (2. * mueff - 1.) / ((n + 2.) * (n + 2.) + mueff))
+                    * (1. - 1. / mueff);
+            if (adjustlr) ccov *= ((n + 2.) / 3.);
+            D.assign(n, 1.);
+            csep.assign(n, 1.);
+            flag = 0;
+            return;
+        }
+
         eigenfreq = eigenrate * lambda / (c1 + cmu) / n;
         eigenlastev = 0;
         D.assign(n, 1.);
@@ -413,6 +432,18 @@ struct Cma {
     void sample()
     {
         zlast.assign((size_t) lambda * n, 0.);
+        if (variant == 2) {
+            /* sep_cmaes.cpp:70-80 */
+            for (int k = 0; k < lambda; k++)
+                for (int i = 0; i < n; i++) {
+                    const double z = next_normal(k, i);
+                    zlast[(size_t) k * n + i] = z;
+                    double v = xmean[i] + sigma * D[i] * z;
+                    if (bound) v = std::max(lower[i], std::min(v, upper[i]));
+                    x(k)[i] = v;
+                }
+            return;
+        }
         for (int k = 0; k < lambda; k++) {
             for (int i = 0; i < n; i++) {
                 const double z = next_normal(k, i);
@@ -458,8 +489,78 @@ struct Cma {
     }
 
     /* cmaes.cpp:82-149 (variant 0) and active_cmaes.cpp:71-168 (variant 1) */
+    /* sep_cmaes.cpp:82-135 */
+    void update_distribution_sep()
+    {
+        std::copy(xmean.begin(), xmean.end(), xold.begin());
+        for (int i = 0; i < n; i++) {
+            double sum = 0.;
+            for (int k = 0; k < mu; k++) sum += weights[k] * x(fit[k].index)[i];
+            xmean[i] = sum;
+            if (bound) xmean[i] = std::max(lower[i], std::min(xmean[i], upper[i]));
+        }
+        const double csc = std::sqrt(cs * (2. - cs) * mueff);
+        for (int i = 0; i < n; i++) {
+            ps[i] *= (1. - cs);
+            /* (the reference scales by _c[i], not by 1/_diagd[i]: kept) */
+            ps[i] += csc * csep[i] * (xmean[i] - xold[i]) / sigma;
+        }
+        const double pslen = nrm2(n, ps.data());
+        const double denom = 1. - std::pow(1. - cs, 2. * fev / lambda);
+        const int hsig = pslen / std::sqrt(denom) / chi < 1.4 + 2. / (n + 1.) ? 1 : 0;
+        const double ccc = std::sqrt(cc * (2. - cc) * mueff);
+        for (int i = 0; i < n; i++)
+            pc[i] = (1. - cc) * pc[i] + hsig * ccc * (xmean[i] - xold[i]) / sigma;
+        for (int i = 0; i < n; i++) {
+            double sum = (1. - ccov) * csep[i] + (ccov / mueff) * pc[i] * pc[i];
+            for (int k = 0; k < mu; k++) {
+                const double di = (x(fit[k].index)[i] - xold[i]) / sigma;
+                sum += ccov * (1. - 1. / mueff) * weights[k] * di * di;
+            }
+            csep[i] = sum;
+            D[i] = std::sqrt(csep[i]);
+        }
+        update_sigma();
+    }
+
+    /* sep_cmaes.cpp:137-206; returns the stop flag (0 = continue) */
+    int converged_sep()
+    {
+        if (it >= mit) return flag = 1;
+        if (it >= hlen && fworst - fbest < tol) return flag = 2;
+        if (best.len >= n && kth.len >= n) {
+            int eq = 0;
+            for (int i = 0; i < n; i++) {
+                if (best.back(i) == kth.back(i)) {
+                    eq++;
+                    if (3 * eq >= n) return flag = 3;
+                }
+            }
+        }
+        bool all = true;
+        for (int i = 0; i < n; i++) {
+            if (std::max(pc[i], D[i]) * sigma / sigma0 >= tol) {
+                all = false;
+                break;
+            }
+        }
+        if (all) return flag = 4;
+        if (sigma / sigma0 > 1.0e20 * D[n - 1]) return flag = 5;   /* unsorted _diagd: kept */
+        if (D[n - 1] > 1.0e7 * D[0]) return flag = 7;
+        const int iaxis = n - 1 - ((it - 1) % n);
+        if (xmean[iaxis] == xmean[iaxis] + 0.1 * sigma * D[iaxis]) return flag = 8;
+        for (int i = 0; i < n; i++) {
+            if (xmean[i] == xmean[i] + 0.2 * sigma * D[i]) return flag = 9;
+        }
+        return 0;
+    }
+
     void update_distribution()
     {
+        if (variant == 2) {
+            update_distribution_sep();
+            return;
+        }
         const bool active = (variant == 1);
         std::copy(xmean.begin(), xmean.end(), xold.begin());
         for (int i = 0; i < n; i++) {
@@ -572,6 +673,7 @@ struct Cma {
     /* cmaes.cpp:151-227; returns the stop flag (0 = continue) */
     int converged()
     {
+        if (variant == 2) return converged_sep();
         if (it >= mit) return flag = 1;
         if (it >= hlen && fworst - fbest < tol) return flag = 2;
         if (best.len >= n && kth.len >= n) {
@@ -880,6 +982,8 @@ struct Cma {
         if (k == "cneg") return put1(cneg, out, cap);
         if (k == "alphaold") return put1(alphaold, out, cap);
         if (k == "cm") return put1(cm, out, cap);
+        if (k == "ccov") return put1(ccov, out, cap);
+        if (k == "csep") return put(csep, out, cap);
         return -1;
     }
 
@@ -898,6 +1002,7 @@ struct Cma {
         if (k == "B") return take(B);
         if (k == "C") return take(C);
         if (k == "invsqrtC") return take(invsqrtC);
+        if (k == "csep") return take(csep);
         if (k == "arx") return take(arx);
         if (k == "best_hist") return take(best.v);
         if (k == "kth_hist") return take(kth.v);
@@ -973,6 +1078,7 @@ void* orc_cma_create(int variant, int mfev, double tol, int np, double sigma0,
     h->bound = bound != 0;
     h->alphacov = alphacov;
     h->eigenrate = eigenrate;
+    if (variant == 2) h->adjustlr = alphacov != 0.;   /* SepCmaes: the slot carries adjustlr */
     return h;
 }
 void orc_cma_destroy(void *p) { delete static_cast<Cma*>(p); }

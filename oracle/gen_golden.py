@@ -187,17 +187,66 @@ def gen_restart_runs(R):
     dump("restart_runs.json", runs)
 
 
+SEP_STATE = ("xmean", "sigma", "pc", "ps", "csep", "D", "arx", "fit_val", "fit_idx", "it",
+             "fev", "fbest", "fworst")
+
+
+def gen_sep_runs(R):
+    """SepCmaes (sep_cmaes.cpp): strategy constants and full trajectories"""
+    runs = []
+    cases = [(10, 20, "ellipsoid", 21, 20000, 1e-8, False, False),
+             (10, 20, "rosenbrock", 22, 20000, 1e-6, False, True),
+             (16, 12, "rastrigin", 23, 20000, 1e-6, True, False),
+             (40, 30, "discus", 24, 30000, 1e-8, False, True)]
+    for n, lam, obj, seed, mfev, tol, bound, adjustlr in cases:
+        R.seed(seed)
+        box = 5.12 if obj == "rastrigin" else 10.
+        lo, up = -box * np.ones(n), box * np.ones(n)
+        guess = np.random.default_rng(seed).uniform(-box, box, n)
+        h = po.cma(R, "sep", mfev, tol, lam, bound=bound, adjustlr=adjustlr)
+        h.init(obj, lo, up, guess)
+        rec = {"n": n, "lambda": lam, "objective": obj, "seed": seed, "mfev": mfev, "tol": tol,
+               "bound": bound, "adjustlr": adjustlr, "box": box, "guess": hx(guess),
+               "constants": {k: hx(h.scalar(k))[0] for k in ("mu", "mueff", "cc", "cs", "ccov",
+                                                             "damps", "chi", "hlen", "ik", "mit")},
+               "states": [], "trace": []}
+        rec["normals_first3"] = hx(h.peek_normals(3 * lam * n))
+        gen, flag = 0, 0
+        while h.scalar("fev") < mfev:
+            h.iterate()
+            gen += 1
+            if gen <= 3 or gen in (10, 50):
+                rec["states"].append({"gen": gen, **{k: hx(h.get(k)) for k in SEP_STATE}})
+            D = h.get("D")
+            rec["trace"].append(hx([h.get("fit_val")[0], h.scalar("sigma"),
+                                    np.linalg.norm(h.get("xmean")), D.max() / D.min()]))
+            flag = h.converged()
+            if flag:
+                break
+        x, fev, conv = h.solution()
+        rec["result"] = {"generations": gen, "flag": flag, "fev": fev, "converged": conv,
+                         "x": hx(x)}
+        if len(rec["trace"]) > 120:
+            rec["trace_head"] = rec["trace"][:60]
+            rec["trace_tail"] = rec["trace"][-60:]
+            del rec["trace"]
+        runs.append(rec)
+        h.destroy()
+    dump("sep_runs.json", runs)
+
+
 def main():
     po.build_ref()
     R = po.reference()
     if R is None:
         sys.exit("the reference is not available here: fixtures can only be generated in the "
                  "development container")
-    gen_rng(R)
-    gen_cma_constants(R)
-    gen_cma_runs(R)
-    gen_pop_runs(R)
-    gen_restart_runs(R)
+    only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
+    gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
+            "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs}
+    for name, fn in gens.items():
+        if only is None or only == name:
+            fn(R)
 
 
 if __name__ == "__main__":

@@ -238,9 +238,12 @@ class Handle:
             self.ptr = None
 
 
-def cma(lib, variant, mfev, tol, np_, sigma0=2., bound=False, alphacov=2., eigenrate=0.25):
-    """variant: 'cmaes' | 'active'"""
-    v = {"cmaes": 0, "active": 1}[variant]
+def cma(lib, variant, mfev, tol, np_, sigma0=2., bound=False, alphacov=2., eigenrate=0.25,
+        adjustlr=False):
+    """variant: 'cmaes' | 'active' | 'sep' (SepCmaes: the alphacov slot carries adjustlr)"""
+    v = {"cmaes": 0, "active": 1, "sep": 2}[variant]
+    if v == 2:
+        alphacov = 1. if adjustlr else 0.
     return Handle(lib, "cma", lib.f("cma_create")(v, mfev, tol, np_, sigma0, int(bound),
                                                    alphacov, eigenrate))
 

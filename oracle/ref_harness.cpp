@@ -32,6 +32,7 @@
 #include "multivariate/cma/active_cmaes.h"
 #include "multivariate/cma/bipop_cmaes.h"
 #include "multivariate/cma/ipop_cmaes.h"
+#include "multivariate/cma/sep_cmaes.h"
 #include "multivariate/de/shade.h"
 #include "multivariate/de/jade.h"
 #include "multivariate/pso/apso.h"
@@ -155,6 +156,56 @@ struct CmaProbe: Base {
 using PlainProbe = CmaProbe<Cmaes, false>;
 using ActiveProbe = CmaProbe<ActiveCmaes, true>;
 
+/* SepCmaes keeps a diagonal: _c and _diagd are vectors, there is no B / C^-1/2 */
+struct SepProbe: SepCmaes {
+    using SepCmaes::SepCmaes;
+
+    int get(const std::string &k, double *out, int cap)
+    {
+        if (k == "xmean") return put(_xmean, out, cap);
+        if (k == "xold") return put(_xold, out, cap);
+        if (k == "pc") return put(_pc, out, cap);
+        if (k == "ps") return put(_ps, out, cap);
+        if (k == "weights") return put(_weights, out, cap);
+        if (k == "D") return put(_diagd, out, cap);
+        if (k == "csep") return put(_c, out, cap);
+        if (k == "arx") return put_mat(_arx, out, cap);
+        if (k == "fit_val" || k == "fit_idx") {
+            int m = 0;
+            for (const auto &f : _fitness) {
+                if (m < cap) out[m] = (k == "fit_val") ? f._value : (double) f._index;
+                m++;
+            }
+            return m;
+        }
+        if (k == "best_hist") return put(_best._hist, out, cap);
+        if (k == "kth_hist") return put(_kth._hist, out, cap);
+        if (k == "sigma") return put1(_sigma, out, cap);
+        if (k == "sigma0") return put1(_sigma0, out, cap);
+        if (k == "n") return put1(_n, out, cap);
+        if (k == "lambda") return put1(_lambda, out, cap);
+        if (k == "mu") return put1(_mu, out, cap);
+        if (k == "mueff") return put1(_mueff, out, cap);
+        if (k == "cc") return put1(_cc, out, cap);
+        if (k == "cs") return put1(_cs, out, cap);
+        if (k == "ccov") return put1(_ccov, out, cap);
+        if (k == "damps") return put1(_damps, out, cap);
+        if (k == "chi") return put1(_chi, out, cap);
+        if (k == "hlen") return put1(_hlen, out, cap);
+        if (k == "ik") return put1(_ik, out, cap);
+        if (k == "mit") return put1(_mit, out, cap);
+        if (k == "mfev") return put1(_mfev, out, cap);
+        if (k == "it") return put1(_it, out, cap);
+        if (k == "fev") return put1(_fev, out, cap);
+        if (k == "flag") return put1(_flag, out, cap);
+        if (k == "fbest") return put1(_fbest, out, cap);
+        if (k == "fworst") return put1(_fworst, out, cap);
+        if (k == "best_len") return put1(_best._len, out, cap);
+        if (k == "best_buffer") return put1(_best._buffer, out, cap);
+        return -1;
+    }
+};
+
 struct RefCma {
     int variant = 1;
     std::unique_ptr<BaseCmaes> alg;
@@ -164,6 +215,7 @@ struct RefCma {
     int get(const char *key, double *out, int cap)
     {
         if (variant == 0) return static_cast<PlainProbe*>(alg.get())->get(key, out, cap);
+        if (variant == 2) return static_cast<SepProbe*>(alg.get())->get(key, out, cap);
         return static_cast<ActiveProbe*>(alg.get())->get(key, out, cap);
     }
     Cmaes* cma() { return static_cast<Cmaes*>(alg.get()); }
@@ -355,6 +407,8 @@ void* ref_cma_create(int variant, int mfev, double tol, int np, double sigma0,
     h->variant = variant;
     if (variant == 0)
         h->alg.reset(new PlainProbe(mfev, tol, np, sigma0, bound != 0, eigenrate));
+    else if (variant == 2)   /* SepCmaes: the alphacov slot carries adjustlr */
+        h->alg.reset(new SepProbe(mfev, tol, np, sigma0, bound != 0, alphacov != 0.));
     else
         h->alg.reset(new ActiveProbe(mfev, tol, np, sigma0, bound != 0, alphacov,
                 eigenrate));
@@ -396,7 +450,7 @@ void ref_cma_peek_normals(void *p, double *out, int count)
 {
     auto *h = static_cast<RefCma*>(p);
     auto eng = Random::get_engine();
-    auto dist = h->cma()->_Z;
+    auto dist = h->variant == 2 ? static_cast<SepCmaes*>(h->alg.get())->_Z : h->cma()->_Z;
     for (int i = 0; i < count; i++) out[i] = dist(eng);
 }
 

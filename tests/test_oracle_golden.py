@@ -114,3 +114,47 @@ def test_restart_schedule(oracle_lib, idx):
             h.iterate()
         for k, v in row.items():
             np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="restart %d %s" % (i, k))
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_sep_cma_trajectory(oracle_lib, idx):
+    """SepCmaes (sep_cmaes.cpp:41-206): constants, first three generations' normals, states at
+    generations 1, 2, 3, 10, 50, the whole (f_best, sigma, |m|, cond) trace and the result, bit
+    for bit against the reference's run (tests/golden/sep_runs.json)."""
+    rec = load("sep_runs.json")[idx]
+    n, lam, box = rec["n"], rec["lambda"], rec["box"]
+    oracle_lib.seed(rec["seed"])
+    h = po.cma(oracle_lib, "sep", rec["mfev"], rec["tol"], lam, bound=rec["bound"],
+               adjustlr=rec["adjustlr"])
+    h.init(rec["objective"], -box * np.ones(n), box * np.ones(n), unhex(rec["guess"]))
+    for k, v in rec["constants"].items():
+        assert h.scalar(k) == float.fromhex(v), k
+    states = {s["gen"]: s for s in rec["states"]}
+    zs = unhex(rec["normals_first3"]).reshape(3, lam * n)
+    gen, flag, rows = 0, 0, []
+    while h.scalar("fev") < rec["mfev"]:
+        h.iterate()
+        if gen < 3:
+            np.testing.assert_array_equal(h.get("zlast"), zs[gen])
+        gen += 1
+        if gen in states:
+            for k, v in states[gen].items():
+                if k != "gen":
+                    np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="gen %d %s" % (gen, k))
+        D = h.get("D")
+        rows.append([h.get("fit_val")[0], h.scalar("sigma"), np.linalg.norm(h.get("xmean")),
+                     D.max() / D.min()])
+        flag = h.converged()
+        if flag:
+            break
+    rows = np.array(rows)
+    if "trace" in rec:
+        np.testing.assert_array_equal(rows, np.array([unhex(r) for r in rec["trace"]]))
+    else:
+        np.testing.assert_array_equal(rows[:60], np.array([unhex(r) for r in rec["trace_head"]]))
+        np.testing.assert_array_equal(rows[-60:], np.array([unhex(r) for r in rec["trace_tail"]]))
+    x, fev, conv = h.solution()
+    res = rec["result"]
+    assert (gen, flag, fev, conv) == (res["generations"], res["flag"], res["fev"],
+                                      res["converged"])
+    np.testing.assert_array_equal(x, unhex(res["x"]))

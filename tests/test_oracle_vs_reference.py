@@ -35,6 +35,32 @@ def test_cma_bit_exact(oracle_lib, ref_lib, variant, n, lam, obj):
             break
 
 
+@pytest.mark.parametrize("n,lam,obj,bound,adjustlr", [
+    (10, 20, "ellipsoid", False, False), (37, 50, "rastrigin", True, True),
+    (64, 128, "rosenbrock", False, False), (5, 6, "cigar", True, False)])
+def test_sep_cma_bit_exact(oracle_lib, ref_lib, n, lam, obj, bound, adjustlr):
+    """SepCmaes (sep_cmaes.cpp), every generation and the stop decision"""
+    oracle_lib.seed(77)
+    ref_lib.seed(77)
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(n).uniform(-4, 4, n)
+    hs = [po.cma(L, "sep", 10 ** 7, 1e-10, lam, sigma0=1.5, bound=bound, adjustlr=adjustlr)
+          for L in (oracle_lib, ref_lib)]
+    for h in hs:
+        h.init(obj, lo, up, guess)
+    for k in ("cc", "cs", "ccov", "damps", "mueff", "chi"):
+        assert hs[0].scalar(k) == hs[1].scalar(k), k
+    for it in range(300):
+        for h in hs:
+            h.iterate()
+        _same(hs[0], hs[1], ("xmean", "sigma", "csep", "D", "pc", "ps", "arx", "fit_val",
+                             "fit_idx"), "sep n=%d it=%d" % (n, it))
+        fo, fr = hs[0].converged(), hs[1].converged()
+        assert fo == fr
+        if fo:
+            break
+
+
 def test_cma_bound_and_lazy_eigen(oracle_lib, ref_lib):
     """bound=True clipping (cmaes.cpp:74-77,93-95) and the lazy eigen schedule of plain CMAES
     at small lambda (cmaes.cpp:48,233)"""
