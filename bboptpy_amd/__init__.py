@@ -8,7 +8,9 @@ of include/bbopt_hip.h.  See DESIGN.md.
 from . import objectives
 from .objectives import vectorized
 from .multivariate import (MultivariateSolution, MultivariateSearch, BaseCMAES, CMAES,
-                           ActiveCMAES, IPopCMAES, BiPopCMAES, JADE, SHADE, APSO)
+                           ActiveCMAES, SepCMAES, IPopCMAES, BiPopCMAES, JADE, SHADE,
+                           APSO)
 
 __all__ = ["MultivariateSolution", "MultivariateSearch", "BaseCMAES", "CMAES", "ActiveCMAES",
-           "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "APSO", "objectives", "vectorized"]
+           "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "APSO", "objectives",
+           "vectorized"]

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbbopt_hip.so")
 
 # bbo_algo
-ALGO_CMAES, ALGO_ACTIVE_CMAES, ALGO_SHADE, ALGO_JADE, ALGO_APSO, ALGO_IPOP, ALGO_BIPOP = range(7)
+ALGO_CMAES, ALGO_ACTIVE_CMAES, ALGO_SHADE, ALGO_JADE, ALGO_APSO, ALGO_IPOP, ALGO_BIPOP, \
+    ALGO_SEP_CMAES = range(8)
 # bbo_objective_kind
 OBJ_BUILTIN, OBJ_SCALAR_CB, OBJ_BATCH_CB = 0, 1, 2
 # bbo_cma_phase
@@ -38,7 +39,7 @@ class Params(C.Structure):
         ("print", C.c_int), ("nipop", C.c_int), ("ksigmadec", C.c_double),
         ("boundlambda", C.c_int), ("maxlargeruns", C.c_int), ("kbudget", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int), ("populations", C.c_int),
-        ("poll_every", C.c_int),
+        ("poll_every", C.c_int), ("adjustlr", C.c_int),
     ]
 
 

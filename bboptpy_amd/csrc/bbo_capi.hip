@@ -109,6 +109,7 @@ int bbo_create(const bbo_params *params, bbo_handle *out)
         switch (params->algo) {
         case BBO_ALGO_CMAES:
         case BBO_ALGO_ACTIVE_CMAES:
+        case BBO_ALGO_SEP_CMAES:
             h->opt.reset(new bbo::CmaEngine(*params));
             break;
         case BBO_ALGO_SHADE:
@@ -144,7 +145,8 @@ int bbo_create_restart(const bbo_params *params, bbo_handle base, bbo_handle *ou
     try {
         if (params->algo != BBO_ALGO_IPOP_CMAES && params->algo != BBO_ALGO_BIPOP_CMAES)
             throw bbo::Error(BBO_ERR_ARG, "bbo_create_restart: algo must be IPOP or BIPOP");
-        if (base->algo != BBO_ALGO_CMAES && base->algo != BBO_ALGO_ACTIVE_CMAES)
+        if (base->algo != BBO_ALGO_CMAES && base->algo != BBO_ALGO_ACTIVE_CMAES
+                && base->algo != BBO_ALGO_SEP_CMAES)
             throw bbo::Error(BBO_ERR_ARG, "bbo_create_restart: base must be a CMA-ES handle");
         std::unique_ptr<bbo_handle_s> h(new bbo_handle_s());
         h->algo = params->algo;

@@ -5,6 +5,7 @@
 // Cmaes::init (cmaes.cpp:44-63), ActiveCmaes::init (active_cmaes.cpp:42-69),
 // BaseCmaes::setParams (:136-148), optimize (:162-174), solution (:158-160).
 #include "bbo_cma_kernels.hpp"
+#include "bbo_sep_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -37,8 +38,8 @@ int gram_ldy(int ld)
 CmaEngine::CmaEngine(const bbo_params &p) :
         params_(p)
 {
-    BBO_REQUIRE(p.algo == BBO_ALGO_CMAES || p.algo == BBO_ALGO_ACTIVE_CMAES,
-            "CmaEngine: algo must be CMAES or ACTIVE_CMAES");
+    BBO_REQUIRE(p.algo == BBO_ALGO_CMAES || p.algo == BBO_ALGO_ACTIVE_CMAES
+            || p.algo == BBO_ALGO_SEP_CMAES, "CmaEngine: algo must be CMAES, ACTIVE_CMAES or SEP_CMAES");
     BBO_REQUIRE(p.np >= 4, "CMA-ES needs np >= 4 (mu >= 2, best/worst pairs)");
     BBO_REQUIRE(p.populations >= 1, "populations must be >= 1");
     int ndev = 0;
@@ -70,7 +71,11 @@ void CmaEngine::set_params(int np, double sigma, int mfev)
 void CmaEngine::init(int n, const double *lower, const double *upper, const double *guess,
         const ObjectiveSpec &obj)
 {
-    BBO_REQUIRE(n >= 1 && n <= EIG_NMAX, "dimension must be in [1, 512]");
+    const bool sep = params_.algo == BBO_ALGO_SEP_CMAES;
+    if (sep)
+        BBO_REQUIRE(n >= 1 && n <= 4096, "SepCMAES: dimension must be in [1, 4096]");
+    else
+        BBO_REQUIRE(n >= 1 && n <= EIG_NMAX, "dimension must be in [1, 512]");
     BBO_HIP(hipSetDevice(params_.device));
     obj_ = obj;
     const int P = params_.populations;
@@ -83,7 +88,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.lambda_pad = round_up(lambda, 16);
     c.mu = lambda / 2;
     c.mu_pad = round_up(c.mu, 16);
-    c.variant = params_.algo == BBO_ALGO_ACTIVE_CMAES ? 1 : 0;
+    c.variant = sep ? 2 : params_.algo == BBO_ALGO_ACTIVE_CMAES ? 1 : 0;
     c.bound = params_.bound ? 1 : 0;
     c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
     c.mfev = params_.mfev;
@@ -135,6 +140,17 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         c.eigenfreq = params_.eigenrate * (1. / (c.c1 + c.cmu + c.cneg)) / n;
     }
 
+    if (sep) {
+        // sep_cmaes.cpp:46-62
+        c.cc = 4. / (n + 4.);
+        c.cs = (c.mueff + 2.) / (3. + n + c.mueff);
+        c.damps = 1. + c.cs + 2. * std::max(0., std::sqrt((c.mueff - 1.) / (n + 1.)) - 1.);
+        c.ccov = 2. / ((n + std::sqrt(2.)) * (n + std::sqrt(2.)) * c.mueff);
+        c.ccov += std::min(1., (2. * c.mueff - 1.) / ((n + 2.) * (n + 2.) + c.mueff))
+                * (1. - 1. / c.mueff);
+        if (params_.adjustlr) c.ccov *= ((n + 2.) / 3.);
+    }
+
     // Gram split-K geometry
     c.rps = 64;
     if (c.ld == 128) {
@@ -144,10 +160,12 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         c.rps = ((c.lambda_pad + want - 1) / want + G128_CH - 1) / G128_CH * G128_CH;
     }
     c.splits = (c.lambda_pad + c.rps - 1) / c.rps;
+    if (sep)   // slabs of the mu selected ranks: enough workgroups to stream at HBM rate
+        c.splits = std::max(1, std::min(c.mu / 16, (1024 + P - 1) / P));
 
     // ---- HBM state ------------------------------------------------------------
     const size_t ld = c.ld, ld2 = ld * ld;
-    const bool same_shape = keep_bc_ && last_n_ == n && C_.count == P * ld2;
+    const bool same_shape = !sep && keep_bc_ && last_n_ == n && C_.count == P * ld2;
     X_.alloc((size_t) P * c.lambda_pad * ld);
     f_.alloc((size_t) P * c.lambda_pad);
     zn2_.alloc((size_t) P * c.lambda_pad);
@@ -158,11 +176,14 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     pc_.alloc(P * ld);
     ps_.alloc(P * ld);
     D_.alloc(P * ld);
-    isc_.alloc(P * ld2);
-    BDp_.alloc(P * ld2);
-    ISp_.alloc(P * ld2);
+    csep_.alloc(P * ld);
+    if (!sep) {
+        isc_.alloc(P * ld2);
+        BDp_.alloc(P * ld2);
+        ISp_.alloc(P * ld2);
+    }
     S_.alloc((size_t) P * c.mu_pad);
-    gram_part_.alloc((size_t) P * c.splits * ld2);
+    gram_part_.alloc((size_t) P * c.splits * (sep ? ld : ld2));   // sep: second moments, [ld]
     mean_part_.alloc((size_t) P * c.splits * ld);
     hist_best_.alloc((size_t) P * c.hlen);
     hist_kth_.alloc((size_t) P * c.hlen);
@@ -188,7 +209,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     // B = C = C^-1/2 = I, D = 1.  The reference resize()s _b/_c, so on a re-init of the
     // SAME object with the same n the old off-diagonals survive and only the diagonals are
     // reset (cmaes.cpp:53-59); restart drivers depend on that, so it is kept.
-    std::vector<double> eye(P * ld2, 0.), ones(P * ld, 1.);
+    std::vector<double> eye(sep ? 0 : P * ld2, 0.), ones(P * ld, 1.);
+    csep_.upload(ones.data(), P * ld);
+    if (!sep) {
     for (int p = 0; p < P; p++)
         for (int i = 0; i < n; i++) eye[p * ld2 + (size_t) i * ld + i] = 1.;
     if (same_shape) {
@@ -209,8 +232,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         C_.upload(eye.data(), P * ld2);
     }
     isc_.upload(eye.data(), P * ld2);
+    }   // !sep
     D_.upload(ones.data(), P * ld);
-    keep_bc_ = true;
+    keep_bc_ = !sep;
     last_n_ = n;
 
     std::vector<double> xm(P * ld, 0.);
@@ -234,14 +258,14 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     // the eigensolver keeps its matrix in LDS when it fits
     // global scratch of the eigensolver: the work matrix when it does not fit LDS, or
     // (divide and conquer) the Householder matrix and the merge factor
-    eig_work_.alloc((size_t) P * 4 * eig_slab((int) ld));
+    if (!sep) eig_work_.alloc((size_t) P * 4 * eig_slab((int) ld));
 
     CmaDev &d = d_;
     d = CmaDev {};
     d.X = X_.p; d.f = f_.p; d.rank = rank_.p; d.order = order_.p;
     d.xmean = xmean_.p; d.xold = xold_.p; d.pc = pc_.p; d.ps = ps_.p;
     d.C = C_.p; d.B = B_.p; d.D = D_.p; d.isc = isc_.p; d.BDp = BDp_.p; d.ISp = ISp_.p;
-    d.S = S_.p; d.zn2 = zn2_.p; d.gram_part = gram_part_.p; d.mean_part = mean_part_.p;
+    d.S = S_.p; d.zn2 = zn2_.p; d.csep = csep_.p; d.gram_part = gram_part_.p; d.mean_part = mean_part_.p;
     d.hist_best = hist_best_.p; d.hist_kth = hist_kth_.p; d.eig_work = eig_work_.p;
     d.weights = weights_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.zinject = nullptr; d.zrecord = nullptr; d.scal = scal_.p;
@@ -250,7 +274,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     // packed operands of the initial B, D, C^-1/2
     c.honor_stop = 0;
     inited_ = true;
-    {
+    if (!sep) {
         launch_post(2);
         BBO_HIP(hipGetLastError());
         BBO_HIP(hipStreamSynchronize(stream_));
@@ -281,6 +305,30 @@ void CmaEngine::launch_sample_eval()
     const CmaConst &c = c_;
     bool zn_valid = false;
     timer_.begin(stream_, K_SAMPLE);
+    if (c.variant == 2) {
+        // separable: 16 lanes per candidate while 16 rows fit LDS, else 64 lanes (4 rows)
+        static bool attr_done = false;
+        if (!attr_done) {
+            BBO_HIP(hipFuncSetAttribute((const void*) sep_sample_eval<16>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            BBO_HIP(hipFuncSetAttribute((const void*) sep_sample_eval<64>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_done = true;
+        }
+        if (c.ld <= 1024) {
+            const size_t lds = (size_t) 16 * c.ld * sizeof(double);
+            hipLaunchKernelGGL(sep_sample_eval<16>, dim3((c.lambda_pad + 15) / 16, c.npop),
+                    dim3(256), lds, stream_, d_, c_);
+        } else {
+            const size_t lds = (size_t) 4 * c.ld * sizeof(double);
+            hipLaunchKernelGGL(sep_sample_eval<64>, dim3((c.lambda_pad + 3) / 4, c.npop),
+                    dim3(256), lds, stream_, d_, c_);
+        }
+        timer_.end(stream_);
+        BBO_HIP(hipGetLastError());
+        c_.use_zn = 0;
+        return;
+    }
     if (c.ld == 128 && (long) c.npop * c.lambda_pad >= 256 * 128
             && (c.obj < 0 || frag_objective_ok(c.obj))) {
         // whole populations in flight: packed operand in LDS, normals drawn into the A fragments
@@ -356,6 +404,17 @@ void CmaEngine::launch_rank()
 void CmaEngine::launch_update()
 {
     const CmaConst &c = c_;
+    if (c.variant == 2) {
+        timer_.begin(stream_, K_GRAM);
+        hipLaunchKernelGGL(sep_moments, dim3(c.splits, (c.ld + 255) / 256, c.npop), dim3(256), 0,
+                stream_, d_, c_);
+        timer_.end(stream_);
+        timer_.begin(stream_, K_PATHS);
+        hipLaunchKernelGGL(sep_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
+        timer_.end(stream_);
+        BBO_HIP(hipGetLastError());
+        return;
+    }
     if (c.variant == 1) {
         timer_.begin(stream_, K_WHITEN);
         if (c.ld == 128 && (long) c.npop * c.mu_pad >= 256 * 128) {
@@ -429,6 +488,7 @@ void CmaEngine::launch_update()
 void CmaEngine::launch_eigen()
 {
     const CmaConst &c = c_;
+    if (c.variant == 2) return;        // diagonal covariance: d = sqrt(c) is part of sep_paths
     const EigPlan pl = eig_plan(c.n, c.ld);
     static bool attr_done = false;
     if (!attr_done) {
@@ -716,11 +776,14 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
         if (out && cap >= 1) out[0] = v;
         return 1;
     };
+    if (c.variant == 2 && (k == "B" || k == "C" || k == "invsqrtC" || k == "ycoeff"))
+        throw Error(BBO_ERR_KEY, "SepCMAES keeps a diagonal covariance: read 'csep' and 'D'");
     if (k == "xmean") return vec(xmean_);
     if (k == "xold") return vec(xold_);
     if (k == "pc") return vec(pc_);
     if (k == "ps") return vec(ps_);
     if (k == "D") return vec(D_);
+    if (k == "csep") return vec(csep_);
     if (k == "B") return mat(B_, n, ld, n, p * ld * ld);
     if (k == "C") return mat(C_, n, ld, n, p * ld * ld);
     if (k == "invsqrtC") return mat(isc_, n, ld, n, p * ld * ld);
@@ -804,6 +867,7 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "cneg") return one(c.cneg);
     if (k == "alphaold") return one(c.alphaold);
     if (k == "cm") return one(c.cm);
+    if (k == "ccov") return one(c.ccov);
     if (k == "damps") return one(c.damps);
     if (k == "chi") return one(c.chi);
     if (k == "eigenfreq") return one(c.eigenfreq);
@@ -837,10 +901,20 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         b.upload(tmp.data(), ld * ld, p * ld * ld);
         return count;
     };
+    if (c.variant == 2 && (k == "B" || k == "C" || k == "D"))
+        throw Error(BBO_ERR_KEY, "SepCMAES: set 'csep' (D is its square root)");
     if (k == "xmean") return vec(xmean_);
     if (k == "xold") return vec(xold_);
     if (k == "pc") return vec(pc_);
     if (k == "ps") return vec(ps_);
+    if (k == "csep") {
+        BBO_REQUIRE(c.variant == 2, "csep belongs to SepCMAES");
+        const int r = vec(csep_);
+        std::vector<double> dd(ld, 1.);
+        for (size_t i = 0; i < n; i++) dd[i] = std::sqrt(in[i]);
+        D_.upload(dd.data(), ld, p * ld);
+        return r;
+    }
     if (k == "C") return mat(C_);
     if (k == "invsqrtC") throw Error(BBO_ERR_KEY, "invsqrtC is derived from B and D: set those");
     if (k == "B" || k == "D") {

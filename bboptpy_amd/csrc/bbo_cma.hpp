@@ -31,7 +31,7 @@ struct CmaConst {
     int n, ld;                // dimension, padded leading dimension (multiple of 16)
     int lambda, lambda_pad;   // population size, padded to a multiple of 16
     int mu, mu_pad;
-    int variant;              // 0 plain (cmaes.cpp), 1 active (active_cmaes.cpp)
+    int variant;              // 0 plain (cmaes.cpp), 1 active (active_cmaes.cpp), 2 separable (sep_cmaes.cpp)
     int bound, obj;
     int use_zn;               // this generation's zn2 is valid and x was not clamped
     int mfev, mit, hlen, ik;
@@ -39,6 +39,7 @@ struct CmaConst {
     int splits, rps;          // Gram split-K: number of row slabs, rows per slab
     int npop;
     double mueff, cc, cs, c1, cmu, cneg, alphaold, cm, damps, chi, sigma0, tol, eigenfreq;
+    double ccov;              // separable variant (sep_cmaes.cpp:53-62)
     uint64_t seed;
 };
 
@@ -55,6 +56,7 @@ struct CmaDev {
     double *BDp;        // [P][ld*ld]   (B diag D) in MFMA B-fragment order
     double *ISp;        // [P][ld*ld]   C^-1/2   in MFMA B-fragment order
     double *S;          // [P][mu_pad]  whitened squared norms of the worst mu
+    double *csep;       // [P][ld] diagonal covariance of the separable variant (D = its sqrt)
     double *zn2;        // [P][lambda_pad] ||z||^2 of every candidate (cma_sample_eval128 only)
     double *gram_part;  // [P][splits][ld][ld]
     double *mean_part;  // [P][splits][ld]
@@ -117,7 +119,7 @@ private:
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;
 
-    DevBuf<double> zn2_;
+    DevBuf<double> zn2_, csep_;
     DevBuf<double> X_, f_, xmean_, xold_, pc_, ps_, C_, B_, D_, isc_, BDp_, ISp_, S_,
             gram_part_, mean_part_, hist_best_, hist_kth_, eig_work_, weights_, lower_,
             upper_, aux_, zinject_, zrecord_;

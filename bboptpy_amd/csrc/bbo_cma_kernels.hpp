@@ -1228,10 +1228,13 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
             for (int off = 32; off > 0; off >>= 1) eq += __shfl_xor(eq, off, 64);
             if (3 * eq >= n) flag = 3;
         }
+        const bool sep = c.variant == 2;   // SepCmaes: the same tests on _diagd (sep_cmaes.cpp:166-205)
         if (!flag) {   // TolX
             int bad = 0;
-            for (int i = lane; i < n; i += 64)
-                bad |= (fmax(pc[i], sqrt(C[(size_t) i * ld + i])) * sigma / c.sigma0 >= c.tol);
+            for (int i = lane; i < n; i += 64) {
+                const double sd = sep ? D[i] : sqrt(C[(size_t) i * ld + i]);
+                bad |= (fmax(pc[i], sd) * sigma / c.sigma0 >= c.tol);
+            }
             if (!__any(bad)) flag = 4;
         }
         if (!flag && sigma / c.sigma0 > 1.0e20 * D[n - 1]) flag = 5;
@@ -1239,14 +1242,20 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
         if (!flag) {   // NoEffectAxis
             const int iaxis = n - 1 - ((it - 1) % n);
             int moved = 0;
-            for (int i = lane; i < n; i += 64)
-                moved |= (xm[i] != xm[i] + 0.1 * sigma * D[iaxis] * B[(size_t) iaxis * ld + i]);
+            if (sep) {
+                moved = xm[iaxis] != xm[iaxis] + 0.1 * sigma * D[iaxis];
+            } else {
+                for (int i = lane; i < n; i += 64)
+                    moved |= (xm[i] != xm[i] + 0.1 * sigma * D[iaxis] * B[(size_t) iaxis * ld + i]);
+            }
             if (!__any(moved)) flag = 8;
         }
         if (!flag) {   // NoEffectCoor
             int stuck = 0;
-            for (int i = lane; i < n; i += 64)
-                stuck |= (xm[i] == xm[i] + 0.2 * sigma * sqrt(C[(size_t) i * ld + i]));
+            for (int i = lane; i < n; i += 64) {
+                const double sd = sep ? D[i] : sqrt(C[(size_t) i * ld + i]);
+                stuck |= (xm[i] == xm[i] + 0.2 * sigma * sd);
+            }
             if (__any(stuck)) flag = 9;
         }
     }

@@ -267,10 +267,22 @@ class ActiveCMAES(CMAES):
         self._params.alphacov = float(alphacov)
 
 
+class SepCMAES(BaseCMAES):
+    """SepCMAES(mfev, tol, np, sigma0=2., bound=False, adjustlr=False) -- :131-135
+    (diagonal covariance, Ros & Hansen 2008; sep_cmaes.cpp)"""
+    _algo = _ffi.ALGO_SEP_CMAES
+
+    def __init__(self, mfev, tol, np, sigma0=2., bound=False, adjustlr=False, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.tol, p.np = int(mfev), float(tol), int(np)
+        p.sigma0, p.bound, p.adjustlr = float(sigma0), int(bool(bound)), int(bool(adjustlr))
+
+
 class _RestartDriver(MultivariateSearch):
     def __init__(self, base, **ext):
         if not isinstance(base, BaseCMAES):
-            raise TypeError("base must be a CMA-ES optimizer (CMAES / ActiveCMAES)")
+            raise TypeError("base must be a CMA-ES optimizer (CMAES / ActiveCMAES / SepCMAES)")
         super().__init__(**ext)
         self._base = base   # kept alive here; the reference only borrows the pointer
 

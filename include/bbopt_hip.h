@@ -48,7 +48,8 @@ typedef enum {
     BBO_ALGO_JADE = 3,         /* JadeSearch   src/multivariate/de/jade.h:49          */
     BBO_ALGO_APSO = 4,         /* APSOSearch   src/multivariate/pso/apso.h:38         */
     BBO_ALGO_IPOP_CMAES = 5,   /* IPopCmaes    src/multivariate/cma/ipop_cmaes.h:55   */
-    BBO_ALGO_BIPOP_CMAES = 6   /* BiPopCmaes   src/multivariate/cma/bipop_cmaes.h:49  */
+    BBO_ALGO_BIPOP_CMAES = 6,  /* BiPopCmaes   src/multivariate/cma/bipop_cmaes.h:49  */
+    BBO_ALGO_SEP_CMAES = 7     /* SepCmaes     src/multivariate/cma/sep_cmaes.h:36    */
 } bbo_algo;
 
 /* Built-in objectives evaluated on the device (the reference ships none; id 1 is
@@ -100,7 +101,8 @@ typedef struct {
     double tol;            /* stop tolerance (meaning differs per family, SURVEY A-17) */
     int np;                /* population size: CMA `np` (lambda), JADE/APSO `np`, SHADE `npinit` */
     /* CMAES(mfev,tol,np,sigma0=2,bound=False,eigenrate=0.25)            :103-108
-     * ActiveCMAES(...,alphacov=2,eigenrate=0.25)                         :110-115 */
+     * ActiveCMAES(...,alphacov=2,eigenrate=0.25)                         :110-115
+     * SepCMAES(mfev,tol,np,sigma0=2,bound=False,adjustlr=False)          :131-135 */
     double sigma0;
     int bound;
     double alphacov;
@@ -134,6 +136,8 @@ typedef struct {
                               handle (>= 1); population p uses sub-stream p       */
     int poll_every;        /* generations between host polls of the device stop
                               flag inside bbo_optimize / bbo_run (default 8)      */
+    /* ---- appended in round 1 (SepCMAES): keeps the layout of everything above */
+    int adjustlr;          /* SepCmaes `adjustlr` (sep_cmaes.cpp:60-62)            */
 } bbo_params;
 
 void bbo_params_default(bbo_params *p, int algo);
