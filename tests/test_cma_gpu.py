@@ -204,6 +204,29 @@ def test_whitened_norm_shortcut_matches_gemm(hip):
     assert a.get_state("sigma")[0] == pytest.approx(b.get_state("sigma")[0], rel=1e-9)
 
 
+@pytest.mark.parametrize("variant", ["active", "cmaes"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_whole_run_same_seed_matches_oracle(hip, oracle_lib, variant, seed):
+    """The README configuration (n = 10, np = 20, Rosenbrock on [-10, 10]^10, tol = 1e-4) run to
+    its own stop on the device and by the oracle drawing the SAME Philox normals (same seed,
+    same counter layout -- the oracle itself is pinned bit for bit to the reference under
+    mt19937): same number of evaluations, same stop flag, the same x* to 1e-9, over ~350
+    generations of sample -> evaluate -> rank -> update -> eigendecomposition."""
+    n, lam = 10, 20
+    cls = hip.ActiveCMAES if variant == "active" else hip.CMAES
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(-10, 10, n)
+    g = cls(mfev=10000, tol=1e-4, np=lam, seed=seed)
+    sol = g.optimize(hip.objectives.rosenbrock, lo, up, guess)
+    o = po.cma(oracle_lib, variant, 10000, 1e-4, lam)
+    o.set_rng(po.RNG_PHILOX, seed)
+    xo, fevo, convo = o.optimize("rosenbrock", lo, up, guess)
+    assert sol.n_evals == fevo
+    assert sol.converged == convo
+    assert int(g.get_state("flag")[0]) == int(o.scalar("flag"))
+    np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-9)
+
+
 def test_optimize_readme_example(hip):
     """README.md:106-128: ActiveCMAES(mfev=10000, tol=1e-4, np=20) on 10-D Rosenbrock"""
     n = 10
