@@ -306,7 +306,7 @@ void CmaEngine::launch_sample_eval()
     bool zn_valid = false;
     timer_.begin(stream_, K_SAMPLE);
     if (c.variant == 2) {
-        // separable: 16 lanes per candidate while 16 rows fit LDS, else 64 lanes (4 rows)
+        // separable: 16 lanes per candidate for short rows, one wavefront per candidate beyond
         static bool attr_done = false;
         if (!attr_done) {
             BBO_HIP(hipFuncSetAttribute((const void*) sep_sample_eval<16>,
@@ -315,7 +315,7 @@ void CmaEngine::launch_sample_eval()
                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             attr_done = true;
         }
-        if (c.ld <= 1024) {
+        if (c.ld <= 256) {   // (beyond that the 16-row LDS tile would leave one workgroup per CU)
             const size_t lds = (size_t) 16 * c.ld * sizeof(double);
             hipLaunchKernelGGL(sep_sample_eval<16>, dim3((c.lambda_pad + 15) / 16, c.npop),
                     dim3(256), lds, stream_, d_, c_);

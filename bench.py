@@ -10,6 +10,7 @@ Workloads (BASELINE.json configs; `--workload`):
   C3  ActiveCMAES n=128 lambda=1024 Rosenbrock
   C2  L-SHADE     n=128 np=4096    Rastrigin
   C4  APSO        n=512 np=65536   Sphere
+  SEP SepCMAES    n=1024 lambda=4096 Ellipsoid       (the HBM-bound CMA variant)
 `--populations P` independent populations of that exact shape are advanced in lockstep on
 each GPU (population p uses Philox sub-stream p).  P = 1 is the strict single-run reading of
 the config; the JSON line always carries BOTH the aggregate over P (`value`) and a
@@ -41,6 +42,7 @@ WORKLOADS = {
     "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=256),
     "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=256),
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
+    "SEP": dict(algo="SepCMAES", n=1024, np=4096, objective="ellipsoid", box=(-5., 5.), P=64),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
     "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
@@ -113,9 +115,24 @@ def measured_traffic(workload, P, kernel):
     return float(sum(hits)) if hits else None
 
 
+def sep_kernel_costs(n, lam, P):
+    """SepCMAES: every kernel is a streaming pass (bbo_sep_kernels.hpp)"""
+    mu = lam // 2
+    return {
+        "cma_sample_eval": ("hbm", P * lam * (8 * n + 8)),     # X written once, f
+        "cma_rank": ("hbm", P * lam * 16),
+        "cma_gram": ("hbm", P * mu * 8 * n),                  # the selected rows, read once
+        "cma_paths": ("hbm", P * 8 * 12 * n),
+        "cma_history_stop": ("hbm", P * 8 * 4 * n),
+    }
+
+
 def make_optimizer(bb, wl, P, seed, device):
     huge = 2 ** 31 - 1
     a = wl["algo"]
+    if a == "SepCMAES":
+        return bb.SepCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
+                           populations=P)
     if a == "ActiveCMAES":
         # tol = 0: TolHistFun / TolX can never fire inside the timed region
         return bb.ActiveCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
@@ -206,6 +223,8 @@ def cpu_baseline(wl, budget_s=12.0):
     lib.seed(1)
     if a == "ActiveCMAES":
         h = po.cma(lib, "active", 2 ** 31 - 1, 0., lam)
+    elif a == "SepCMAES":
+        h = po.cma(lib, "sep", 2 ** 31 - 1, 0., lam)
     elif a == "SHADE":
         h = po.shade(lib, 2 ** 31 - 1, lam, 0., npmin=lam)
     elif a == "JADE":
@@ -278,6 +297,8 @@ def main():
         # per-kernel device time (HIP events on the engine's stream) -> roofline
         if wl["algo"] == "ActiveCMAES":
             names, costs = CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], P)
+        elif wl["algo"] == "SepCMAES":
+            names, costs = CMA_KERNELS, sep_kernel_costs(wl["n"], wl["np"], P)
         elif wl["algo"] in ("SHADE", "JADE"):
             names, costs = DE_KERNELS, de_kernel_costs(wl["n"], wl["np"], P)
         else:
@@ -287,6 +308,8 @@ def main():
             for i, name in enumerate(names):
                 ms, calls = prof[2 * i], prof[2 * i + 1]
                 if calls <= 0:
+                    continue
+                if name not in costs:
                     continue
                 bound, work = costs[name]
                 avg_s = ms * 1e-3 / calls
