@@ -360,6 +360,7 @@ void CmaEngine::launch_sample_eval()
             hipLaunchKernelGGL(cma_sample_eval64<1>, grid, dim3(256), lds, stream_, d_, c_);
         else
             hipLaunchKernelGGL(cma_sample_eval64<2>, grid, dim3(256), lds, stream_, d_, c_);
+        zn_valid = true;
     } else {
         dim3 grid(c.lambda_pad / 16, c.npop);
         const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);

@@ -199,17 +199,24 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
     const int ar = lane & 15, ak = lane >> 4;
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
+        double zz = 0.;
 #pragma unroll
         for (int t = 0; t < MAXT; t++) acc[mt][t] = d4_t { 0., 0., 0., 0. };
 #pragma unroll
         for (int ks = 0; ks < 32; ks++) {
             if (ks < KS) {
                 const double a = lds[(mt * 16 + ar) * ldz + 4 * ks + ak];
+                zz = __builtin_fma(a, a, zz);
 #pragma unroll
                 for (int t = 0; t < MAXT; t++)
                     acc[mt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfr[t][ks], acc[mt][t], 0, 0, 0);
             }
         }
+        // ||z||^2 of the 16 rows of this tile (by-product for the whitened-norm shortcut)
+        zz += __shfl_xor(zz, 16, 64);
+        zz += __shfl_xor(zz, 32, 64);
+        if (wave == 0 && ak == 0 && row0 + mt * 16 + ar < c.lambda_pad)
+            d.zn2[(size_t) p * c.lambda_pad + row0 + mt * 16 + ar] = zz;
     }
     __syncthreads();
 
@@ -440,6 +447,18 @@ __global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c.ld, ldz = ld + 2;
+    if (c.use_zn && sc->basis_ok) {
+        // sigma^2 ||z||^2 from the sampler stands in for the GEMM (see cma_whiten128)
+        if (tid < 16) {
+            const int wr = mt * 16 + tid;
+            if (wr < c.mu_pad)
+                d.S[(size_t) p * c.mu_pad + wr] = wr < c.mu
+                        ? sc->sigma * sc->sigma * d.zn2[(size_t) p * c.lambda_pad
+                                + d.order[(size_t) p * c.lambda_pad + c.lambda - c.mu + wr]]
+                        : 0.;
+        }
+        return;
+    }
     double *part = lds + 16 * ldz;   // [4][16]
     const double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
     const double *xold = d.xmean + (size_t) p * ld;   // the mean has not moved yet

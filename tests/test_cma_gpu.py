@@ -179,13 +179,14 @@ def test_many_population_sampling_matches_oracle(hip, oracle_lib, obj):
     assert not np.array_equal(g.get_state("arx", 0), g.get_state("arx", 1))
 
 
-def test_whitened_norm_shortcut_matches_gemm(hip):
+@pytest.mark.parametrize("n,lam,P", [(128, 4096, 8), (64, 256, 1), (37, 50, 2), (128, 1024, 1)])
+def test_whitened_norm_shortcut_matches_gemm(hip, n, lam, P):
     """Active CMA's negative-update coefficients need ||C^-1/2 (x - m)||^2 of the worst mu
     candidates.  With an unclamped x = m + sigma B D z and C^-1/2 from the same (B, D) that is
     sigma^2 ||z||^2, which the n = 128 sampling kernel hands over; bound=True (here with a box
     no sample reaches, so X is identical) disables the shortcut and takes the reference's GEMM.
-    Both must agree, and keep agreeing while C moves away from I."""
-    n, lam, P = 128, 4096, 8
+    Both must agree, and keep agreeing while C moves away from I (whole-population kernel,
+    64-row kernel, ragged shape)."""
     rng = np.random.default_rng(9)
     guess = rng.uniform(-3, 3, (P, n))
     lo, up = -1e6 * np.ones(n), 1e6 * np.ones(n)
