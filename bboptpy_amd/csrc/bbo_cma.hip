@@ -289,11 +289,19 @@ void CmaEngine::launch_post(int mode)
         const size_t lds = (size_t) (c.ld * (c.ld + 2) + c.ld) * sizeof(double);
         static bool attr_done = false;
         if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma,
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma<1>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma<4>,
                     hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
             attr_done = true;
         }
-        hipLaunchKernelGGL(cma_post_mfma, dim3(c.npop), dim3(256), lds, stream_, d_, c_, mode);
+        // few populations: four workgroups each (latency); many: one (no redundant staging)
+        if (c.npop < 32)
+            hipLaunchKernelGGL(cma_post_mfma<4>, dim3(c.npop, 4), dim3(256), lds, stream_, d_, c_,
+                    mode);
+        else
+            hipLaunchKernelGGL(cma_post_mfma<1>, dim3(c.npop, 1), dim3(256), lds, stream_, d_, c_,
+                    mode);
     } else {
         dim3 grid(c.ld / 16, c.ld / 16, c.npop);
         hipLaunchKernelGGL(cma_post, grid, dim3(256), 0, stream_, d_, c_, mode);

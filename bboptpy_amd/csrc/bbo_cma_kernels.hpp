@@ -1076,11 +1076,12 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
 }
 
 // ---------------------------------------------------------------------------
-// post for ld <= 128 on the matrix cores: one workgroup per population stages B in LDS,
-// C^-1/2 = (B diag(1/D)) B^T is 2 x NT tiles per wavefront (A fragment = B[i][k] / D[k], the
-// reference's own term order, cmaes.cpp:277; B fragment = the same rows of B unscaled), then
-// the two packed operands are written.  grid (P), 256 threads, dynamic LDS ld*(ld+2)+ld doubles
+// post for ld <= 128 on the matrix cores: NBW (1 or 4: few populations) workgroups per
+// population, each stages B in LDS and owns 8/NBW tile rows of C^-1/2 = (B diag(1/D)) B^T (A fragment = B[i][k] / D[k], the
+// reference's own term order, cmaes.cpp:277; B fragment = the same rows of B unscaled) and a
+// 1/NBW of the two packed operands.  grid (P, NBW), 256 threads, dynamic LDS ld*(ld+2)+ld doubles
 // ---------------------------------------------------------------------------
+template<int NBW>
 __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int mode)
 {
     const int p = blockIdx.x;
@@ -1119,41 +1120,42 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
 
     const int NT = ld >> 4, KS = ld >> 2;
     const int fr = lane & 15, fk = lane >> 4;
+    const int wb = blockIdx.y;            // workgroup wb of NBW: tile rows wb, wb + NBW, ...
+    constexpr int NR = 8 / NBW;           // tile rows per workgroup (NBW = 4: 2, NBW = 1: 8)
     if (mode != 2) {
-        d4_t acc[2][8];
+        // wavefront w: column tiles w, w + 4 of this workgroup's tile rows
+        d4_t acc[NR][2];
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int h = 0; h < NR; h++)
 #pragma unroll
-            for (int t = 0; t < 8; t++) acc[h][t] = d4_t { 0., 0., 0., 0. };
-        const bool has1 = wave + 4 < NT;
-        if (wave < NT) {
+            for (int u = 0; u < 2; u++) acc[h][u] = d4_t { 0., 0., 0., 0. };
+        const bool c1 = wave + 4 < NT;
+        if (wb < NT && wave < NT) {
             for (int ks = 0; ks < KS; ks++) {
                 const int k = 4 * ks + fk;
                 const double dk = Dv[k];
-                double f[8];
+                const double f0 = Bs[(wave * 16 + fr) * ldp + k];
+                const double f1 = c1 ? Bs[((wave + 4) * 16 + fr) * ldp + k] : 0.;
 #pragma unroll
-                for (int t = 0; t < 8; t++) f[t] = t < NT ? Bs[(t * 16 + fr) * ldp + k] : 0.;
-                const double a0 = Bs[(wave * 16 + fr) * ldp + k] / dk;
-                const double a1 = has1 ? Bs[((wave + 4) * 16 + fr) * ldp + k] / dk : 0.;
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    if (t < NT) {
-                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f[t], acc[0][t], 0, 0, 0);
-                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f[t], acc[1][t], 0, 0, 0);
-                    }
+                for (int h = 0; h < NR; h++) {
+                    const int ti = wb + NBW * h;
+                    const double a = ti < NT ? Bs[(ti * 16 + fr) * ldp + k] / dk : 0.;
+                    acc[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f0, acc[h][0], 0, 0, 0);
+                    acc[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, f1, acc[h][1], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int ti = wave + 4 * h;
+            for (int h = 0; h < NR; h++) {
+                const int ti = wb + NBW * h;
                 if (ti < NT) {
 #pragma unroll
-                    for (int t = 0; t < 8; t++) {
+                    for (int u = 0; u < 2; u++) {
+                        const int t = wave + 4 * u;
                         if (t < NT) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 const int i = ti * 16 + fk + 4 * r, j = t * 16 + fr;
-                                const double v = acc[h][t][r];   // 0 outside n: B is staged as 0 there
+                                const double v = acc[h][u][r];   // 0 outside n: B is staged as 0 there
                                 isc[(size_t) i * ld + j] = v;
                                 ISp[((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15)] = v;
                             }
@@ -1163,10 +1165,11 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
             }
         }
     }
-    if (mode != 2 && tid == 0) d.scal[p].basis_ok = 1;
+    if (mode != 2 && tid == 0 && wb == 0) d.scal[p].basis_ok = 1;
     // packed operands: element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
+    const int q0 = wb * (ld * ld / NBW), q1 = q0 + ld * ld / NBW;   // this workgroup's share
 #pragma unroll 4
-    for (int q = tid; q < ld * ld; q += 256) {
+    for (int q = q0 + tid; q < q1; q += 256) {
         const int t4 = q >> 6, l = q & 63;             // t4 = nt * KS + ks
         const int nt = t4 / KS, ks = t4 - nt * KS;
         const int i = nt * 16 + (l & 15), j = 4 * ks + (l >> 4);
@@ -1174,7 +1177,7 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
         BDp[q] = in ? Bs[i * ldp + j] * Dv[j] : 0.;
     }
     if (mode == 2) {
-        for (int q = tid; q < ld * ld; q += 256) {
+        for (int q = q0 + tid; q < q1; q += 256) {
             const int t4 = q >> 6, l = q & 63;
             const int nt = t4 / KS, ks = t4 - nt * KS;
             const int i = nt * 16 + (l & 15), j = 4 * ks + (l >> 4);

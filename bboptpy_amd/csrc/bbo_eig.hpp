@@ -40,7 +40,9 @@ struct EigPlan {
 constexpr int EIG_NVEC = 9;   // d, e, u, w, g, h, tdiag, uh0, uh1
 
 // one slab of the eigensolver's per-population global scratch ([work | Q_house | F | Q F])
-__host__ __device__ inline size_t eig_slab(int ld) { return (size_t) (ld + 32) * (ld + 32); }
+// (+ 72: keeps the per-population stride off large powers of two -- 256 workgroups walking
+// their slabs in step would otherwise land on the same L2 / HBM channels)
+__host__ __device__ inline size_t eig_slab(int ld) { return (size_t) (ld + 32) * (ld + 32) + 72; }
 
 inline EigPlan eig_plan(int n, int ld)
 {

@@ -123,9 +123,9 @@ __device__ inline double dc_quad_sum(double v)
 // walk through the same barriers).  Q (LDS) holds the blocks' eigenvectors on its diagonal
 // blocks (zeros elsewhere inside [a,b)^2), dv their eigenvalues, rho_in = e[mid-1].
 // Fg (global) is scratch for the eigenvector factor of this merge (m x m).
-template<int LPR>
+template<int LPR, bool do_gemm>
 __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
-        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps, bool do_gemm)
+        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps)
 {
 #define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a > 64) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
@@ -557,7 +557,7 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     DcWork W;
     {
         double *p = scratch;
-        const int M = ((n > 128 ? n : 128) + 2);
+        const int M = ext_top ? n + 2 : 130;
         W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
         W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
         W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
@@ -656,13 +656,15 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
         // (chosen from the WIDEST merge so that all teams run the same code path)
         int m = 0;
         for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
-        const bool gemm = !(ext_top && nc == 2);
-        if (4 * m <= tm.tthreads)
-            dc_merge_level<4>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
+        if (ext_top && nc == 2) {
+            // the top merge of a matrix wider than 128 (512 threads, m <= 256): scalar part only
+            dc_merge_level<2, false>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+        } else if (4 * m <= tm.tthreads)
+            dc_merge_level<4, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
         else if (2 * m <= tm.tthreads)
-            dc_merge_level<2>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
+            dc_merge_level<2, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
         else
-            dc_merge_level<1>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, gemm);
+            dc_merge_level<1, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
         int nxt[DC_MAXB + 1];
         int nn = 0;
         nxt[nn++] = cur[0];
