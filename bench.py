@@ -11,6 +11,9 @@ Workloads (BASELINE.json configs; `--workload`):
   C2  L-SHADE     n=128 np=4096    Rastrigin
   C4  APSO        n=512 np=65536   Sphere
   SEP SepCMAES    n=1024 lambda=4096 Ellipsoid       (the HBM-bound CMA variant)
+  C5  BIPOP-CMA-ES n=256 Rastrigin: world_size concurrent restart populations, one per GPU,
+      one RCCL all-gather of per-restart bests per round (bboptpy_amd.distributed); a "step" is
+      one restart ROUND and --steps bounds the evaluation budget (steps * 25 000 per rank)
 `--populations P` independent populations of that exact shape are advanced in lockstep on
 each GPU (population p uses Philox sub-stream p).  P = 1 is the strict single-run reading of
 the config; the JSON line always carries BOTH the aggregate over P (`value`) and a
@@ -247,12 +250,55 @@ def cpu_baseline(wl, budget_s=12.0):
                 gens, a, n, lam, wl["objective"], dt, note)}
 
 
+def bench_bipop(args, world, rank, local_rank, use_dist):
+    """C5: concurrent BIPOP over the ranks.  value = objective evaluations of ALL restarts of
+    ALL ranks per second of wall time (max over ranks); no single-kernel roofline applies (a
+    restart is a whole CMA-ES run, dominated by the n = 256 eigensolver at small lambda)."""
+    import bboptpy_amd as bb
+    from bboptpy_amd.distributed import ConcurrentBiPop
+    n = 256
+    lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
+    guess = np.random.default_rng(7).uniform(-5.12, 5.12, n)
+    budget = max(1, args.steps) * 25000 * world
+    drv = ConcurrentBiPop(mfev=budget, tol=1e-8, sigma0=2., seed=2024, device=local_rank,
+                          variant="active")
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sol = drv.optimize(bb.objectives.rastrigin, lo, up, guess)
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    st = drv.state
+    out = {
+        "metric": "candidate-evals/sec", "value": st.fev / dt, "unit": "candidate-evals/s",
+        "n_gpus": world, "steps": st.round, "warmup": 0,
+        "ms_per_step": 1e3 * dt / max(st.round, 1), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BIPOP-CMA-ES (ActiveCMAES inner) n=256 rastrigin, %d concurrent "
+                               "restart populations (one per GPU), budget %d evaluations"
+                               % (world, budget),
+                   "n": n, "objective": "rastrigin", "box": [-5.12, 5.12],
+                   "rounds": st.round, "large_restarts": st.largerestarts,
+                   "small_restarts": st.smallrestarts, "best_f": st.fxbest},
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)    # SURVEY 8d: >= 200 generations ...
     ap.add_argument("--warmup", type=int, default=20)   # ... after 20 warm-up generations
-    ap.add_argument("--workload", default="M", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="M", choices=sorted(WORKLOADS) + ["C5"])
     ap.add_argument("--populations", type=int, default=None,
                     help="independent populations per GPU (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,6 +326,12 @@ def main():
             torch.cuda.synchronize()
     import bboptpy_amd as bb
 
+    if args.workload == "C5":
+        bench_bipop(args, world, rank, local_rank, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     wl = WORKLOADS[args.workload]
     P = args.populations if args.populations else wl["P"]
     dt, prof, _, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
