@@ -134,25 +134,55 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     const int *order = d.order + pbase;
     const uint32_t sub = (uint32_t) p;
 
-    // ---- per-individual draws (lane 0 of the group), shade.cpp:105-131 / jade.cpp:107-133 --
+    // ---- per-individual draws, shade.cpp:105-131 / jade.cpp:107-133.  The draws of one
+    // individual are independent Philox calls, so the 16 lanes of its group make one each
+    // (lane 0 the normal for CR, lane 1 the parameter word, lane 2 the pbest word, lanes 3-6
+    // the first four Cauchy tries for F, 7-10 the first four tries for r1, 11-15 the first five
+    // for r2) instead of lane 0 walking through all of them; the group then picks the first
+    // admissible try exactly as the sequential rule does, and only falls back to a loop when
+    // all speculative tries were rejected ---------------------------------------------------
+    const uint32_t sw_param = stream_word(STREAM_DE_PARAM, sub);
+    double mine_d = 0.;        // lane 0: z0; lanes 3-6: Cauchy deviate * 0.1
+    uint32_t mine_x = 0, mine_y = 0, mine_z = 0, mine_w = 0;
+    if (live) {
+        if (g == 0) {
+            double z1;
+            normal_pair(c.seed, (uint32_t) i, 0, (uint32_t) gen, sw_param, mine_d, z1);
+        } else {
+            const uint32_t ctr = g == 1 ? 1u : g == 2 ? 2u : g <= 6 ? (uint32_t) (16 + g - 3)
+                    : g <= 10 ? (uint32_t) (96 + g - 7) : (uint32_t) (160 + g - 11);
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, ctr, (uint32_t) gen, sw_param);
+            mine_x = w.x; mine_y = w.y; mine_z = w.z; mine_w = w.w;
+            if (g >= 3 && g <= 6) mine_d = tan(DE_PI * (u01(w.x, w.y) - 0.5)) * 0.1;
+        }
+    }
+    const double z0 = __shfl(mine_d, 0, 16);
+    const uint32_t p1x = __shfl(mine_x, 1, 16), p1y = __shfl(mine_y, 1, 16),
+            p1z = __shfl(mine_z, 1, 16), p1w = __shfl(mine_w, 1, 16);
+    const uint32_t p2x = __shfl(mine_x, 2, 16);
     double CR = 0., F = 0.;
     int ibest = 0, r1 = 0, r2 = 0, jrand = 0;
-    if (live && g == 0) {
-        double z0, z1;
-        normal_pair(c.seed, (uint32_t) i, 0, (uint32_t) gen, stream_word(STREAM_DE_PARAM, sub),
-                z0, z1);
-        u32x4 w = philox4x32_10(c.seed, (uint32_t) i, 1, (uint32_t) gen,
-                stream_word(STREAM_DE_PARAM, sub));
-        const int ri = uint_below(w.x, c.h);
-        jrand = uint_below(w.y, n);
-        const double up = u01(w.z, w.w);
-        const double mcr = c.variant == 0 ? d.MCR[(size_t) p * c.h + ri] : sc->mucr;
-        const double mf = c.variant == 0 ? d.MF[(size_t) p * c.h + ri] : sc->muf;
+    {
+        const int ri = uint_below(p1x, c.h);
+        jrand = uint_below(p1y, n);
+        const double up = u01(p1z, p1w);
+        const double mcr = !live ? 0. : c.variant == 0 ? d.MCR[(size_t) p * c.h + ri] : sc->mucr;
+        const double mf = !live ? 0.5 : c.variant == 0 ? d.MF[(size_t) p * c.h + ri] : sc->muf;
         CR = fmax(0., fmin(z0 * 0.1 + mcr, 1.));
         bool got = false;
-        for (int t = 0; t < DE_MAX_TRIES && !got; t++) {
-            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (16 + t), (uint32_t) gen,
-                    stream_word(STREAM_DE_PARAM, sub));
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const double dev = __shfl(mine_d, 3 + t, 16);
+            const double Ft = fmin(1., dev + mf);
+            const bool ok = c.variant == 0 ? (Ft > 0.) : !(Ft < 0.);
+            if (!got && ok) {
+                F = Ft;
+                got = true;
+            }
+        }
+        for (int t = 4; t < DE_MAX_TRIES && !got && live; t++) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (16 + t), (uint32_t) gen,
+                    sw_param);
             F = fmin(1., tan(DE_PI * (u01(w.x, w.y) - 0.5)) * 0.1 + mf);
             got = c.variant == 0 ? (F > 0.) : !(F < 0.);
         }
@@ -165,40 +195,37 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
         } else {
             nelite = max(1, (int) (c.pelite * np));
         }
-        w = philox4x32_10(c.seed, (uint32_t) i, 2, (uint32_t) gen,
-                stream_word(STREAM_DE_PARAM, sub));
-        ibest = uint_below(w.x, nelite);
-        r1 = (i + 1) % np;
-        for (int t = 0; t < DE_MAX_TRIES; t++) {
-            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (96 + t), (uint32_t) gen,
-                    stream_word(STREAM_DE_PARAM, sub));
-            const int cnd = uint_below(w.x, np);
-            if (cnd != i) {
-                r1 = cnd;
-                break;
-            }
+        ibest = uint_below(p2x, nelite);
+        r1 = -1;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int cnd = uint_below(__shfl(mine_x, 7 + t, 16), np);
+            if (r1 < 0 && cnd != i) r1 = cnd;
         }
+        for (int t = 4; t < DE_MAX_TRIES && r1 < 0 && live; t++) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (96 + t), (uint32_t) gen,
+                    sw_param);
+            const int cnd = uint_below(w.x, np);
+            if (cnd != i) r1 = cnd;
+        }
+        if (r1 < 0) r1 = (i + 1) % max(np, 1);
         r2 = -1;
-        for (int t = 0; t < DE_MAX_TRIES; t++) {
-            w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (160 + t), (uint32_t) gen,
-                    stream_word(STREAM_DE_PARAM, sub));
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const int cnd = uint_below(__shfl(mine_x, 11 + t, 16), np + larch);
+            if (r2 < 0 && cnd != i && cnd != r1) r2 = cnd;
+        }
+        for (int t = 5; t < DE_MAX_TRIES && r2 < 0 && live; t++) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (160 + t), (uint32_t) gen,
+                    sw_param);
             const int cnd = uint_below(w.x, np + larch);
-            if (cnd != i && cnd != r1) {
-                r2 = cnd;
-                break;
-            }
+            if (cnd != i && cnd != r1) r2 = cnd;
         }
         if (r2 < 0) {
             r2 = 0;
             while (r2 == i || r2 == r1) r2++;
         }
     }
-    CR = __shfl(CR, 0, 16);
-    F = __shfl(F, 0, 16);
-    ibest = __shfl(ibest, 0, 16);
-    r1 = __shfl(r1, 0, 16);
-    r2 = __shfl(r2, 0, 16);
-    jrand = __shfl(jrand, 0, 16);
 
     // ---- mutation + binomial crossover + midpoint bound repair, into LDS ------------------
     double cnt = 0.;
