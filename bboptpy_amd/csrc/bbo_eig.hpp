@@ -184,6 +184,13 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
     }
 
     for (int i = n - 1; i > 0; i--) {
+        if ((tid >> 6) * 16 >= i) {
+            // this wavefront's 16 rows are finished (the active block is rows < i): it only
+            // keeps the two barriers of the step company and leaves the SIMD to the others
+            __syncthreads();
+            __syncthreads();
+            continue;
+        }
         __syncthreads();
         const double d0 = lane < i ? dv[lane] : 0.;
         const double d1 = lane + 64 < i ? dv[lane + 64] : 0.;
