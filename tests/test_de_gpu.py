@@ -107,3 +107,27 @@ def test_python_callback_objective(hip):
     sol = alg.optimize(f, -2 * np.ones(n), 2 * np.ones(n), np.zeros(n))
     assert np.abs(sol.x - 0.5).max() < 1e-3
     assert len(calls) == sol.n_evals
+
+
+@pytest.mark.parametrize("algo", ["shade", "jade"])
+@pytest.mark.parametrize("obj,seed", [("sphere", 1), ("ellipsoid", 2)])
+def test_whole_run_same_seed_matches_oracle(hip, oracle_lib, algo, obj, seed):
+    """optimize() to the algorithm's own stop (radius-spread test, L-SHADE's population
+    reduction on the way) on the device and by the generation-synchronous oracle drawing the same
+    Philox numbers: the same number of evaluations, the same x* (smooth objectives: on Rosenbrock
+    a last-bit difference in f flips a `<=` selection late in the run and the counts differ by
+    a few dozen evaluations, with the same optimum)."""
+    n = 10
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    if algo == "shade":
+        g = hip.SHADE(mfev=60000, npinit=40, tol=1e-8, seed=seed)
+        o = po.shade(oracle_lib, 60000, 40, 1e-8)
+    else:
+        g = hip.JADE(mfev=60000, np=30, tol=1e-8, seed=seed)
+        o = po.jade(oracle_lib, 60000, 30, 1e-8)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    sol = g.optimize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
+    xo, fevo, convo = o.optimize(obj, lo, up, np.zeros(n))
+    assert sol.converged and convo
+    assert sol.n_evals == fevo
+    np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-10)

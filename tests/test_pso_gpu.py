@@ -75,3 +75,19 @@ def test_apso_python_callback(hip):
     alg = hip.APSO(mfev=8000, tol=1e-7, np=20, seed=9)
     sol = alg.optimize(f, -4 * np.ones(n), 4 * np.ones(n), np.zeros(n))
     assert np.abs(sol.x + 1.0).max() < 0.05
+
+
+@pytest.mark.parametrize("obj,seed", [("rosenbrock", 1), ("rosenbrock", 2)])
+def test_whole_run_same_seed_matches_oracle(hip, oracle_lib, obj, seed):
+    """APSO run to its evaluation budget on the device and by the synchronous oracle with the
+    same Philox numbers: same evaluation count (incl. the elitist-learning extras), same best
+    point"""
+    n = 10
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    g = hip.APSO(mfev=60000, tol=1e-8, np=30, seed=seed)
+    sol = g.optimize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
+    o = po.apso(oracle_lib, 60000, 1e-8, 30)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    xo, fevo, convo = o.optimize(obj, lo, up, np.zeros(n))
+    assert sol.n_evals == fevo and sol.converged == convo
+    np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-8)
