@@ -235,6 +235,36 @@ def gen_sep_runs(R):
     dump("sep_runs.json", runs)
 
 
+SANSDE_KEYS = ("x", "f", "cr", "p", "fp", "crm", "crrec", "crdeltaf", "pns", "pnf", "fpns", "fpnf",
+               "fev", "it")
+
+
+def gen_sansde_runs(R):
+    """SaNSDESearch (sansde.cpp): generations and the adaptation counters"""
+    runs = []
+    n = 8
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    cases = [("rastrigin", 41, dict(mfev=8000, np_=16, tol=1e-9)),
+             ("rosenbrock", 42, dict(mfev=8000, np_=12, tol=1e-9, repaircr=False, crref=3,
+                                     pupdate=7, crupdate=5)),
+             ("sphere", 43, dict(mfev=8000, np_=10, tol=1e-9, pupdate=10, crupdate=4))]
+    for obj, seed, kw in cases:
+        R.seed(seed)
+        h = po.sansde(R, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        rec = {"params": kw, "n": n, "objective": obj, "seed": seed, "box": 5.,
+               "states": [{"gen": 0, **{k: hx(h.get(k)) for k in SANSDE_KEYS}}]}
+        for gen in range(1, 61):
+            h.iterate()
+            if gen in (1, 2, 5, 10, 25, 50, 60):
+                rec["states"].append({"gen": gen, **{k: hx(h.get(k)) for k in SANSDE_KEYS}})
+        x, fev, conv = h.solution()
+        rec["result"] = {"x": hx(x), "fev": fev, "converged": conv}
+        runs.append(rec)
+        h.destroy()
+    dump("sansde_runs.json", runs)
+
+
 def main():
     po.build_ref()
     R = po.reference()
@@ -243,7 +273,8 @@ def main():
                  "development container")
     only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
     gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
-            "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs}
+            "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs,
+            "sansde": gen_sansde_runs}
     for name, fn in gens.items():
         if only is None or only == name:
             fn(R)

@@ -71,7 +71,7 @@ class _Lib:
         f("cma_create").restype = C.c_void_p
         f("cma_create").argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                     C.c_int, C.c_double, C.c_double]
-        for alg in ("cma", "shade", "jade", "apso", "bipop", "ipop"):
+        for alg in ("cma", "shade", "jade", "sansde", "apso", "bipop", "ipop"):
             if not hasattr(L, p + alg + "_init"):
                 continue
             f(alg + "_init").argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
@@ -99,6 +99,10 @@ class _Lib:
                                          C.c_double, C.c_double, C.c_double]
             f("apso_create").restype = C.c_void_p
             f("apso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.c_int]
+            if hasattr(L, p + "sansde_create"):
+                f("sansde_create").restype = C.c_void_p
+                f("sansde_create").argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                               C.c_int, C.c_int]
             f("bipop_create").restype = C.c_void_p
             f("bipop_create").argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
                                           C.c_double, C.c_double]
@@ -229,8 +233,8 @@ class Handle:
         if self.alg in ("bipop", "ipop"):
             self.lib.f("restart_set_rng")(self.ptr, rng_mode, seed)
         else:
-            self.lib.f("pop_set_mode")(self.ptr, 1 if self.alg == "apso" else 0,
-                                        1 if sync else 0, rng_mode, seed)
+            kind = {"apso": 1, "sansde": 2}.get(self.alg, 0)
+            self.lib.f("pop_set_mode")(self.ptr, kind, 1 if sync else 0, rng_mode, seed)
 
     def destroy(self):
         if self.ptr:
@@ -257,6 +261,11 @@ def jade(lib, mfev, np_, tol, archive=True, repaircr=True, pelite=0.05, cdamp=0.
          sigma=0.07):
     return Handle(lib, "jade", lib.f("jade_create")(mfev, np_, tol, int(archive),
                                                      int(repaircr), pelite, cdamp, sigma))
+
+
+def sansde(lib, mfev, np_, tol, repaircr=True, crref=5, pupdate=50, crupdate=25):
+    return Handle(lib, "sansde", lib.f("sansde_create")(mfev, np_, tol, int(repaircr), crref,
+                                                         pupdate, crupdate))
 
 
 def apso(lib, mfev, tol, np_, correct=True):

@@ -35,6 +35,7 @@
 #include "multivariate/cma/sep_cmaes.h"
 #include "multivariate/de/shade.h"
 #include "multivariate/de/jade.h"
+#include "multivariate/de/sansde.h"
 #include "multivariate/pso/apso.h"
 
 #include "objectives.h"
@@ -278,6 +279,43 @@ struct JadeProbe: JadeSearch {
         if (k == "np") return put1(_np, out, cap);
         if (k == "fev") return put1(_fev, out, cap);
         if (k == "larch") return put1((double) _arch.size(), out, cap);
+        return -1;
+    }
+};
+
+struct SansdeProbe: SaNSDESearch {
+    using SaNSDESearch::SaNSDESearch;
+    int get(const std::string &k, double *out, int cap)
+    {
+        if (k == "x" || k == "f" || k == "cr") {
+            int m = 0;
+            for (const auto &q : _swarm) {
+                if (k == "x") {
+                    for (double v : q._x) {
+                        if (m < cap) out[m] = v;
+                        m++;
+                    }
+                } else {
+                    if (m < cap) out[m] = k == "f" ? q._f : q._cr;
+                    m++;
+                }
+            }
+            return m;
+        }
+        if (k == "np") return put1(_np, out, cap);
+        if (k == "fev") return put1(_fev, out, cap);
+        if (k == "it") return put1(_it, out, cap);
+        if (k == "p") return put1(_p, out, cap);
+        if (k == "fp") return put1(_fp, out, cap);
+        if (k == "crm") return put1(_crm, out, cap);
+        if (k == "crrec") return put1(_crrec, out, cap);
+        if (k == "crdeltaf") return put1(_crdeltaf, out, cap);
+        if (k == "pns" || k == "pnf") {
+            const auto &a = k == "pns" ? _pns : _pnf;
+            if (cap >= 2) { out[0] = a[0]; out[1] = a[1]; }
+            return 2;
+        }
+        if (k == "fpns" || k == "fpnf") return put(k == "fpns" ? _fpns : _fpnf, out, cap);
         return -1;
     }
 };
@@ -535,6 +573,10 @@ POP_API(jade, JadeProbe,
         (int mfev, int np, double tol, int archive, int repaircr, double pelite,
                 double cdamp, double sigma),
         (mfev, np, tol, archive != 0, repaircr != 0, pelite, cdamp, sigma))
+
+POP_API(sansde, SansdeProbe,
+        (int mfev, int np, double tol, int repaircr, int crref, int pupdate, int crupdate),
+        (mfev, np, tol, repaircr != 0, crref, pupdate, crupdate))
 
 POP_API(apso, ApsoProbe,
         (int mfev, double tol, int np, int correct),

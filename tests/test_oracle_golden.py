@@ -158,3 +158,26 @@ def test_sep_cma_trajectory(oracle_lib, idx):
     assert (gen, flag, fev, conv) == (res["generations"], res["flag"], res["fev"],
                                       res["converged"])
     np.testing.assert_array_equal(x, unhex(res["x"]))
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_sansde_generations(oracle_lib, idx):
+    """SaNSDESearch (sansde.cpp:58-300): swarm, per-individual CR, strategy / crossover /
+    mutation adaptation state at generations 0, 1, 2, 5, 10, 25, 50, 60, bit for bit against
+    the reference's run (tests/golden/sansde_runs.json)"""
+    rec = load("sansde_runs.json")[idx]
+    n, box = rec["n"], rec["box"]
+    oracle_lib.seed(rec["seed"])
+    h = po.sansde(oracle_lib, **rec["params"])
+    h.init(rec["objective"], -box * np.ones(n), box * np.ones(n), np.zeros(n))
+    gen = 0
+    for st in rec["states"]:
+        while gen < st["gen"]:
+            h.iterate()
+            gen += 1
+        for k, v in st.items():
+            if k != "gen":
+                np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="gen %d %s" % (gen, k))
+    x, fev, conv = h.solution()
+    np.testing.assert_array_equal(x, unhex(rec["result"]["x"]))
+    assert (fev, conv) == (rec["result"]["fev"], rec["result"]["converged"])

@@ -121,6 +121,32 @@ def test_de_pso_bit_exact(oracle_lib, ref_lib, algo, kw, keys, obj):
         assert (fo, co) == (fr, cr)
 
 
+@pytest.mark.parametrize("n,npp,obj,kw", [
+    (8, 16, "rastrigin", {}),
+    (13, 24, "rosenbrock", dict(repaircr=False, crref=3, pupdate=7, crupdate=5)),
+    (5, 10, "sphere", dict(pupdate=10, crupdate=4)),
+    (21, 40, "griewank", dict(crref=1))])
+def test_sansde_bit_exact(oracle_lib, ref_lib, n, npp, obj, kw):
+    """SaNSDESearch, every generation: swarm, per-individual CR and all adaptation counters"""
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    hs = []
+    for L in (oracle_lib, ref_lib):
+        L.seed(31)
+        h = po.sansde(L, 200000, npp, 1e-9, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        hs.append(h)
+    for it in range(200):
+        for h in hs:
+            h.iterate()
+        for k in ("x", "f", "cr", "p", "fp", "crm", "crrec", "crdeltaf", "pns", "pnf", "fpns",
+                  "fpnf", "fev", "it"):
+            np.testing.assert_array_equal(hs[0].get(k), hs[1].get(k),
+                                          err_msg="sansde n=%d it=%d %s" % (n, it, k))
+    (xa, fa, ca), (xb, fb, cb) = hs[0].solution(), hs[1].solution()
+    np.testing.assert_array_equal(xa, xb)
+    assert (fa, ca) == (fb, cb)
+
+
 @pytest.mark.parametrize("driver", ["bipop", "ipop"])
 @pytest.mark.parametrize("variant", ["active", "cmaes"])
 def test_restart_drivers_bit_exact(oracle_lib, ref_lib, driver, variant):
