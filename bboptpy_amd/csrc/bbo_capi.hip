@@ -93,6 +93,10 @@ void bbo_params_default(bbo_params *p, int algo)
     p->device = 0;
     p->populations = 1;
     p->poll_every = 8;
+    p->adjustlr = 0;
+    p->crref = 5;
+    p->pupdate = 50;
+    p->crupdate = 25;
 }
 
 int bbo_create(const bbo_params *params, bbo_handle *out)
@@ -114,6 +118,7 @@ int bbo_create(const bbo_params *params, bbo_handle *out)
             break;
         case BBO_ALGO_SHADE:
         case BBO_ALGO_JADE:
+        case BBO_ALGO_SANSDE:
             h->opt.reset(bbo::make_de_engine(*params));
             break;
         case BBO_ALGO_APSO:

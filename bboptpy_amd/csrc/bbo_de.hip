@@ -1,4 +1,4 @@
-// bbo_de.hip -- host side of the L-SHADE / JADE engine.
+// bbo_de.hip -- host side of the L-SHADE / JADE / SaNSDE engine.
 // Reference behaviour restated on the host: ShadeSearch::init/optimize/solution
 // (shade.cpp:56-94, :238-256), JadeSearch likewise (jade.cpp:64-96, :208-226).
 #include "bbo_de_kernels.hpp"
@@ -16,7 +16,11 @@ enum { K_GEN = 0, K_BOOK, K_ARCH, K_RANK, K_FINISH, K_SELECT, K_COUNT };
 DeEngine::DeEngine(const bbo_params &p) :
         params_(p)
 {
-    BBO_REQUIRE(p.algo == BBO_ALGO_SHADE || p.algo == BBO_ALGO_JADE, "DeEngine: bad algo");
+    BBO_REQUIRE(p.algo == BBO_ALGO_SHADE || p.algo == BBO_ALGO_JADE || p.algo == BBO_ALGO_SANSDE,
+            "DeEngine: bad algo");
+    if (p.algo == BBO_ALGO_SANSDE)
+        BBO_REQUIRE(p.crref >= 1 && p.pupdate >= 1 && p.crupdate >= 1,
+                "SANSDE: crref, pupdate, crupdate must be >= 1");
     BBO_REQUIRE(p.np >= 4, "DE needs a population of at least 4");
     BBO_REQUIRE(p.populations >= 1, "populations must be >= 1");
     if (p.algo == BBO_ALGO_SHADE) {
@@ -49,13 +53,16 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
     const int P = params_.populations;
     DeConst &c = c_;
     c = DeConst {};
-    c.variant = params_.algo == BBO_ALGO_JADE ? 1 : 0;
+    c.variant = params_.algo == BBO_ALGO_SANSDE ? 2 : params_.algo == BBO_ALGO_JADE ? 1 : 0;
+    c.ncrref = params_.crref;
+    c.npup = params_.pupdate;
+    c.ncrup = params_.crupdate;
     c.n = n;
     c.ld = round_up(n, 2);
     c.npinit = params_.np;
     c.npmin = c.variant == 0 ? params_.npmin : params_.np;
     c.h = c.variant == 0 ? params_.h : 1;
-    c.archive = params_.archive ? 1 : 0;
+    c.archive = (params_.archive && c.variant != 2) ? 1 : 0;   // SaNSDE has no archive
     c.repaircr = params_.repaircr ? 1 : 0;
     c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
     c.mfev = params_.mfev;
@@ -72,7 +79,9 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
     Xb_.alloc(rows * ld);
     fa_.alloc(rows);
     fb_.alloc(rows);
-    arch_.alloc(rows * ld);
+    arch_.alloc(c.variant == 2 ? 1 : rows * ld);
+    cra_.alloc(rows);
+    crb_.alloc(rows);
     MCR_.alloc((size_t) P * c.h);
     MF_.alloc((size_t) P * c.h);
     rec_cr_.alloc(rows);
@@ -107,6 +116,12 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
         s.np = c.npinit;
         s.k = 1;
         s.fev = c.npinit;   // the initial population is evaluated (shade.cpp:88-89)
+        s.sp = s.sfp = s.crm = 0.5;   // sansde.cpp:72-76
+    }
+    {
+        std::vector<double> half_rows(rows, 0.5);   // sansde.cpp:90: every _cr starts at 0.5
+        cra_.upload(half_rows.data(), rows);
+        crb_.upload(half_rows.data(), rows);
     }
     scal_.upload(sc.data(), P);
 
@@ -116,6 +131,7 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
     d.order = order_.p; d.rank = rank_.p; d.arch = arch_.p; d.MCR = MCR_.p; d.MF = MF_.p;
     d.rec_cr = rec_cr_.p; d.rec_f = rec_f_.p; d.rec_df = rec_df_.p; d.radius = radius_.p;
     d.rec_flag = rec_flag_.p; d.claim = claim_.p; d.slot_of = slot_of_.p;
+    d.crow[0] = cra_.p; d.crow[1] = crb_.p;
     d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
 
     np_host_ = c.npinit;
@@ -185,7 +201,10 @@ void DeEngine::generation(bool honor_stop)
     dim3 g16((np_host_ + 15) / 16, P);
     const size_t lds = (size_t) 16 * c.ld * sizeof(double);
     timer_.begin(stream_, K_GEN);
-    hipLaunchKernelGGL(de_generation, g16, dim3(256), lds, stream_, d_, c_);
+    if (c.variant == 2)
+        hipLaunchKernelGGL(sansde_generation, g16, dim3(256), lds, stream_, d_, c_);
+    else
+        hipLaunchKernelGGL(de_generation, g16, dim3(256), lds, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) {
@@ -196,7 +215,10 @@ void DeEngine::generation(bool honor_stop)
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_BOOK);
-    hipLaunchKernelGGL(de_bookkeep, dim3(P), dim3(1024), 0, stream_, d_, c_);
+    if (c.variant == 2)
+        hipLaunchKernelGGL(sansde_bookkeep, dim3(P), dim3(1024), 0, stream_, d_, c_);
+    else
+        hipLaunchKernelGGL(de_bookkeep, dim3(P), dim3(1024), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (c.archive) {
@@ -373,6 +395,29 @@ int DeEngine::get(const std::string &k, int p, double *out, int cap)
         }
         return s.np;
     }
+    if (k == "cr") {   // SaNSDE: per-individual CR in sorted order
+        if (out && cap >= s.np) {
+            std::vector<int> ord(s.np);
+            order_.download(ord.data(), s.np, pbase);
+            std::vector<double> crv(c.npinit);
+            (s.cur == 0 ? cra_ : crb_).download(crv.data(), c.npinit, pbase);
+            for (int i = 0; i < s.np; i++) out[i] = crv[ord[i]];
+        }
+        return s.np;
+    }
+    if (k == "pns" || k == "pnf" || k == "fpns" || k == "fpnf") {
+        if (out && cap >= 2)
+            for (int q = 0; q < 2; q++)
+                out[q] = k == "pns" ? s.pns[q] : k == "pnf" ? s.pnf[q] : k == "fpns" ? s.fpns[q]
+                                                                                     : s.fpnf[q];
+        return 2;
+    }
+    if (k == "p") return one(s.sp);
+    if (k == "fp") return one(s.sfp);
+    if (k == "crm") return one(s.crm);
+    if (k == "crrec") return one(s.crrec);
+    if (k == "crdeltaf") return one(s.crdeltaf);
+    if (k == "it") return one(s.gen);
     if (k == "k") return one(s.k);
     if (k == "np") return one(s.np);
     if (k == "fev") return one(s.fev);

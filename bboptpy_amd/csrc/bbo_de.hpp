@@ -1,4 +1,4 @@
-// bbo_de.hpp -- device-resident differential evolution: L-SHADE and JADE.
+// bbo_de.hpp -- device-resident differential evolution: L-SHADE, JADE and SaNSDE.
 //
 // Reference: ShadeSearch (src/multivariate/de/shade.cpp:56-298) and JadeSearch
 // (src/multivariate/de/jade.cpp:64-294).  The reference loops over the individuals one at a
@@ -25,10 +25,15 @@ struct DeScal {
     int cur;                 // which half of the double buffer holds the population
     int nsucc;               // successes of the last generation
     int pad_;
+    // SaNSDE adaptation state (sansde.cpp:70-80): strategy / mutation-kind probabilities, CR mean
+    double sp, sfp, crm, crrec, crdeltaf;
+    double fpns[2], fpnf[2];
+    int pns[2], pnf[2];
 };
 
 struct DeConst {
-    int variant;             // 0 = L-SHADE, 1 = JADE
+    int variant;             // 0 = L-SHADE, 1 = JADE, 2 = SaNSDE
+    int ncrref, npup, ncrup; // SaNSDE: generations between CR refresh / p update / CR-F update
     int n, ld;
     int npinit, npmin, h;
     int archive, repaircr;
@@ -48,7 +53,9 @@ struct DeDev {
     double *rec_cr, *rec_f, *rec_df, *radius;   // [P][npinit]
     int *rec_flag;           // [P][npinit] bit0 accepted, bit1 strictly better
     int *claim;              // [P][npinit] archive slot -> highest claiming individual (or -1)
-    int *slot_of;            // [P][npinit] individual -> archive slot it writes (or -1)
+    int *slot_of;            // [P][npinit] individual -> archive slot it writes (or -1);
+                             // SaNSDE: bit 0 = mutation strategy, bit 1 = F distribution of the trial
+    double *crow[2];         // SaNSDE [P][npinit] per-individual CR, double buffered like X
     const double *lower, *upper, *aux;
     DeScal *scal;
 };
@@ -83,6 +90,7 @@ private:
     int np_host_ = 0;        // upper bound of the device np (exact while no population stopped)
     long fev_host_ = 0;
     std::vector<double> aux_h_;
+    DevBuf<double> cra_, crb_;
     DevBuf<double> Xa_, Xb_, fa_, fb_, arch_, MCR_, MF_, rec_cr_, rec_f_, rec_df_, radius_,
             lower_, upper_, aux_;
     DevBuf<int> order_, rank_, rec_flag_, claim_, slot_of_;

@@ -310,6 +310,172 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     }
 }
 
+// ---------------------------------------------------------------------------
+// SaNSDE (sansde.cpp:96-211): the fused generation.  Per individual: CR (persistent, redrawn
+// every ncrref generations around crm), F from N(0.5, 0.3) or Cauchy(0, 1) by probability fp,
+// three distinct partners, DE/rand/1 or DE/current-to-best/2 by probability p, binomial
+// crossover (`<=`), midpoint repair, evaluation, replacement on strict improvement.
+// Generation-synchronous like de_generation (oracle: Sansde::iterate_sync).
+// grid (ceil(np/16), P), 256 threads; LDS 16 * ld doubles
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
+{
+    const int p = blockIdx.y;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r;
+    const int ld = c.ld, n = c.n, np = sc->np, gen = sc->gen, cur = sc->cur;
+    const bool live = i < np;
+    double *trial = lds + r * ld;
+    const size_t pbase = (size_t) p * c.npinit;
+    const double *Xc = d.X[cur] + pbase * ld;
+    double *Xn = d.X[cur ^ 1] + pbase * ld;
+    const double *fc = d.f[cur] + pbase;
+    const int *order = d.order + pbase;
+    const uint32_t sw = stream_word(STREAM_DE_PARAM, (uint32_t) p);
+
+    double CR = 0., F = 0.5;
+    int strat = 0, r1 = 0, r2 = 0, r3 = 0, jrand = 0;
+    if (live && g == 0) {
+        CR = d.crow[cur][pbase + order[i]];
+        if (gen % c.ncrref == 0) {
+            double z0, z1;
+            normal_pair(c.seed, (uint32_t) i, 0, (uint32_t) gen, sw, z0, z1);
+            CR = fmax(0., fmin(z0 * 0.1 + sc->crm, 1.));
+        }
+        u32x4 w = philox4x32_10(c.seed, (uint32_t) i, 1, (uint32_t) gen, sw);
+        const int ifstrat = u01(w.x, w.y) < sc->sfp ? 0 : 1;
+        const int istrat = u01(w.z, w.w) < sc->sp ? 0 : 1;
+        strat = istrat | (ifstrat << 1);
+        bool got = false;
+        for (int t = 0; t < DE_MAX_TRIES && !got; t++) {
+            if (ifstrat == 0) {
+                double z0, z1;
+                normal_pair(c.seed, (uint32_t) i, (uint32_t) (16 + t), (uint32_t) gen, sw, z0, z1);
+                F = z0 * 0.3 + 0.5;
+            } else {
+                w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (16 + t), (uint32_t) gen, sw);
+                F = tan(DE_PI * (u01(w.x, w.y) - 0.5));
+            }
+            F = fmin(F, 1.);
+            got = !(F < 0.);
+        }
+        if (!got) F = 0.5;
+        int rr[3] = { -1, -1, -1 };
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            for (int t = 0; t < DE_MAX_TRIES && rr[q] < 0; t++) {
+                w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (96 + 64 * q + t),
+                        (uint32_t) gen, sw);
+                const int cnd = uint_below(w.x, np);
+                if (cnd != i && cnd != rr[0] && cnd != rr[1]) rr[q] = cnd;
+            }
+            for (int cnd = 0; rr[q] < 0; cnd++)
+                if (cnd != i && cnd != rr[0] && cnd != rr[1]) rr[q] = cnd;
+        }
+        r1 = rr[0];
+        r2 = rr[1];
+        r3 = rr[2];
+        w = philox4x32_10(c.seed, (uint32_t) i, 2, (uint32_t) gen, sw);
+        jrand = uint_below(w.x, n);
+    }
+    CR = __shfl(CR, 0, 16);
+    F = __shfl(F, 0, 16);
+    strat = __shfl(strat, 0, 16);
+    r1 = __shfl(r1, 0, 16);
+    r2 = __shfl(r2, 0, 16);
+    r3 = __shfl(r3, 0, 16);
+    jrand = __shfl(jrand, 0, 16);
+
+    double cnt = 0.;
+    if (live) {
+        const double *xi = Xc + (size_t) order[i] * ld;
+        const double *xb = Xc + (size_t) order[0] * ld;
+        const double *x1 = Xc + (size_t) order[r1] * ld;
+        const double *x2 = Xc + (size_t) order[r2] * ld;
+        const double *x3 = Xc + (size_t) order[r3] * ld;
+        const bool rand1 = (strat & 1) == 0;
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const int j = 2 * pj;
+            const double2 a = *reinterpret_cast<const double2*>(&xi[j]);
+            const double2 q1 = *reinterpret_cast<const double2*>(&x1[j]);
+            const double2 q2 = *reinterpret_cast<const double2*>(&x2[j]);
+            double2 m;
+            if (rand1) {
+                const double2 q3 = *reinterpret_cast<const double2*>(&x3[j]);
+                m.x = q1.x + F * (q2.x - q3.x);
+                m.y = q1.y + F * (q2.y - q3.y);
+            } else {
+                const double2 b = *reinterpret_cast<const double2*>(&xb[j]);
+                m.x = a.x + F * (b.x - a.x) + F * (q1.x - q2.x);
+                m.y = a.y + F * (b.y - a.y) + F * (q1.y - q2.y);
+            }
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen,
+                    stream_word(STREAM_DE_CROSS, (uint32_t) p));
+            double2 v = a;
+            if (j < n && (u01(w.x, w.y) <= CR || j == jrand)) {
+                v.x = m.x;
+                cnt += 1.;
+            }
+            if (j + 1 < n && (u01(w.z, w.w) <= CR || j + 1 == jrand)) {
+                v.y = m.y;
+                cnt += 1.;
+            }
+            if (j < n) {
+                if (v.x < d.lower[j]) v.x = (d.lower[j] + a.x) / 2.;
+                else if (v.x > d.upper[j]) v.x = (d.upper[j] + a.x) / 2.;
+            }
+            if (j + 1 < n) {
+                if (v.y < d.lower[j + 1]) v.y = (d.lower[j + 1] + a.y) / 2.;
+                else if (v.y > d.upper[j + 1]) v.y = (d.upper[j + 1] + a.y) / 2.;
+            }
+            *reinterpret_cast<double2*>(&trial[j]) = v;
+        }
+    }
+    __syncthreads();
+    cnt = group_sum_d<16>(cnt);
+    if (live && g == 0) {
+        d.crow[cur ^ 1][pbase + i] = CR;
+        d.rec_cr[pbase + i] = c.repaircr ? cnt / n : CR;
+        d.rec_f[pbase + i] = F;
+        d.slot_of[pbase + i] = strat;
+    }
+    if (c.obj < 0) {
+        // host objective: park the trial in the other buffer; de_select finishes the job
+        if (live)
+            for (int pj = g; pj < ld / 2; pj += 16)
+                *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + 2 * pj]) =
+                        *reinterpret_cast<const double2*>(&trial[2 * pj]);
+        return;
+    }
+    double ft = eval_row_group<16>(c.obj, n, trial, d.aux, g);
+    if (ft != ft) ft = BBO_INF_D;
+    double ssq = 0.;
+    bool accept = false;
+    double fold = 0.;
+    if (live) {
+        const double *xi = Xc + (size_t) order[i] * ld;
+        fold = fc[order[i]];
+        accept = ft < fold;
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const int j = 2 * pj;
+            const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j])
+                                     : *reinterpret_cast<const double2*>(&xi[j]);
+            *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + j]) = v;
+            ssq += v.x * v.x + v.y * v.y;
+        }
+    }
+    ssq = group_sum_d<16>(ssq);
+    if (live && g == 0) {
+        d.f[cur ^ 1][pbase + i] = accept ? ft : fold;
+        d.radius[pbase + i] = sqrt(ssq);
+        d.rec_df[pbase + i] = fold - ft;
+        d.rec_flag[pbase + i] = accept ? 3 : 0;
+    }
+}
+
 // host-objective path: the trials sit in X[cur^1], their fitness in f[cur^1]; finish the
 // selection (same arithmetic as the tail of de_generation)
 __global__ __launch_bounds__(256) void de_select(DeDev d, DeConst c)
@@ -332,7 +498,7 @@ __global__ __launch_bounds__(256) void de_select(DeDev d, DeConst c)
         fold = d.f[cur][pbase + row];
         ft = d.f[cur ^ 1][pbase + i];
         if (ft != ft) ft = BBO_INF_D;
-        accept = ft <= fold;
+        accept = c.variant == 2 ? ft < fold : ft <= fold;   // SaNSDE replaces on `<` (sansde.cpp:164)
         for (int pj = g; pj < ld / 2; pj += 16) {
             const int j = 2 * pj;
             double2 v = *reinterpret_cast<const double2*>(&Xn[(size_t) i * ld + j]);
@@ -490,6 +656,74 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
         if (c.archive) {
             int tot = carry;
             sc->larch = min(np, larch0 + tot);
+        }
+    }
+}
+
+// SaNSDE bookkeeping (sansde.cpp:166-183, :213-234): success / failure tallies per strategy
+// and per F distribution, the CR record, then the periodic re-estimation of p, crm, fp.
+// one workgroup of 1024 threads per population
+__global__ __launch_bounds__(1024) void sansde_bookkeep(DeDev d, DeConst c)
+{
+    const int p = blockIdx.x;
+    DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    __shared__ double scratch[16];
+    const int tid = threadIdx.x;
+    const int np = sc->np;
+    const size_t pbase = (size_t) p * c.npinit;
+    const int *flag = d.rec_flag + pbase, *strat = d.slot_of + pbase;
+    const double *cr = d.rec_cr + pbase, *ff = d.rec_f + pbase, *df = d.rec_df + pbase;
+    double ns[2] = { 0., 0. }, nf[2] = { 0., 0. }, fs[2] = { 0., 0. }, ffl[2] = { 0., 0. };
+    double rec = 0., del = 0.;
+    for (int i = tid; i < np; i += 1024) {
+        const int is = strat[i] & 1, fi = (strat[i] >> 1) & 1;
+        if (flag[i] & 1) {
+            ns[is] += 1.;
+            fs[fi] += ff[i];
+            rec += cr[i] * df[i];
+            del += df[i];
+        } else {
+            nf[is] += 1.;
+            ffl[fi] += ff[i];
+        }
+    }
+    double tot[10];
+    tot[0] = block_sum_1024(ns[0], scratch);
+    tot[1] = block_sum_1024(ns[1], scratch);
+    tot[2] = block_sum_1024(nf[0], scratch);
+    tot[3] = block_sum_1024(nf[1], scratch);
+    tot[4] = block_sum_1024(fs[0], scratch);
+    tot[5] = block_sum_1024(fs[1], scratch);
+    tot[6] = block_sum_1024(ffl[0], scratch);
+    tot[7] = block_sum_1024(ffl[1], scratch);
+    tot[8] = block_sum_1024(rec, scratch);
+    tot[9] = block_sum_1024(del, scratch);
+    if (tid == 0) {
+        sc->pns[0] += (int) tot[0];
+        sc->pns[1] += (int) tot[1];
+        sc->pnf[0] += (int) tot[2];
+        sc->pnf[1] += (int) tot[3];
+        sc->fpns[0] += tot[4];
+        sc->fpns[1] += tot[5];
+        sc->fpnf[0] += tot[6];
+        sc->fpnf[1] += tot[7];
+        sc->crrec += tot[8];
+        sc->crdeltaf += tot[9];
+        sc->nsucc = (int) (tot[0] + tot[1]);
+        sc->fev += np;
+        const int it = sc->gen + 1;     // de_finish commits gen + 1 afterwards
+        if (it % c.npup == 0) {
+            const int pnsf0 = sc->pns[0] + sc->pnf[0], pnsf1 = sc->pns[1] + sc->pnf[1];
+            sc->sp = (1. * sc->pns[0] * pnsf1) / (sc->pns[1] * pnsf0 + sc->pns[0] * pnsf1);
+            sc->pns[0] = sc->pns[1] = sc->pnf[0] = sc->pnf[1] = 0;
+        }
+        if (it % c.ncrup == 0) {
+            if (sc->crdeltaf > 0) sc->crm = sc->crrec / sc->crdeltaf;
+            sc->crrec = sc->crdeltaf = 0.;
+            const double f0 = sc->fpns[0] + sc->fpnf[0], f1 = sc->fpns[1] + sc->fpnf[1];
+            sc->sfp = (1. * sc->fpns[0] * f1) / (sc->fpns[1] * f0 + sc->fpns[0] * f1);
+            sc->fpns[0] = sc->fpns[1] = sc->fpnf[0] = sc->fpnf[1] = 0.;
         }
     }
 }

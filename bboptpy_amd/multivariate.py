@@ -347,6 +347,19 @@ class SHADE(MultivariateSearch):
             h), int(npmin)
 
 
+class SANSDE(MultivariateSearch):
+    """SANSDE(mfev, np, tol, repaircr=True, crref=5, pupdate=50, crupdate=25) -- :174-177
+    (self-adaptive DE with neighbourhood search, Yang et al. 2008; sansde.cpp)"""
+    _algo = _ffi.ALGO_SANSDE
+
+    def __init__(self, mfev, np, tol, repaircr=True, crref=5, pupdate=50, crupdate=25, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.np, p.tol = int(mfev), int(np), float(tol)
+        p.repaircr = int(bool(repaircr))
+        p.crref, p.pupdate, p.crupdate = int(crref), int(pupdate), int(crupdate)
+
+
 class APSO(MultivariateSearch):
     """APSO(mfev, tol, np, correct=True) -- :265-269"""
     _algo = _ffi.ALGO_APSO

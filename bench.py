@@ -46,6 +46,7 @@ WORKLOADS = {
     "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=256),
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "SEP": dict(algo="SepCMAES", n=1024, np=4096, objective="ellipsoid", box=(-5., 5.), P=64),
+    "SANSDE": dict(algo="SANSDE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
     "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
@@ -144,6 +145,8 @@ def make_optimizer(bb, wl, P, seed, device):
         # npmin = npinit: population-size reduction off, steady-state throughput
         return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
                         device=device, populations=P)
+    if a == "SANSDE":
+        return bb.SANSDE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
     if a == "JADE":
         return bb.JADE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
     if a == "APSO":
@@ -232,6 +235,8 @@ def cpu_baseline(wl, budget_s=12.0):
         h = po.shade(lib, 2 ** 31 - 1, lam, 0., npmin=lam)
     elif a == "JADE":
         h = po.jade(lib, 2 ** 31 - 1, lam, 0.)
+    elif a == "SANSDE":
+        h = po.sansde(lib, 2 ** 31 - 1, lam, 0.)
     else:
         h = po.apso(lib, 2 ** 31 - 1, 0., lam)
     h.init(wl["objective"], lo, up, guess)
@@ -351,8 +356,10 @@ def main():
             names, costs = CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], P)
         elif wl["algo"] == "SepCMAES":
             names, costs = CMA_KERNELS, sep_kernel_costs(wl["n"], wl["np"], P)
-        elif wl["algo"] in ("SHADE", "JADE"):
+        elif wl["algo"] in ("SHADE", "JADE", "SANSDE"):
             names, costs = DE_KERNELS, de_kernel_costs(wl["n"], wl["np"], P)
+            if wl["algo"] == "SANSDE":   # x_i, best, three partners read, one row written
+                costs["de_generation"] = ("hbm", P * wl["np"] * (48 * wl["n"] + 24))
         else:
             names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
         kernels = {}

@@ -49,7 +49,8 @@ typedef enum {
     BBO_ALGO_APSO = 4,         /* APSOSearch   src/multivariate/pso/apso.h:38         */
     BBO_ALGO_IPOP_CMAES = 5,   /* IPopCmaes    src/multivariate/cma/ipop_cmaes.h:55   */
     BBO_ALGO_BIPOP_CMAES = 6,  /* BiPopCmaes   src/multivariate/cma/bipop_cmaes.h:49  */
-    BBO_ALGO_SEP_CMAES = 7     /* SepCmaes     src/multivariate/cma/sep_cmaes.h:36    */
+    BBO_ALGO_SEP_CMAES = 7,    /* SepCmaes     src/multivariate/cma/sep_cmaes.h:36    */
+    BBO_ALGO_SANSDE = 8        /* SaNSDESearch src/multivariate/de/sansde.h:40        */
 } bbo_algo;
 
 /* Built-in objectives evaluated on the device (the reference ships none; id 1 is
@@ -138,6 +139,10 @@ typedef struct {
                               flag inside bbo_optimize / bbo_run (default 8)      */
     /* ---- appended in round 1 (SepCMAES): keeps the layout of everything above */
     int adjustlr;          /* SepCmaes `adjustlr` (sep_cmaes.cpp:60-62)            */
+    /* SANSDE(mfev,np,tol,repaircr=True,crref=5,pupdate=50,crupdate=25)  :174-177 */
+    int crref;             /* generations between redraws of the per-individual CR */
+    int pupdate;           /* generations between updates of the strategy probability */
+    int crupdate;          /* generations between updates of the CR mean and of fp */
 } bbo_params;
 
 void bbo_params_default(bbo_params *p, int algo);

@@ -19,10 +19,12 @@ def _make(hip, algo, P, seed):
         return hip.SHADE(mfev=10 ** 8, npinit=32, tol=1e-12, seed=seed, populations=P)
     if algo == "jade":
         return hip.JADE(mfev=10 ** 8, np=32, tol=1e-12, seed=seed, populations=P)
+    if algo == "sansde":
+        return hip.SANSDE(mfev=10 ** 8, np=32, tol=1e-12, seed=seed, populations=P)
     return hip.APSO(mfev=10 ** 8, tol=1e-12, np=32, seed=seed, populations=P)
 
 
-@pytest.mark.parametrize("algo", ["active", "cmaes", "sep", "shade", "jade", "apso"])
+@pytest.mark.parametrize("algo", ["active", "cmaes", "sep", "shade", "jade", "sansde", "apso"])
 def test_population_zero_is_the_single_run(hip, algo):
     n, P, seed, gens = 12, 5, 77, 30
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
