@@ -265,6 +265,33 @@ def gen_sansde_runs(R):
     dump("sansde_runs.json", runs)
 
 
+def gen_cso_runs(R):
+    """CSOSearch (cso.cpp): swarm, velocities, means after generations 1, 2, 5, 20, 40"""
+    runs = []
+    n = 6
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    cases = [("rastrigin", 51, dict(mfev=10 ** 7, stol=1e-9, np_=12)),
+             ("rosenbrock", 52, dict(mfev=10 ** 7, stol=1e-9, np_=13, pcompete=2)),
+             ("sphere", 53, dict(mfev=10 ** 7, stol=1e-9, np_=20, pcompete=4, ring=True)),
+             ("ackley", 54, dict(mfev=10 ** 7, stol=1e-9, np_=150, pcompete=2, ring=True,
+                                 correct=False, vmax=0.1))]
+    for obj, seed, kw in cases:
+        R.seed(seed)
+        h = po.cso(R, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        keys = ["x", "v", "f", "mean", "meanw", "xbest", "fbest", "fev"] + \
+            (["pmean", "home"] if kw.get("ring") else [])
+        rec = {"params": kw, "n": n, "objective": obj, "seed": seed, "box": 5., "keys": keys,
+               "phil": hx(h.get("phil")), "phih": hx(h.get("phih")), "states": []}
+        for gen in range(1, 41):
+            h.iterate()
+            if gen in (1, 2, 5, 20, 40):
+                rec["states"].append({"gen": gen, **{k: hx(h.get(k)) for k in keys}})
+        runs.append(rec)
+        h.destroy()
+    dump("cso_runs.json", runs)
+
+
 def main():
     po.build_ref()
     R = po.reference()
@@ -274,7 +301,7 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
     gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
             "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs,
-            "sansde": gen_sansde_runs}
+            "sansde": gen_sansde_runs, "cso": gen_cso_runs}
     for name, fn in gens.items():
         if only is None or only == name:
             fn(R)

@@ -37,6 +37,7 @@
 #include "multivariate/de/jade.h"
 #include "multivariate/de/sansde.h"
 #include "multivariate/pso/apso.h"
+#include "multivariate/pso/cso.h"
 
 #include "objectives.h"
 
@@ -320,6 +321,43 @@ struct SansdeProbe: SaNSDESearch {
     }
 };
 
+struct CsoProbe: CSOSearch {
+    using CSOSearch::CSOSearch;
+    int get(const std::string &k, double *out, int cap)
+    {
+        if (k == "x" || k == "v" || k == "pmean" || k == "f" || k == "home") {
+            int m = 0;
+            for (const auto &q : _swarm) {
+                if (k == "f") {
+                    if (m < cap) out[m] = q._f;
+                    m++;
+                } else if (k == "home") {
+                    /* birth slot, recovered from the stored neighbour pointer */
+                    const int right = _ring ? (int) (q._right - &_swarm[0]) : 0;
+                    if (m < cap) out[m] = _ring ? (double) ((right - 1 + _np) % _np) : -1.;
+                    m++;
+                } else {
+                    const auto &src = k == "x" ? q._x : k == "v" ? q._v : q._mean;
+                    for (double v : src) {
+                        if (m < cap) out[m] = v;
+                        m++;
+                    }
+                }
+            }
+            return m;
+        }
+        if (k == "mean") return put(_mean, out, cap);
+        if (k == "meanw") return put(_meanw, out, cap);
+        if (k == "phil") return put(_phil, out, cap);
+        if (k == "phih") return put(_phih, out, cap);
+        if (k == "xbest") return put(_best->_x, out, cap);
+        if (k == "fbest") return put1(_best->_f, out, cap);
+        if (k == "np") return put1(_np, out, cap);
+        if (k == "fev") return put1(_fev, out, cap);
+        return -1;
+    }
+};
+
 struct ApsoProbe: APSOSearch {
     using APSOSearch::APSOSearch;
     int get(const std::string &k, double *out, int cap)
@@ -577,6 +615,10 @@ POP_API(jade, JadeProbe,
 POP_API(sansde, SansdeProbe,
         (int mfev, int np, double tol, int repaircr, int crref, int pupdate, int crupdate),
         (mfev, np, tol, repaircr != 0, crref, pupdate, crupdate))
+
+POP_API(cso, CsoProbe,
+        (int mfev, double stol, int np, int pcompete, int ring, int correct, double vmax),
+        (mfev, stol, np, pcompete, ring != 0, correct != 0, vmax))
 
 POP_API(apso, ApsoProbe,
         (int mfev, double tol, int np, int correct),

@@ -181,3 +181,24 @@ def test_sansde_generations(oracle_lib, idx):
     x, fev, conv = h.solution()
     np.testing.assert_array_equal(x, unhex(rec["result"]["x"]))
     assert (fev, conv) == (rec["result"]["fev"], rec["result"]["converged"])
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_cso_generations(oracle_lib, idx):
+    """CSOSearch (cso.cpp:67-276), incl. the libstdc++ std::shuffle it calls and the
+    birth-slot ring neighbourhood its stored pointers amount to: swarm, velocities, means and
+    incumbent at generations 1, 2, 5, 20, 40, bit for bit (tests/golden/cso_runs.json)"""
+    rec = load("cso_runs.json")[idx]
+    n, box = rec["n"], rec["box"]
+    oracle_lib.seed(rec["seed"])
+    h = po.cso(oracle_lib, **rec["params"])
+    h.init(rec["objective"], -box * np.ones(n), box * np.ones(n), np.zeros(n))
+    np.testing.assert_array_equal(h.get("phil"), unhex(rec["phil"]))
+    np.testing.assert_array_equal(h.get("phih"), unhex(rec["phih"]))
+    gen = 0
+    for st in rec["states"]:
+        while gen < st["gen"]:
+            h.iterate()
+            gen += 1
+        for k in rec["keys"]:
+            np.testing.assert_array_equal(h.get(k), unhex(st[k]), err_msg="gen %d %s" % (gen, k))

@@ -147,6 +147,31 @@ def test_sansde_bit_exact(oracle_lib, ref_lib, n, npp, obj, kw):
     assert (fa, ca) == (fb, cb)
 
 
+@pytest.mark.parametrize("n,npp,obj,kw", [
+    (8, 12, "rastrigin", {}),
+    (8, 13, "rosenbrock", dict(pcompete=2)),
+    (5, 30, "sphere", dict(pcompete=4, ring=True)),
+    (11, 200, "ackley", dict(pcompete=2, ring=True, correct=False, vmax=0.1)),
+    (6, 500, "sphere", dict(pcompete=5)),
+    (4, 70000, "sphere", dict(pcompete=2))])      # np^2 > 2^32: one swap per draw in std::shuffle
+def test_cso_bit_exact(oracle_lib, ref_lib, n, npp, obj, kw):
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    hs = []
+    for L in (oracle_lib, ref_lib):
+        L.seed(57)
+        h = po.cso(L, 10 ** 8, 1e-9, npp, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        hs.append(h)
+    keys = ["x", "v", "f", "mean", "meanw", "xbest", "fbest", "fev", "phil", "phih"] + \
+        (["pmean", "home"] if kw.get("ring") else [])
+    for it in range(3 if npp > 10000 else 40):
+        for h in hs:
+            h.iterate()
+        for k in keys:
+            np.testing.assert_array_equal(hs[0].get(k), hs[1].get(k),
+                                          err_msg="cso n=%d it=%d %s" % (n, it, k))
+
+
 @pytest.mark.parametrize("driver", ["bipop", "ipop"])
 @pytest.mark.parametrize("variant", ["active", "cmaes"])
 def test_restart_drivers_bit_exact(oracle_lib, ref_lib, driver, variant):
