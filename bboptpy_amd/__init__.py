@@ -9,8 +9,8 @@ from . import objectives
 from .objectives import vectorized
 from .multivariate import (MultivariateSolution, MultivariateSearch, BaseCMAES, CMAES,
                            ActiveCMAES, SepCMAES, IPopCMAES, BiPopCMAES, JADE, SHADE,
-                           SANSDE, APSO)
+                           SANSDE, APSO, CSO)
 
 __all__ = ["MultivariateSolution", "MultivariateSearch", "BaseCMAES", "CMAES", "ActiveCMAES",
-           "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "SANSDE", "APSO", "objectives",
+           "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "SANSDE", "APSO", "CSO", "objectives",
            "vectorized"]

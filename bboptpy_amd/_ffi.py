@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libbbopt_hip.so")
 
 # bbo_algo
 ALGO_CMAES, ALGO_ACTIVE_CMAES, ALGO_SHADE, ALGO_JADE, ALGO_APSO, ALGO_IPOP, ALGO_BIPOP, \
-    ALGO_SEP_CMAES, ALGO_SANSDE = range(9)
+    ALGO_SEP_CMAES, ALGO_SANSDE, ALGO_CSO = range(10)
 # bbo_objective_kind
 OBJ_BUILTIN, OBJ_SCALAR_CB, OBJ_BATCH_CB = 0, 1, 2
 # bbo_cma_phase
@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("seed", C.c_uint64), ("device", C.c_int), ("populations", C.c_int),
         ("poll_every", C.c_int), ("adjustlr", C.c_int),
         ("crref", C.c_int), ("pupdate", C.c_int), ("crupdate", C.c_int),
+        ("pcompete", C.c_int), ("ring", C.c_int), ("vmax", C.c_double),
     ]
 
 

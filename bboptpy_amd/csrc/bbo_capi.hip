@@ -9,6 +9,7 @@
 namespace bbo {
 Optimizer* make_de_engine(const bbo_params &p);       // bbo_de.hip
 Optimizer* make_pso_engine(const bbo_params &p);      // bbo_pso.hip
+Optimizer* make_cso_engine(const bbo_params &p);      // bbo_cso.hip
 Optimizer* make_restart_driver(const bbo_params &p, Optimizer *base);   // bbo_restart.hip
 }
 
@@ -97,6 +98,9 @@ void bbo_params_default(bbo_params *p, int algo)
     p->crref = 5;
     p->pupdate = 50;
     p->crupdate = 25;
+    p->pcompete = 3;
+    p->ring = 0;
+    p->vmax = 0.2;
 }
 
 int bbo_create(const bbo_params *params, bbo_handle *out)
@@ -123,6 +127,9 @@ int bbo_create(const bbo_params *params, bbo_handle *out)
             break;
         case BBO_ALGO_APSO:
             h->opt.reset(bbo::make_pso_engine(*params));
+            break;
+        case BBO_ALGO_CSO:
+            h->opt.reset(bbo::make_cso_engine(*params));
             break;
         default:
             throw bbo::Error(BBO_ERR_ARG,

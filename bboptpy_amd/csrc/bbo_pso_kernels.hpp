@@ -163,7 +163,15 @@ __global__ __launch_bounds__(256) void pso_center(PsoDev d, PsoConst c, int part
     const int r0 = part * rows_per, r1 = min(c.np, r0 + rows_per);
     for (int j = threadIdx.x; j < c.ld; j += 256) {
         double s = 0.;
-        for (int i = r0; i < r1; i++) s += d.X[((size_t) p * c.np + i) * c.ld + j];
+        int i = r0;
+        for (; i + 8 <= r1; i += 8) {          // eight independent row reads in flight
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = d.X[((size_t) p * c.np + i + u) * c.ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += x[u];
+        }
+        for (; i < r1; i++) s += d.X[((size_t) p * c.np + i) * c.ld + j];
         d.colpart[((size_t) p * parts + part) * c.ld + j] = s;
     }
 }
@@ -175,7 +183,15 @@ __global__ __launch_bounds__(256) void pso_mean(PsoDev d, PsoConst c, int parts)
     if (pso_frozen(c, sc)) return;
     for (int j = threadIdx.x; j < c.ld; j += 256) {
         double s = 0.;
-        for (int q = 0; q < parts; q++) s += d.colpart[((size_t) p * parts + q) * c.ld + j];
+        int q = 0;
+        for (; q + 8 <= parts; q += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = d.colpart[((size_t) p * parts + q + u) * c.ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += x[u];
+        }
+        for (; q < parts; q++) s += d.colpart[((size_t) p * parts + q) * c.ld + j];
         d.mean[(size_t) p * c.ld + j] = s / c.np;
     }
 }

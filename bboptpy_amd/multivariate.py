@@ -360,6 +360,19 @@ class SANSDE(MultivariateSearch):
         p.crref, p.pupdate, p.crupdate = int(crref), int(pupdate), int(crupdate)
 
 
+class CSO(MultivariateSearch):
+    """CSO(mfev, stol, np, pcompete=3, ring=False, correct=True, vmax=0.2) -- :272-275
+    (competitive swarm optimizer, Cheng & Jin 2015; cso.cpp)"""
+    _algo = _ffi.ALGO_CSO
+
+    def __init__(self, mfev, stol, np, pcompete=3, ring=False, correct=True, vmax=0.2, **ext):
+        super().__init__(**ext)
+        p = self._params
+        p.mfev, p.tol, p.np = int(mfev), float(stol), int(np)
+        p.pcompete, p.ring = int(pcompete), int(bool(ring))
+        p.correct, p.vmax = int(bool(correct)), float(vmax)
+
+
 class APSO(MultivariateSearch):
     """APSO(mfev, tol, np, correct=True) -- :265-269"""
     _algo = _ffi.ALGO_APSO

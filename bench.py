@@ -47,6 +47,7 @@ WORKLOADS = {
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "SEP": dict(algo="SepCMAES", n=1024, np=4096, objective="ellipsoid", box=(-5., 5.), P=64),
     "SANSDE": dict(algo="SANSDE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
+    "CSO": dict(algo="CSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=4),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
     "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
@@ -56,6 +57,19 @@ CMA_KERNELS = ["cma_sample_eval", "cma_rank", "cma_whiten", "cma_gram", "cma_pat
 DE_KERNELS = ["de_generation", "de_bookkeep", "de_archive_copy", "de_rank", "de_finish",
               "de_select"]
 PSO_KERNELS = ["pso_center", "pso_ese", "pso_control", "pso_update", "pso_finish"]
+CSO_KERNELS = ["cso_mean", "cso_shuffle", "cso_groups", "cso_compete", "cso_finish"]
+
+
+def cso_kernel_costs(n, np_, P, pc=3):
+    """CSO (bbo_cso_kernels.hpp): streaming passes; the learning step moves np (pc-1)/pc losers"""
+    losers = np_ * (pc - 1) // pc
+    return {
+        "cso_mean": ("hbm", P * np_ * 8 * n),
+        "cso_shuffle": ("hbm", P * np_ * 24),
+        "cso_groups": ("hbm", P * (np_ * 16 + (np_ // pc) * 8 * n)),
+        "cso_compete": ("hbm", P * losers * (48 * n + 8)),
+        "cso_finish": ("hbm", P * np_ * 20),
+    }
 
 
 def de_kernel_costs(n, np_, P):
@@ -145,6 +159,8 @@ def make_optimizer(bb, wl, P, seed, device):
         # npmin = npinit: population-size reduction off, steady-state throughput
         return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
                         device=device, populations=P)
+    if a == "CSO":
+        return bb.CSO(mfev=huge, stol=0., np=wl["np"], seed=seed, device=device, populations=P)
     if a == "SANSDE":
         return bb.SANSDE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
     if a == "JADE":
@@ -165,6 +181,7 @@ def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
         assert alg.run(warmup) == warmup
     if profile:
         alg.set_state("profile", [1.0])
+    fev0 = alg.get_state("fev")[0]
     if barrier:
         barrier()
     t0 = time.perf_counter()
@@ -175,7 +192,9 @@ def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
     assert done == steps, "a population stopped inside the timed region (%d of %d)" % (done,
                                                                                        steps)
     prof = alg.get_state("profile") if profile else None
-    fev = alg.get_state("fev")[0]
+    # objective evaluations of ONE population inside the timed region (np per generation for
+    # CMA / DE; CSO evaluates its losers only, APSO adds its elitist-learning probes)
+    fev = alg.get_state("fev")[0] - fev0
     return dt, prof, fev, alg
 
 
@@ -237,6 +256,8 @@ def cpu_baseline(wl, budget_s=12.0):
         h = po.jade(lib, 2 ** 31 - 1, lam, 0.)
     elif a == "SANSDE":
         h = po.sansde(lib, 2 ** 31 - 1, lam, 0.)
+    elif a == "CSO":
+        h = po.cso(lib, 2 ** 31 - 1, 0., lam)
     else:
         h = po.apso(lib, 2 ** 31 - 1, 0., lam)
     h.init(wl["objective"], lo, up, guess)
@@ -339,14 +360,14 @@ def main():
         return
     wl = WORKLOADS[args.workload]
     P = args.populations if args.populations else wl["P"]
-    dt, prof, _, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
-                             profile=True, barrier=barrier)
+    dt, prof, fev_pop, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
+                                   profile=True, barrier=barrier)
     if use_dist:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_evals = world * P * wl["np"] * args.steps
+    total_evals = world * P * fev_pop
     value = total_evals / dt
 
     out = None
@@ -360,6 +381,8 @@ def main():
             names, costs = DE_KERNELS, de_kernel_costs(wl["n"], wl["np"], P)
             if wl["algo"] == "SANSDE":   # x_i, best, three partners read, one row written
                 costs["de_generation"] = ("hbm", P * wl["np"] * (48 * wl["n"] + 24))
+        elif wl["algo"] == "CSO":
+            names, costs = CSO_KERNELS, cso_kernel_costs(wl["n"], wl["np"], P)
         else:
             names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
         kernels = {}
@@ -397,10 +420,9 @@ def main():
                         "avg_us": kd["avg_us"], "time_share": kd["share"]}
         single = None
         if P != 1 and world == 1 and not args.no_single:
-            dt1, _, _, _ = measure(bb, wl, 1, max(10, args.steps // 2), 5, 77, local_rank,
-                                   profile=False)
             s1 = max(10, args.steps // 2)
-            single = {"value": wl["np"] * s1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
+            dt1, _, fev1, _ = measure(bb, wl, 1, s1, 5, 77, local_rank, profile=False)
+            single = {"value": fev1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
                       "unit": "candidate-evals/s"}
         conv = None
         if (world == 1 and wl["algo"] == "ActiveCMAES" and not args.no_convergence

@@ -50,7 +50,8 @@ typedef enum {
     BBO_ALGO_IPOP_CMAES = 5,   /* IPopCmaes    src/multivariate/cma/ipop_cmaes.h:55   */
     BBO_ALGO_BIPOP_CMAES = 6,  /* BiPopCmaes   src/multivariate/cma/bipop_cmaes.h:49  */
     BBO_ALGO_SEP_CMAES = 7,    /* SepCmaes     src/multivariate/cma/sep_cmaes.h:36    */
-    BBO_ALGO_SANSDE = 8        /* SaNSDESearch src/multivariate/de/sansde.h:40        */
+    BBO_ALGO_SANSDE = 8,       /* SaNSDESearch src/multivariate/de/sansde.h:40        */
+    BBO_ALGO_CSO = 9           /* CSOSearch    src/multivariate/pso/cso.h:44          */
 } bbo_algo;
 
 /* Built-in objectives evaluated on the device (the reference ships none; id 1 is
@@ -143,6 +144,11 @@ typedef struct {
     int crref;             /* generations between redraws of the per-individual CR */
     int pupdate;           /* generations between updates of the strategy probability */
     int crupdate;          /* generations between updates of the CR mean and of fp */
+    /* CSO(mfev,stol,np,pcompete=3,ring=False,correct=True,vmax=0.2)     :272-275
+     * (`stol` travels in `tol`, `correct` is shared with APSO) */
+    int pcompete;          /* particles per competition                            */
+    int ring;              /* ring neighbourhood instead of the swarm mean         */
+    double vmax;           /* velocity clamp as a fraction of the box width        */
 } bbo_params;
 
 void bbo_params_default(bbo_params *p, int algo);
