@@ -127,6 +127,11 @@ def measured_traffic(workload, P, kernel):
         return None
     # the timer slot is named after the phase; the launched kernel may be a shape-specific
     # variant of it (cma_sample_eval -> cma_sample_eval128, pso_ese -> pso_ese_sym + _finish)
+    alias = {"SEP": {"cma_sample_eval": "sep_sample_eval", "cma_gram": "sep_moments",
+                     "cma_paths": "sep_paths"},
+             "SANSDE": {"de_generation": "sansde_generation", "de_bookkeep": "sansde_bookkeep"},
+             "CSO": {"cso_mean": "cso_colsum"}}.get(workload, {})
+    kernel = alias.get(kernel, kernel)
     hits = [v.get("hbm_bytes_per_launch") for k, v in e.get("kernels", {}).items()
             if k == kernel or k.startswith(kernel)]
     hits = [h for h in hits if h is not None]
