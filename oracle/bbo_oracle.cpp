@@ -36,6 +36,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <stdexcept>
 #include <vector>
 
 #include "objectives.h"

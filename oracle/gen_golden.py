@@ -292,6 +292,33 @@ def gen_cso_runs(R):
     dump("cso_runs.json", runs)
 
 
+CCPSO_KEYS = ("x", "y", "yhat", "fx", "fy", "k", "ibest", "strat", "fyhat", "phat", "fev", "is",
+              "nswarm", "cpswarm", "improved")
+
+
+def gen_ccpso_runs(R):
+    """CCPSOSearch (ccpso.cpp), no local optimizer: state after generations 1, 2, 5, 20, 40.
+    (the reference prints _fyhat to stdout every generation: expect noise while this runs)"""
+    runs = []
+    cases = [(12, "rastrigin", 61, dict(mfev=10 ** 8, stol=1e-9, np_=8, pps=[2, 3, 6])),
+             (20, "rosenbrock", 62, dict(mfev=10 ** 8, stol=1e-9, np_=10, pps=[5, 10],
+                                         correct=False)),
+             (16, "sphere", 63, dict(mfev=10 ** 8, stol=1e-9, np_=6, pps=[1, 2, 4, 8, 16]))]
+    for n, obj, seed, kw in cases:
+        R.seed(seed)
+        lo, up = -5. * np.ones(n), 5. * np.ones(n)
+        h = po.ccpso(R, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        rec = {"params": kw, "n": n, "objective": obj, "seed": seed, "box": 5., "states": []}
+        for gen in range(1, 41):
+            h.iterate()
+            if gen in (1, 2, 5, 20, 40):
+                rec["states"].append({"gen": gen, **{k: hx(h.get(k)) for k in CCPSO_KEYS}})
+        runs.append(rec)
+        h.destroy()
+    dump("ccpso_runs.json", runs)
+
+
 def main():
     po.build_ref()
     R = po.reference()
@@ -301,7 +328,7 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
     gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
             "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs,
-            "sansde": gen_sansde_runs, "cso": gen_cso_runs}
+            "sansde": gen_sansde_runs, "cso": gen_cso_runs, "ccpso": gen_ccpso_runs}
     for name, fn in gens.items():
         if only is None or only == name:
             fn(R)

@@ -71,7 +71,7 @@ class _Lib:
         f("cma_create").restype = C.c_void_p
         f("cma_create").argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                     C.c_int, C.c_double, C.c_double]
-        for alg in ("cma", "shade", "jade", "sansde", "cso", "apso", "bipop", "ipop"):
+        for alg in ("cma", "shade", "jade", "sansde", "cso", "ccpso", "apso", "bipop", "ipop"):
             if not hasattr(L, p + alg + "_init"):
                 continue
             f(alg + "_init").argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
@@ -99,6 +99,10 @@ class _Lib:
                                          C.c_double, C.c_double, C.c_double]
             f("apso_create").restype = C.c_void_p
             f("apso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.c_int]
+            if hasattr(L, p + "ccpso_create"):
+                f("ccpso_create").restype = C.c_void_p
+                f("ccpso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int),
+                                              C.c_int, C.c_int, C.c_double]
             if hasattr(L, p + "cso_create"):
                 f("cso_create").restype = C.c_void_p
                 f("cso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
@@ -237,7 +241,7 @@ class Handle:
         if self.alg in ("bipop", "ipop"):
             self.lib.f("restart_set_rng")(self.ptr, rng_mode, seed)
         else:
-            kind = {"apso": 1, "sansde": 2, "cso": 3}.get(self.alg, 0)
+            kind = {"apso": 1, "sansde": 2, "cso": 3, "ccpso": 4}.get(self.alg, 0)
             self.lib.f("pop_set_mode")(self.ptr, kind, 1 if sync else 0, rng_mode, seed)
 
     def destroy(self):
@@ -275,6 +279,12 @@ def sansde(lib, mfev, np_, tol, repaircr=True, crref=5, pupdate=50, crupdate=25)
 def cso(lib, mfev, stol, np_, pcompete=3, ring=False, correct=True, vmax=0.2):
     return Handle(lib, "cso", lib.f("cso_create")(mfev, stol, np_, pcompete, int(ring),
                                                    int(correct), vmax))
+
+
+def ccpso(lib, mfev, stol, np_, pps, correct=True, pcauchy=-1.):
+    arr = (C.c_int * len(pps))(*[int(v) for v in pps])
+    return Handle(lib, "ccpso", lib.f("ccpso_create")(mfev, stol, np_, arr, len(pps),
+                                                       int(correct), pcauchy))
 
 
 def apso(lib, mfev, tol, np_, correct=True):

@@ -38,6 +38,7 @@
 #include "multivariate/de/sansde.h"
 #include "multivariate/pso/apso.h"
 #include "multivariate/pso/cso.h"
+#include "multivariate/pso/ccpso.h"
 
 #include "objectives.h"
 
@@ -358,6 +359,49 @@ struct CsoProbe: CSOSearch {
     }
 };
 
+struct CcpsoProbe: CCPSOSearch {
+    using CCPSOSearch::CCPSOSearch;
+    int get(const std::string &k, double *out, int cap)
+    {
+        auto flat = [&](const std::vector<std::vector<double>> &m) {
+            int q = 0;
+            for (const auto &row : m)
+                for (double v : row) {
+                    if (q < cap) out[q] = v;
+                    q++;
+                }
+            return q;
+        };
+        auto flati = [&](const std::vector<std::vector<int>> &m) {
+            int q = 0;
+            for (const auto &row : m)
+                for (int v : row) {
+                    if (q < cap) out[q] = v;
+                    q++;
+                }
+            return q;
+        };
+        if (k == "x") return flat(_X);
+        if (k == "y") return flat(_Y);
+        if (k == "yhat") return put(_yhat, out, cap);
+        if (k == "fx") return flat(_fX);
+        if (k == "fy") return flat(_fY);
+        if (k == "k") return flati(_k);
+        if (k == "ibest") return flati(_ibest);
+        if (k == "strat") return flati(_strat);
+        if (k == "fyhat") return put1(_fyhat, out, cap);
+        if (k == "phat") return put1(_phat, out, cap);
+        if (k == "fev") return put1(_fev, out, cap);
+        if (k == "it") return put1(_gen, out, cap);
+        if (k == "is") return put1(_is, out, cap);
+        if (k == "nswarm") return put1(_nswarm, out, cap);
+        if (k == "cpswarm") return put1(_cpswarm, out, cap);
+        if (k == "improved") return put1(_improved ? 1 : 0, out, cap);
+        if (k == "np") return put1(_np, out, cap);
+        return -1;
+    }
+};
+
 struct ApsoProbe: APSOSearch {
     using APSOSearch::APSOSearch;
     int get(const std::string &k, double *out, int cap)
@@ -619,6 +663,10 @@ POP_API(sansde, SansdeProbe,
 POP_API(cso, CsoProbe,
         (int mfev, double stol, int np, int pcompete, int ring, int correct, double vmax),
         (mfev, stol, np, pcompete, ring != 0, correct != 0, vmax))
+
+POP_API(ccpso, CcpsoProbe,
+        (int mfev, double stol, int np, const int *pps, int npps, int correct, double pcauchy),
+        (mfev, stol, np, const_cast<int*>(pps), npps, correct != 0, pcauchy, nullptr, 10))
 
 POP_API(apso, ApsoProbe,
         (int mfev, double tol, int np, int correct),

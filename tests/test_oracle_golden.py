@@ -202,3 +202,24 @@ def test_cso_generations(oracle_lib, idx):
             gen += 1
         for k in rec["keys"]:
             np.testing.assert_array_equal(h.get(k), unhex(st[k]), err_msg="gen %d %s" % (gen, k))
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_ccpso_generations(oracle_lib, idx):
+    """CCPSOSearch (ccpso.cpp:66-371, no local optimizer): random regrouping (std::shuffle),
+    context-vector evaluations, personal / ring / global bests with the reference's stale-fY
+    and last-particle-wins rules, Cauchy / normal resampling and the adaptive Cauchy rate, at
+    generations 1, 2, 5, 20, 40, bit for bit (tests/golden/ccpso_runs.json)"""
+    rec = load("ccpso_runs.json")[idx]
+    n, box = rec["n"], rec["box"]
+    oracle_lib.seed(rec["seed"])
+    h = po.ccpso(oracle_lib, **rec["params"])
+    h.init(rec["objective"], -box * np.ones(n), box * np.ones(n), np.zeros(n))
+    gen = 0
+    for st in rec["states"]:
+        while gen < st["gen"]:
+            h.iterate()
+            gen += 1
+        for k, v in st.items():
+            if k != "gen":
+                np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="gen %d %s" % (gen, k))

@@ -172,6 +172,29 @@ def test_cso_bit_exact(oracle_lib, ref_lib, n, npp, obj, kw):
                                           err_msg="cso n=%d it=%d %s" % (n, it, k))
 
 
+@pytest.mark.parametrize("n,npp,obj,pps,kw", [
+    (12, 8, "rastrigin", [2, 3, 6], {}),
+    (20, 10, "rosenbrock", [5, 10], dict(correct=False)),
+    (30, 12, "ackley", [5], {}),
+    (64, 20, "ellipsoid", [4, 8, 16, 32], {})])
+def test_ccpso_bit_exact(oracle_lib, ref_lib, capfd, n, npp, obj, pps, kw):
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    hs = []
+    for L in (oracle_lib, ref_lib):
+        L.seed(91)
+        h = po.ccpso(L, 10 ** 8, 1e-9, npp, pps, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        hs.append(h)
+    for it in range(40):
+        for h in hs:
+            h.iterate()
+        for k in ("x", "y", "yhat", "fx", "fy", "k", "ibest", "strat", "fyhat", "phat", "fev", "is",
+                  "nswarm", "cpswarm", "improved"):
+            np.testing.assert_array_equal(hs[0].get(k), hs[1].get(k),
+                                          err_msg="ccpso n=%d it=%d %s" % (n, it, k))
+    capfd.readouterr()      # the reference prints _fyhat every generation (ccpso.cpp:121)
+
+
 @pytest.mark.parametrize("driver", ["bipop", "ipop"])
 @pytest.mark.parametrize("variant", ["active", "cmaes"])
 def test_restart_drivers_bit_exact(oracle_lib, ref_lib, driver, variant):
