@@ -9,8 +9,8 @@ from . import objectives
 from .objectives import vectorized
 from .multivariate import (MultivariateSolution, MultivariateSearch, BaseCMAES, CMAES,
                            ActiveCMAES, SepCMAES, IPopCMAES, BiPopCMAES, JADE, SHADE,
-                           SANSDE, APSO, CSO)
+                           SANSDE, APSO, CSO, CCPSO)
 
 __all__ = ["MultivariateSolution", "MultivariateSearch", "BaseCMAES", "CMAES", "ActiveCMAES",
-           "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "SANSDE", "APSO", "CSO", "objectives",
+           "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE", "SANSDE", "APSO", "CSO", "CCPSO", "objectives",
            "vectorized"]

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libbbopt_hip.so")
 
 # bbo_algo
 ALGO_CMAES, ALGO_ACTIVE_CMAES, ALGO_SHADE, ALGO_JADE, ALGO_APSO, ALGO_IPOP, ALGO_BIPOP, \
-    ALGO_SEP_CMAES, ALGO_SANSDE, ALGO_CSO = range(10)
+    ALGO_SEP_CMAES, ALGO_SANSDE, ALGO_CSO, ALGO_CCPSO = range(11)
 # bbo_objective_kind
 OBJ_BUILTIN, OBJ_SCALAR_CB, OBJ_BATCH_CB = 0, 1, 2
 # bbo_cma_phase
@@ -42,6 +42,7 @@ class Params(C.Structure):
         ("poll_every", C.c_int), ("adjustlr", C.c_int),
         ("crref", C.c_int), ("pupdate", C.c_int), ("crupdate", C.c_int),
         ("pcompete", C.c_int), ("ring", C.c_int), ("vmax", C.c_double),
+        ("npps", C.c_int), ("pps", C.c_int * 16), ("pcauchy", C.c_double),
     ]
 
 

@@ -10,6 +10,7 @@ namespace bbo {
 Optimizer* make_de_engine(const bbo_params &p);       // bbo_de.hip
 Optimizer* make_pso_engine(const bbo_params &p);      // bbo_pso.hip
 Optimizer* make_cso_engine(const bbo_params &p);      // bbo_cso.hip
+Optimizer* make_ccpso_engine(const bbo_params &p);    // bbo_ccpso.hip
 Optimizer* make_restart_driver(const bbo_params &p, Optimizer *base);   // bbo_restart.hip
 }
 
@@ -101,6 +102,8 @@ void bbo_params_default(bbo_params *p, int algo)
     p->pcompete = 3;
     p->ring = 0;
     p->vmax = 0.2;
+    p->npps = 0;
+    p->pcauchy = -1.;
 }
 
 int bbo_create(const bbo_params *params, bbo_handle *out)
@@ -130,6 +133,9 @@ int bbo_create(const bbo_params *params, bbo_handle *out)
             break;
         case BBO_ALGO_CSO:
             h->opt.reset(bbo::make_cso_engine(*params));
+            break;
+        case BBO_ALGO_CCPSO:
+            h->opt.reset(bbo::make_ccpso_engine(*params));
             break;
         default:
             throw bbo::Error(BBO_ERR_ARG,

@@ -1,0 +1,392 @@
+// bbo_ccpso.hip -- host side of the CCPSO2 engine (ccpso.cpp:51-148; no local optimizer).
+#include "bbo_ccpso_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace bbo {
+
+namespace {
+enum { K_REGROUP = 0, K_EVAL, K_UPDATE, K_POSITION, K_FINISH, K_COUNT };
+}
+
+CcpsoEngine::CcpsoEngine(const bbo_params &p) :
+        params_(p)
+{
+    BBO_REQUIRE(p.algo == BBO_ALGO_CCPSO, "CcpsoEngine: bad algo");
+    BBO_REQUIRE(p.np >= 3, "CCPSO needs at least 3 particles (ring neighbourhood)");
+    BBO_REQUIRE(p.npps >= 1 && p.npps <= 16, "CCPSO: between 1 and 16 swarm sizes (pps)");
+    BBO_REQUIRE(p.populations >= 1, "populations must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(BBO_ERR_NO_DEVICE, "no HIP device visible: libbbopt_hip has no CPU path");
+    BBO_REQUIRE(p.device >= 0 && p.device < ndev, "device ordinal out of range");
+    BBO_HIP(hipSetDevice(p.device));
+    BBO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+}
+
+CcpsoEngine::~CcpsoEngine()
+{
+    if (stream_) (void) hipStreamDestroy(stream_);
+}
+
+void CcpsoEngine::init(int n, const double *lower, const double *upper, const double *guess,
+        const ObjectiveSpec &obj)
+{
+    (void) guess;   // never read (ccpso.cpp:66-112)
+    BBO_REQUIRE(n >= 1 && n <= 1024, "CCPSO: dimension must be in [1, 1024]");
+    for (int j = 0; j < n; j++)
+        BBO_REQUIRE(std::isfinite(lower[j]) && std::isfinite(upper[j]),
+                "CCPSO draws its swarm from [lower, upper]: the bounds must be finite");
+    for (int k = 0; k < params_.npps; k++)   // the reference throws when the size is drawn (:196)
+        if (params_.pps[k] <= 0 || params_.pps[k] > n || n % params_.pps[k] != 0)
+            throw Error(BBO_ERR_ARG, "Error [CC-PSO]: invalid component size.");
+    BBO_HIP(hipSetDevice(params_.device));
+    obj_ = obj;
+    const int P = params_.populations;
+    CcpConst &c = c_;
+    c = CcpConst {};
+    c.n = n;
+    c.ld = round_up(n, 2);
+    c.np = params_.np;
+    c.npps = params_.npps;
+    for (int k = 0; k < c.npps; k++) c.pps[k] = params_.pps[k];
+    c.correct = params_.correct ? 1 : 0;
+    c.phat0 = params_.pcauchy;
+    // (the reference reads an uninitialised member in this test, ccpso.cpp:60; the intended
+    // reading is taken: adapt unless a probability in (0, 1) was given)
+    c.adaptp = !(c.phat0 > 0. && c.phat0 < 1.) ? 1 : 0;
+    c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
+    c.mfev = params_.mfev;
+    c.npop = P;
+    c.stol = params_.tol;
+    c.seed = params_.seed;
+
+    const size_t rows = (size_t) P * c.np, ld = c.ld, sw = (size_t) P * n * c.np;
+    X_.alloc(rows * ld);
+    Y_.alloc(rows * ld);
+    yhat_.alloc(P * ld);
+    ysave_.alloc(P * ld);
+    fX_.alloc(sw);
+    fY_.alloc(sw);
+    ibest_.alloc(sw);
+    strat_.alloc(sw);
+    range_.alloc((size_t) P * n);
+    grp_of_.alloc((size_t) P * n);
+    radius_.alloc(rows);
+    lower_.alloc(ld);
+    upper_.alloc(ld);
+    aux_.alloc(ld);
+    scal_.alloc(P);
+    std::vector<double> lo(ld, 0.), up(ld, 0.);
+    aux_h_.assign(ld, 0.);
+    std::copy(lower, lower + n, lo.begin());
+    std::copy(upper, upper + n, up.begin());
+    fill_objective_aux(obj.on_device() ? obj.builtin : -1, n, aux_h_.data());
+    lower_.upload(lo.data(), ld);
+    upper_.upload(up.data(), ld);
+    aux_.upload(aux_h_.data(), ld);
+    std::vector<int> zi(sw, 0);
+    strat_.upload(zi.data(), sw);
+    ibest_.upload(zi.data(), sw);
+    std::vector<CcpScal> sc(P);
+    for (auto &s : sc) {
+        std::memset(&s, 0, sizeof(s));
+        s.fev = c.np;
+        s.is = -1;
+        s.phat = c.adaptp ? 0.5 : c.phat0;
+        s.fyhat = std::numeric_limits<double>::infinity();
+    }
+    scal_.upload(sc.data(), P);
+
+    CcpDev &d = d_;
+    d = CcpDev {};
+    d.X = X_.p; d.Y = Y_.p; d.yhat = yhat_.p; d.ysave = ysave_.p; d.fX = fX_.p; d.fY = fY_.p;
+    d.ibest = ibest_.p; d.strat = strat_.p; d.range = range_.p; d.grp_of = grp_of_.p;
+    d.radius = radius_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
+    c.honor_stop = 0;
+    inited_ = true;
+
+    static bool attr_done = false;
+    if (!attr_done) {
+        BBO_HIP(hipFuncSetAttribute((const void*) ccp_init,
+                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        BBO_HIP(hipFuncSetAttribute((const void*) ccp_eval<16>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ccp_init, dim3((c.np + 15) / 16, P), dim3(256),
+            (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
+    BBO_HIP(hipGetLastError());
+    if (!obj_.on_device()) {
+        BBO_HIP(hipStreamSynchronize(stream_));
+        std::vector<double> xh((size_t) c.np * c.ld), fh(c.np);
+        for (int p = 0; p < P; p++) {
+            X_.download(xh.data(), xh.size(), (size_t) p * c.np * c.ld);
+            obj_.eval_host(xh.data(), c.np, c.n, c.ld, fh.data());
+            for (auto &v : fh)
+                if (v != v) v = std::numeric_limits<double>::infinity();
+            fX_.upload(fh.data(), c.np, (size_t) p * n * c.np);
+        }
+    }
+    hipLaunchKernelGGL(ccp_init_yhat, dim3(P), dim3(256), 0, stream_, d_, c_);
+    BBO_HIP(hipGetLastError());
+    BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+// host objective: the 2 nswarm np context-vector evaluations, in the reference's order
+void CcpsoEngine::host_eval_candidates()
+{
+    const CcpConst &c = c_;
+    BBO_HIP(hipStreamSynchronize(stream_));
+    std::vector<CcpScal> sc(c.npop);
+    scal_.download(sc.data(), c.npop);
+    std::vector<double> X((size_t) c.np * c.ld), Y(X.size()), yh(c.ld), work(c.ld);
+    std::vector<int> rg(c.n);
+    for (int p = 0; p < c.npop; p++) {
+        if (c.honor_stop && sc[p].stop) continue;
+        const int nswarm = sc[p].nswarm, cp = sc[p].cpswarm;
+        X_.download(X.data(), X.size(), (size_t) p * c.np * c.ld);
+        Y_.download(Y.data(), Y.size(), (size_t) p * c.np * c.ld);
+        yhat_.download(yh.data(), c.ld, (size_t) p * c.ld);
+        range_.download(rg.data(), c.n, (size_t) p * c.n);
+        std::vector<double> fx((size_t) nswarm * c.np), fy(fx.size());
+        for (int j = 0; j < nswarm; j++)
+            for (int i = 0; i < c.np; i++)
+                for (int which = 0; which < 2; which++) {
+                    work = yh;
+                    const double *src = (which ? Y : X).data() + (size_t) i * c.ld;
+                    for (int q = 0; q < cp; q++) work[rg[j * cp + q]] = src[rg[j * cp + q]];
+                    double f = 0.;
+                    obj_.eval_host(work.data(), 1, c.n, c.ld, &f);
+                    if (f != f) f = std::numeric_limits<double>::infinity();
+                    (which ? fy : fx)[(size_t) j * c.np + i] = f;
+                }
+        fX_.upload(fx.data(), fx.size(), (size_t) p * c.n * c.np);
+        fY_.upload(fy.data(), fy.size(), (size_t) p * c.n * c.np);
+    }
+}
+
+// host objective: f of a moved yhat, parked in scal.fyhat for ccp_yhat
+void CcpsoEngine::host_eval_yhat()
+{
+    const CcpConst &c = c_;
+    BBO_HIP(hipStreamSynchronize(stream_));
+    std::vector<CcpScal> sc(c.npop);
+    scal_.download(sc.data(), c.npop);
+    std::vector<double> yh(c.ld);
+    bool touched = false;
+    for (int p = 0; p < c.npop; p++) {
+        if ((c.honor_stop && sc[p].stop) || !sc[p].yupd) continue;
+        yhat_.download(yh.data(), c.ld, (size_t) p * c.ld);
+        double f = 0.;
+        obj_.eval_host(yh.data(), 1, c.n, c.ld, &f);
+        sc[p].fyhat = f != f ? std::numeric_limits<double>::infinity() : f;
+        touched = true;
+    }
+    if (touched) scal_.upload(sc.data(), c.npop);
+}
+
+void CcpsoEngine::generation(bool honor_stop)
+{
+    CcpConst &c = c_;
+    c.honor_stop = honor_stop ? 1 : 0;
+    const int P = c.npop;
+    timer_.begin(stream_, K_REGROUP);
+    hipLaunchKernelGGL(ccp_regroup, dim3(P), dim3(256), 0, stream_, d_, c_);
+    timer_.end(stream_);
+    BBO_HIP(hipGetLastError());
+    // the largest candidate count any subset size can ask for (the device knows the real one)
+    int cpmin = c.pps[0];
+    for (int k = 1; k < c.npps; k++) cpmin = std::min(cpmin, c.pps[k]);
+    const int maxcand = 2 * (c.n / cpmin) * c.np;
+    timer_.begin(stream_, K_EVAL);
+    if (obj_.on_device()) {
+        if (c.ld <= 256)
+            hipLaunchKernelGGL(ccp_eval<16>, dim3((maxcand + 15) / 16, P), dim3(256),
+                    (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
+        else
+            hipLaunchKernelGGL(ccp_eval<64>, dim3((maxcand + 3) / 4, P), dim3(256),
+                    (size_t) 4 * c.ld * sizeof(double), stream_, d_, c_);
+    } else {
+        host_eval_candidates();
+    }
+    timer_.end(stream_);
+    BBO_HIP(hipGetLastError());
+    timer_.begin(stream_, K_UPDATE);
+    hipLaunchKernelGGL(ccp_update, dim3(c.n / cpmin, P), dim3(256), 0, stream_, d_, c_);
+    if (!obj_.on_device()) host_eval_yhat();
+    hipLaunchKernelGGL(ccp_yhat, dim3(P), dim3(256), (size_t) c.ld * sizeof(double), stream_, d_,
+            c_);
+    timer_.end(stream_);
+    BBO_HIP(hipGetLastError());
+    timer_.begin(stream_, K_POSITION);
+    hipLaunchKernelGGL(ccp_strategy, dim3(((c.n / cpmin) * c.np + 255) / 256, P), dim3(256), 0,
+            stream_, d_, c_);
+    hipLaunchKernelGGL(ccp_position, dim3((c.np + 15) / 16, P), dim3(256), 0, stream_, d_, c_);
+    timer_.end(stream_);
+    BBO_HIP(hipGetLastError());
+    timer_.begin(stream_, K_FINISH);
+    hipLaunchKernelGGL(ccp_finish, dim3(P), dim3(256), 0, stream_, d_, c_);
+    timer_.end(stream_);
+    BBO_HIP(hipGetLastError());
+}
+
+void CcpsoEngine::iterate()
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "iterate() before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    generation(false);
+    BBO_HIP(hipStreamSynchronize(stream_));
+    timer_.collect();
+}
+
+bool CcpsoEngine::all_stopped()
+{
+    std::vector<CcpScal> sc(c_.npop);
+    scal_.download(sc.data(), c_.npop);
+    for (const auto &s : sc)
+        if (!s.stop) return false;
+    return true;
+}
+
+int CcpsoEngine::run(int max_generations)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "run() before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    // (the reference's loop is `while (true) { iterate(); ... }`: at least one generation)
+    const int poll = params_.poll_every > 0 ? params_.poll_every : 8;
+    int done = 0;
+    while (done < max_generations) {
+        if (all_stopped()) break;
+        const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
+        for (int g = 0; g < chunk; g++) generation(true);
+        BBO_HIP(hipStreamSynchronize(stream_));
+        timer_.collect();
+        done += chunk;
+    }
+    return done;
+}
+
+void CcpsoEngine::solution(int population, double *x_out, int *n_evals, int *converged)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "solution() before initialize()");
+    BBO_REQUIRE(population >= 0 && population < c_.npop, "population index out of range");
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    CcpScal s;
+    scal_.download(&s, 1, population);
+    std::vector<double> x(c_.ld);
+    yhat_.download(x.data(), c_.ld, (size_t) population * c_.ld);
+    std::copy(x.begin(), x.begin() + c_.n, x_out);
+    *n_evals = s.fev;
+    if (s.gen == 0) {
+        std::vector<double> rad(c_.np);
+        radius_.download(rad.data(), c_.np, (size_t) population * c_.np);
+        double mean = 0.;
+        for (double r : rad) mean += r;
+        mean /= c_.np;
+        double m2 = 0.;
+        for (double r : rad) m2 += (r - mean) * (r - mean);
+        *converged = m2 <= (c_.np - 1) * c_.stol * c_.stol ? 1 : 0;
+    } else {
+        *converged = s.conv;
+    }
+}
+
+void CcpsoEngine::optimize(int n, const double *lower, const double *upper, const double *guess,
+        const ObjectiveSpec &obj, double *x_out, int *n_evals, int *converged)
+{
+    init(n, lower, upper, guess, obj);
+    run(std::numeric_limits<int>::max());
+    int conv = 0;
+    solution(0, x_out, n_evals, &conv);
+    CcpScal s;
+    scal_.download(&s, 1, 0);
+    *converged = s.stop == 1 ? 1 : 0;
+}
+
+int CcpsoEngine::get(const std::string &k, int p, double *out, int cap)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "get() before initialize()");
+    BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    const CcpConst &c = c_;
+    CcpScal s;
+    scal_.download(&s, 1, p);
+    auto one = [&](double v) {
+        if (out && cap >= 1) out[0] = v;
+        return 1;
+    };
+    if (k == "profile") return timer_.report(out, cap);
+    if (k == "x" || k == "y") {
+        const int cnt = c.np * c.n;
+        if (out && cap >= cnt) {
+            std::vector<double> M((size_t) c.np * c.ld);
+            (k == "x" ? X_ : Y_).download(M.data(), M.size(), (size_t) p * c.np * c.ld);
+            for (int i = 0; i < c.np; i++)
+                std::copy(M.begin() + (size_t) i * c.ld, M.begin() + (size_t) i * c.ld + c.n,
+                        out + (size_t) i * c.n);
+        }
+        return cnt;
+    }
+    if (k == "yhat") {
+        if (out && cap >= c.n) {
+            std::vector<double> v(c.ld);
+            yhat_.download(v.data(), c.ld, (size_t) p * c.ld);
+            std::copy(v.begin(), v.begin() + c.n, out);
+        }
+        return c.n;
+    }
+    if (k == "fx" || k == "fy") {
+        const int cnt = s.nswarm * c.np;
+        if (out && cap >= cnt && cnt > 0)
+            (k == "fx" ? fX_ : fY_).download(out, cnt, (size_t) p * c.n * c.np);
+        return cnt;
+    }
+    if (k == "ibest" || k == "strat" || k == "k") {
+        const int cnt = k == "k" ? c.n : s.nswarm * c.np;
+        if (out && cap >= cnt && cnt > 0) {
+            std::vector<int> v(cnt);
+            if (k == "k") range_.download(v.data(), cnt, (size_t) p * c.n);
+            else (k == "ibest" ? ibest_ : strat_).download(v.data(), cnt, (size_t) p * c.n * c.np);
+            for (int q = 0; q < cnt; q++) out[q] = v[q];
+        }
+        return cnt;
+    }
+    if (k == "fyhat") return one(s.fyhat);
+    if (k == "phat") return one(s.phat);
+    if (k == "fev") return one(s.fev);
+    if (k == "it") return one(s.gen);
+    if (k == "is") return one(s.is);
+    if (k == "nswarm") return one(s.nswarm);
+    if (k == "cpswarm") return one(s.cpswarm);
+    if (k == "improved") return one(s.improved);
+    if (k == "np") return one(c.np);
+    if (k == "stop") return one(s.stop);
+    if (k == "conv") return one(s.conv);
+    if (k == "m2") return one(s.m2);
+    if (k == "n") return one(c.n);
+    throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
+}
+
+int CcpsoEngine::set(const std::string &k, int p, const double *in, int count)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "set() before initialize()");
+    BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
+    (void) count;
+    if (k == "profile") {
+        timer_.enable(in[0] != 0., K_COUNT);
+        return 1;
+    }
+    throw Error(BBO_ERR_KEY, "unknown or read-only state key '" + k + "'");
+}
+
+Optimizer* make_ccpso_engine(const bbo_params &p)
+{
+    return new CcpsoEngine(p);
+}
+
+} // namespace bbo

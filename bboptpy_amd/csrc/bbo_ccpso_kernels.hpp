@@ -1,0 +1,392 @@
+// bbo_ccpso_kernels.hpp -- one CCPSO2 generation as gfx950 kernels.
+//
+//   kernel          reference lines (ccpso.cpp)
+//   ccp_init        :76-100 uniform swarm, Y = X, yhat = the best particle
+//   ccp_regroup     :188-231 subset size (kept while yhat improves), random regrouping
+//                   (std::shuffle -> the keyed Feistel bijection of bbo_cso_kernels.hpp)
+//   ccp_eval<G>     :233-247 + evaluate :150-168: 2 nswarm np context-vector evaluations,
+//                   one candidate per G lanes built in LDS (yhat with one swarm's coordinates
+//                   replaced): objective-bound, the throughput driver
+//   ccp_update      :251-290 personal bests, swarm bests into yhat (last qualifying particle
+//                   wins, stale fY -- both kept), ring local bests
+//   ccp_yhat        :292-303 re-evaluation of a moved yhat, accept / revert; :306-332 Cauchy rate
+//   ccp_strategy + ccp_position   :335-371 Cauchy / normal resampling around y_i / y_lbest
+//   ccp_finish      :170-186 radius spread, stop
+#pragma once
+
+#include "bbo_ccpso.hpp"
+#include "bbo_objectives.hpp"
+#include "bbo_rng.hpp"
+
+namespace bbo {
+
+#define CCP_INF (__builtin_huge_val())
+constexpr double CCP_PI = 3.14159265358979323846;
+
+__device__ inline bool ccp_frozen(const CcpConst &c, const CcpScal *sc)
+{
+    return c.honor_stop && sc->stop != 0;
+}
+
+template<int G>
+__device__ inline double ccp_group_sum(double v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+
+// grid (ceil(np/16), P), 256 threads, LDS 16 * ld doubles (n <= 1024) -- init only
+__global__ __launch_bounds__(256) void ccp_init(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.y;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r, ld = c.ld;
+    double *row = lds + r * ld;
+    const size_t base = ((size_t) p * c.np + i) * ld;
+    double ssq = 0.;
+    if (i < c.np) {
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, 0,
+                    stream_word(STREAM_INIT, (uint32_t) p));
+            const int j = 2 * pj;
+            double2 v = make_double2(0., 0.);
+            if (j < c.n) v.x = u01(w.x, w.y) * (d.upper[j] - d.lower[j]) + d.lower[j];
+            if (j + 1 < c.n) v.y = u01(w.z, w.w) * (d.upper[j + 1] - d.lower[j + 1]) + d.lower[j + 1];
+            *reinterpret_cast<double2*>(&row[j]) = v;
+            *reinterpret_cast<double2*>(&d.X[base + j]) = v;
+            *reinterpret_cast<double2*>(&d.Y[base + j]) = v;
+            ssq += v.x * v.x + v.y * v.y;
+        }
+    }
+    __syncthreads();
+    ssq = ccp_group_sum<16>(ssq);
+    double f = CCP_INF;
+    if (c.obj >= 0) {
+        f = eval_row_group<16>(c.obj, c.n, row, d.aux, g);
+        if (f != f) f = CCP_INF;
+    }
+    if (g == 0 && i < c.np) {
+        d.fX[(size_t) p * c.n * c.np + i] = f;        // scratch: the initial fitness
+        d.radius[(size_t) p * c.np + i] = sqrt(ssq);
+    }
+}
+
+// yhat = the first particle with the smallest initial fitness.  grid (P), 256 threads
+__global__ __launch_bounds__(256) void ccp_init_yhat(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.x;
+    __shared__ int sbest;
+    CcpScal *sc = d.scal + p;
+    if (threadIdx.x == 0) {
+        const double *f = d.fX + (size_t) p * c.n * c.np;
+        double best = CCP_INF;
+        int ib = 0;
+        for (int i = 0; i < c.np; i++)
+            if (f[i] < best) {
+                best = f[i];
+                ib = i;
+            }
+        sbest = ib;
+        sc->fyhat = best;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c.ld; j += 256)
+        d.yhat[(size_t) p * c.ld + j] = d.X[((size_t) p * c.np + sbest) * c.ld + j];
+}
+
+// grid (P), 256 threads
+__global__ __launch_bounds__(256) void ccp_regroup(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.x;
+    CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    __shared__ int s_changed, s_cp;
+    const int tid = threadIdx.x, gen = sc->gen;
+    const uint32_t sw = stream_word(STREAM_PSO_CTRL, (uint32_t) p);
+    if (tid == 0) {
+        const int is0 = sc->is;
+        int is = is0;
+        if (!sc->improved) {
+            const u32x4 w = philox4x32_10(c.seed, 0, 0, (uint32_t) gen, sw);
+            is = uint_below(w.x, c.npps);
+        }
+        s_changed = is != is0;
+        if (is != is0) {
+            sc->is = is;
+            sc->cpswarm = c.pps[is];
+            sc->nswarm = c.n / c.pps[is];
+        }
+        s_cp = sc->cpswarm;
+        sc->yupd = 0;
+        sc->fyhat0 = sc->fyhat;
+    }
+    __syncthreads();
+    const int cp = s_cp;
+    if (s_changed)   // _strat is re-created (zeros) with the new shape, ccpso.cpp:209-210
+        for (int q = tid; q < c.n * c.np; q += 256) d.strat[(size_t) p * c.n * c.np + q] = 0;
+    int bits = 1;
+    while ((1u << bits) < (unsigned) c.n) bits++;
+    const int kb = (bits + 1) / 2;
+    for (int q = tid; q < c.n; q += 256) {
+        const int coord = (int) cso_perm((uint32_t) q, kb, (uint32_t) c.n, c.seed, (uint32_t) gen, sw);
+        d.range[(size_t) p * c.n + q] = coord;
+        d.grp_of[(size_t) p * c.n + coord] = q / cp;
+    }
+    for (int j = tid; j < c.ld; j += 256) d.ysave[(size_t) p * c.ld + j] = d.yhat[(size_t) p * c.ld + j];
+}
+
+// candidate (j, i, which): yhat with the coordinates of swarm j taken from X_i (which = 0) or
+// Y_i (1).  G lanes per candidate, 256 / G candidates per workgroup, LDS (256/G) * ld doubles.
+// grid (ceil(2 * nswarm_max * np / (256/G)), P) -- candidates past 2 nswarm np return
+template<int G>
+__global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.y;
+    const CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    constexpr int R = 256 / G;
+    const int tid = threadIdx.x, r = tid / G, g = tid % G;
+    const int cand = blockIdx.x * R + r, ld = c.ld, np = c.np;
+    const int nswarm = sc->nswarm, cp = sc->cpswarm;
+    if (blockIdx.x * R >= 2 * nswarm * np) return;   // the grid is sized for the smallest subset size
+    const bool live = cand < 2 * nswarm * np;
+    double *row = lds + (size_t) r * ld;
+    const int which = cand & 1, t = cand >> 1;
+    const int i = live ? t % np : 0, j = live ? t / np : 0;
+    const double *yh = d.yhat + (size_t) p * ld;
+    for (int q = g; q < ld; q += G) row[q] = yh[q];
+    __syncthreads();
+    if (live) {
+        const double *src = (which ? d.Y : d.X) + ((size_t) p * np + i) * ld;
+        const int *rg = d.range + (size_t) p * c.n + (size_t) j * cp;
+        for (int q = g; q < cp; q += G) {
+            const int coord = rg[q];
+            row[coord] = src[coord];
+        }
+    }
+    __syncthreads();
+    if (c.obj >= 0) {
+        double f = eval_row_group<G>(c.obj, c.n, row, d.aux, g);
+        if (f != f) f = CCP_INF;
+        if (live && g == 0) (which ? d.fY : d.fX)[(size_t) p * c.n * np + (size_t) j * np + i] = f;
+    }
+}
+
+// one workgroup per swarm j: personal bests, the swarm's contribution to yhat, ring local bests.
+// grid (n (>= nswarm), P), 256 threads
+__global__ __launch_bounds__(256) void ccp_update(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.y, j = blockIdx.x;
+    CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    if (j >= sc->nswarm) return;
+    __shared__ int s_last[4];
+    const int tid = threadIdx.x, np = c.np, ld = c.ld, cp = sc->cpswarm;
+    const size_t fb = (size_t) p * c.n * np + (size_t) j * np;
+    const double *fX = d.fX + fb, *fY = d.fY + fb;
+    const int *rg = d.range + (size_t) p * c.n + (size_t) j * cp;
+    const double fyhat = sc->fyhat0;
+    // personal bests: Y_i <- X_i on this swarm's coordinates where X scored better
+    for (int q = tid; q < np * cp; q += 256) {
+        const int i = q / cp, coord = rg[q - i * cp];
+        if (fX[i] < fY[i]) d.Y[((size_t) p * np + i) * ld + coord] = d.X[((size_t) p * np + i) * ld + coord];
+    }
+    // the LAST particle whose (stale) fY beats fyhat gives the swarm's coordinates to yhat
+    int last = -1;
+    for (int i = tid; i < np; i += 256)
+        if (fY[i] < fyhat) last = i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+    if ((tid & 63) == 0) s_last[tid >> 6] = last;
+    __syncthreads();                       // (also orders the Y writes above)
+    last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    if (last >= 0) {
+        for (int q = tid; q < cp; q += 256) {
+            const int coord = rg[q];
+            d.yhat[(size_t) p * ld + coord] = d.Y[((size_t) p * np + last) * ld + coord];
+        }
+        if (tid == 0) atomicOr(&sc->yupd, 1);
+    }
+    // ring local best: the first smallest of (i-1, i, i+1)
+    int *ib = d.ibest + fb;
+    for (int i = tid; i < np; i += 256) {
+        const int a = (i - 1 + np) % np, b = (i + 1) % np;
+        int im = a;
+        if (fY[i] < fY[im]) im = i;
+        if (fY[b] < fY[im]) im = b;
+        ib[i] = im;
+    }
+}
+
+// a moved yhat is re-evaluated, kept only if better; then the Cauchy rate.  grid (P), 256
+// threads, LDS ld doubles (the objective reads yhat from there)
+__global__ __launch_bounds__(256) void ccp_yhat(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.x;
+    CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    extern __shared__ double lds[];
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x, ld = c.ld, np = c.np;
+    const int nswarm = sc->nswarm;
+    double *yh = d.yhat + (size_t) p * ld;
+    double fnew = sc->fyhat0;
+    const int yupd = sc->yupd;
+    if (yupd && c.obj >= 0) {
+        for (int q = tid; q < ld; q += 256) lds[q] = yh[q];
+        __syncthreads();
+        double f = 0.;
+        if (tid < 64) {
+            f = eval_row_group<64>(c.obj, c.n, lds, d.aux, tid);
+            if (f != f) f = CCP_INF;
+        }
+        f = __shfl(f, 0, 64);
+        if (tid == 0) red[0][0] = f;
+        __syncthreads();
+        fnew = red[0][0];
+        __syncthreads();
+    } else if (yupd) {
+        fnew = sc->fyhat;                // host objective: the host stored f(yhat) here
+    }
+    const bool improved = yupd && fnew < sc->fyhat0;
+    if (!improved)
+        for (int q = tid; q < ld; q += 256) yh[q] = d.ysave[(size_t) p * ld + q];
+    // success rates of the two resampling kinds (ccpso.cpp:306-332)
+    double cs = 0., ns = 0., ct = 0., nt = 0.;
+    const size_t fb = (size_t) p * c.n * np;
+    for (int q = tid; q < nswarm * np; q += 256) {
+        const int st = d.strat[fb + q];
+        const bool ok = d.fX[fb + q] < d.fY[fb + q];
+        if (st == 0) {
+            ct += 1.;
+            cs += ok ? 1. : 0.;
+        } else {
+            nt += 1.;
+            ns += ok ? 1. : 0.;
+        }
+    }
+    double v[4] = { cs, ns, ct, nt };
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[u] += __shfl_xor(v[u], off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][u] = v[u];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot[4];
+        for (int u = 0; u < 4; u++) tot[u] = red[0][u] + red[1][u] + red[2][u] + red[3][u];
+        sc->fev += 2 * nswarm * np + (yupd ? 1 : 0);
+        sc->improved = improved ? 1 : 0;
+        sc->fyhat = improved ? fnew : sc->fyhat0;
+        if (sc->gen > 0 && c.adaptp) {
+            const double crate = tot[0] / fmax(1., tot[2]);
+            const double nrate = tot[1] / fmax(1., tot[3]);
+            sc->phat = fmax(0.05, fmin(crate / fmax(1., crate + nrate), 0.95));
+        }
+    }
+}
+
+// resampling kind of every (swarm, particle).  grid (ceil(n*np/256), P)
+__global__ __launch_bounds__(256) void ccp_strategy(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.y;
+    const CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    const int q = blockIdx.x * 256 + threadIdx.x, np = c.np;
+    if (q >= sc->nswarm * np) return;
+    const int j = q / np, i = q - j * np;
+    const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) (16 + j), (uint32_t) sc->gen,
+            stream_word(STREAM_PSO_CTRL, (uint32_t) p));
+    d.strat[(size_t) p * c.n * np + q] = u01(w.x, w.y) < sc->phat ? 0 : 1;
+}
+
+// new positions: 16 lanes per particle sweep its coordinates.  grid (ceil(np/16), P)
+__global__ __launch_bounds__(256) void ccp_position(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.y;
+    const CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
+    const int i = blockIdx.x * 16 + r, np = c.np, ld = c.ld, gen = sc->gen;
+    double ssq = 0.;
+    if (i < np) {
+        const size_t fb = (size_t) p * c.n * np;
+        const int *grp = d.grp_of + (size_t) p * c.n;
+        const double *Y = d.Y + (size_t) p * np * ld;
+        double *x = d.X + ((size_t) p * np + i) * ld;
+        const uint32_t sw = stream_word(STREAM_PSO_R, (uint32_t) p);
+        for (int pj = g; pj < ld / 2; pj += 16) {
+            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw);
+            double z0 = 0., z1 = 0.;
+            bool have_z = false;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int dd = 2 * pj + h;
+                if (dd >= c.n) continue;
+                const int j = grp[dd];
+                const int st = d.strat[fb + (size_t) j * np + i];
+                const int ihat = d.ibest[fb + (size_t) j * np + i];
+                const double yi = Y[(size_t) i * ld + dd], yl = Y[(size_t) ihat * ld + dd];
+                double dev;
+                if (st == 0) {
+                    const double u = h ? u01(w.z, w.w) : u01(w.x, w.y);
+                    dev = tan(CCP_PI * (u - 0.5));
+                } else {
+                    if (!have_z) {
+                        normal_pair(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw, z0, z1);
+                        have_z = true;
+                    }
+                    dev = h ? z1 : z0;
+                }
+                double v = (st == 0 ? yi : yl) + dev * fabs(yi - yl);
+                if (c.correct) v = fmax(d.lower[dd], fmin(v, d.upper[dd]));
+                x[dd] = v;
+                ssq += v * v;
+            }
+        }
+    }
+    ssq = ccp_group_sum<16>(ssq);
+    if (g == 0 && i < np) d.radius[(size_t) p * np + i] = sqrt(ssq);
+}
+
+// grid (P), 256 threads
+__global__ __launch_bounds__(256) void ccp_finish(CcpDev d, CcpConst c)
+{
+    const int p = blockIdx.x;
+    CcpScal *sc = d.scal + p;
+    if (ccp_frozen(c, sc)) return;
+    __shared__ double red[4];
+    const int tid = threadIdx.x, np = c.np;
+    auto block_sum = [&](double v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    double s = 0.;
+    for (int q = tid; q < np; q += 256) s += d.radius[(size_t) p * np + q];
+    const double mean = block_sum(s) / np;
+    double m2 = 0.;
+    for (int q = tid; q < np; q += 256) {
+        const double dd = d.radius[(size_t) p * np + q] - mean;
+        m2 += dd * dd;
+    }
+    m2 = block_sum(m2);
+    if (tid == 0) {
+        sc->gen += 1;
+        sc->m2 = m2;
+        const int conv = m2 <= (np - 1) * c.stol * c.stol ? 1 : 0;
+        sc->conv = conv;
+        // ccpso.cpp:137-146: the budget test comes first
+        if (sc->fev >= c.mfev) sc->stop = 2;
+        else if (conv) sc->stop = 1;
+    }
+}
+
+} // namespace bbo

@@ -145,25 +145,6 @@ __global__ __launch_bounds__(256) void cso_mean(CsoDev d, CsoConst c, int winner
 // new slot s takes the occupant of slot perm(s), perm = 4-round Feistel network on 2 kb bits
 // with one Philox word per round, cycle-walked back into [0, np).  O(1) per slot, no
 // communication; oracle twin: Cso::feistel_perm.  grid (ceil(np/256), P), 256 threads
-__device__ inline uint32_t cso_perm(uint32_t s0, int kb, uint32_t np, uint64_t seed, uint32_t gen,
-        uint32_t sw)
-{
-    const uint32_t mask = (1u << kb) - 1u;
-    uint32_t x = s0;
-    do {
-        uint32_t L = x >> kb, R = x & mask;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const u32x4 w = philox4x32_10(seed, R, (uint32_t) (8 + r), gen, sw);
-            const uint32_t t = L ^ (w.x & mask);
-            L = R;
-            R = t;
-        }
-        x = (L << kb) | R;
-    } while (x >= np);
-    return x;
-}
-
 __global__ __launch_bounds__(256) void cso_shuffle(CsoDev d, CsoConst c, int kb)
 {
     const int p = blockIdx.y;

@@ -157,4 +157,27 @@ __device__ inline void normal_pair(uint64_t seed, uint32_t c0, uint32_t c1, uint
 // i.e. exactly the two k-steps lane group (pj & 3) feeds to the MFMA A operand
 __host__ __device__ inline int cma_pair_col0(int pj) { return 8 * (pj >> 2) + (pj & 3); }
 
+// Keyed bijection of [0, np): 4-round Feistel network on 2 kb bits (kb = half the bits of
+// np - 1, rounded up), one Philox word per round keyed by (half-word, 8 + round, generation),
+// cycle-walked back into range.  The device's std::shuffle (CSO slots, CCPSO coordinates);
+// oracle twins: Cso::feistel_perm, Ccpso::feistel_perm.
+__device__ inline uint32_t cso_perm(uint32_t s0, int kb, uint32_t np, uint64_t seed, uint32_t gen,
+        uint32_t sw)
+{
+    const uint32_t mask = (1u << kb) - 1u;
+    uint32_t x = s0;
+    do {
+        uint32_t L = x >> kb, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u32x4 w = philox4x32_10(seed, R, (uint32_t) (8 + r), gen, sw);
+            const uint32_t t = L ^ (w.x & mask);
+            L = R;
+            R = t;
+        }
+        x = (L << kb) | R;
+    } while (x >= np);
+    return x;
+}
+
 } // namespace bbo

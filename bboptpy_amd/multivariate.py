@@ -373,6 +373,31 @@ class CSO(MultivariateSearch):
         p.correct, p.vmax = int(bool(correct)), float(vmax)
 
 
+class CCPSO(MultivariateSearch):
+    """CCPSO(mfev, sigmatol, np, pps, npps, correct=True, pcauchy=-1., local=None, localfreq=10)
+    -- :291-295 (cooperatively coevolving PSO, Li & Yao 2012; ccpso.cpp).  `pps` lists the
+    candidate swarm sizes (each must divide n).  The optional `local` optimizer of the reference
+    is not supported on the device path."""
+    _algo = _ffi.ALGO_CCPSO
+
+    def __init__(self, mfev, sigmatol, np, pps, npps=None, correct=True, pcauchy=-1., local=None,
+                 localfreq=10, **ext):
+        if local is not None:
+            raise NotImplementedError("CCPSO: the local optimizer hook is not available on the "
+                                      "device path (pass local=None)")
+        super().__init__(**ext)
+        pps = [int(v) for v in pps]
+        npps = len(pps) if npps is None else int(npps)
+        if not 1 <= npps <= min(16, len(pps)):
+            raise ValueError("CCPSO: npps must be in [1, min(16, len(pps))]")
+        p = self._params
+        p.mfev, p.tol, p.np = int(mfev), float(sigmatol), int(np)
+        p.npps = npps
+        for k in range(npps):
+            p.pps[k] = pps[k]
+        p.correct, p.pcauchy = int(bool(correct)), float(pcauchy)
+
+
 class APSO(MultivariateSearch):
     """APSO(mfev, tol, np, correct=True) -- :265-269"""
     _algo = _ffi.ALGO_APSO

@@ -48,6 +48,8 @@ WORKLOADS = {
     "SEP": dict(algo="SepCMAES", n=1024, np=4096, objective="ellipsoid", box=(-5., 5.), P=64),
     "SANSDE": dict(algo="SANSDE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "CSO": dict(algo="CSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=4),
+    "CCPSO": dict(algo="CCPSO", n=1000, np=30, objective="rosenbrock", box=(-10., 10.), P=16,
+                  pps=[2, 5, 10, 50, 100, 250]),
     "C4": dict(algo="APSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=1),
     "C4s": dict(algo="APSO", n=512, np=4096, objective="sphere", box=(-10., 10.), P=8),
 }
@@ -58,6 +60,7 @@ DE_KERNELS = ["de_generation", "de_bookkeep", "de_archive_copy", "de_rank", "de_
               "de_select"]
 PSO_KERNELS = ["pso_center", "pso_ese", "pso_control", "pso_update", "pso_finish"]
 CSO_KERNELS = ["cso_mean", "cso_shuffle", "cso_groups", "cso_compete", "cso_finish"]
+CCPSO_KERNELS = ["ccp_regroup", "ccp_eval", "ccp_update", "ccp_position", "ccp_finish"]
 
 
 def cso_kernel_costs(n, np_, P, pc=3):
@@ -164,6 +167,9 @@ def make_optimizer(bb, wl, P, seed, device):
         # npmin = npinit: population-size reduction off, steady-state throughput
         return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
                         device=device, populations=P)
+    if a == "CCPSO":
+        return bb.CCPSO(mfev=huge, sigmatol=0., np=wl["np"], pps=wl["pps"], seed=seed,
+                        device=device, populations=P)
     if a == "CSO":
         return bb.CSO(mfev=huge, stol=0., np=wl["np"], seed=seed, device=device, populations=P)
     if a == "SANSDE":
@@ -186,7 +192,9 @@ def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
         assert alg.run(warmup) == warmup
     if profile:
         alg.set_state("profile", [1.0])
-    fev0 = alg.get_state("fev")[0]
+    count_all = wl["algo"] == "CCPSO"    # every population draws its own swarm size there
+    pops = range(P) if count_all else (0,)
+    fev0 = sum(alg.get_state("fev", p)[0] for p in pops)
     if barrier:
         barrier()
     t0 = time.perf_counter()
@@ -199,7 +207,9 @@ def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
     prof = alg.get_state("profile") if profile else None
     # objective evaluations of ONE population inside the timed region (np per generation for
     # CMA / DE; CSO evaluates its losers only, APSO adds its elitist-learning probes)
-    fev = alg.get_state("fev")[0] - fev0
+    fev = sum(alg.get_state("fev", p)[0] for p in pops) - fev0
+    if count_all:
+        fev /= P            # (the caller multiplies by P again)
     return dt, prof, fev, alg
 
 
@@ -263,18 +273,34 @@ def cpu_baseline(wl, budget_s=12.0):
         h = po.sansde(lib, 2 ** 31 - 1, lam, 0.)
     elif a == "CSO":
         h = po.cso(lib, 2 ** 31 - 1, 0., lam)
+    elif a == "CCPSO":
+        h = po.ccpso(lib, 2 ** 31 - 1, 0., lam, wl["pps"])
     else:
         h = po.apso(lib, 2 ** 31 - 1, 0., lam)
     h.init(wl["objective"], lo, up, guess)
     fev0 = h.scalar("fev")
     gens = 0
-    t0 = time.perf_counter()
-    while True:
-        h.iterate()
-        gens += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or gens >= 200:
-            break
+    # the reference's CCPSO prints _fyhat to stdout every generation (ccpso.cpp:121): keep it
+    # out of this script's one-line JSON
+    saved_fd = None
+    if a == "CCPSO":
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        os.close(devnull)
+    try:
+        t0 = time.perf_counter()
+        while True:
+            h.iterate()
+            gens += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or gens >= 200:
+                break
+    finally:
+        if saved_fd is not None:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     evals = h.scalar("fev") - fev0
     return {"value": evals / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
             "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s%s" % (
@@ -388,6 +414,10 @@ def main():
                 costs["de_generation"] = ("hbm", P * wl["np"] * (48 * wl["n"] + 24))
         elif wl["algo"] == "CSO":
             names, costs = CSO_KERNELS, cso_kernel_costs(wl["n"], wl["np"], P)
+        elif wl["algo"] == "CCPSO":
+            # the candidate count changes with the subset size drawn: no fixed per-launch work;
+            # the evaluation kernel is bound by the objective's arithmetic, not by a roofline
+            names, costs = CCPSO_KERNELS, {k: ("hbm", None) for k in CCPSO_KERNELS}
         else:
             names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
         kernels = {}

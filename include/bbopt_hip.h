@@ -51,7 +51,8 @@ typedef enum {
     BBO_ALGO_BIPOP_CMAES = 6,  /* BiPopCmaes   src/multivariate/cma/bipop_cmaes.h:49  */
     BBO_ALGO_SEP_CMAES = 7,    /* SepCmaes     src/multivariate/cma/sep_cmaes.h:36    */
     BBO_ALGO_SANSDE = 8,       /* SaNSDESearch src/multivariate/de/sansde.h:40        */
-    BBO_ALGO_CSO = 9           /* CSOSearch    src/multivariate/pso/cso.h:44          */
+    BBO_ALGO_CSO = 9,          /* CSOSearch    src/multivariate/pso/cso.h:44          */
+    BBO_ALGO_CCPSO = 10        /* CCPSOSearch  src/multivariate/pso/ccpso.h:46        */
 } bbo_algo;
 
 /* Built-in objectives evaluated on the device (the reference ships none; id 1 is
@@ -149,6 +150,11 @@ typedef struct {
     int pcompete;          /* particles per competition                            */
     int ring;              /* ring neighbourhood instead of the swarm mean         */
     double vmax;           /* velocity clamp as a fraction of the box width        */
+    /* CCPSO(mfev,sigmatol,np,pps,npps,correct=True,pcauchy=-1,local=None,localfreq=10) :291-295
+     * (`sigmatol` travels in `tol`; the optional local optimizer is not supported) */
+    int npps;              /* number of candidate swarm sizes                      */
+    int pps[16];           /* the candidate swarm sizes (each must divide n)       */
+    double pcauchy;        /* fixed Cauchy rate in (0,1), else adaptive            */
 } bbo_params;
 
 void bbo_params_default(bbo_params *p, int algo);

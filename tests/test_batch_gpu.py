@@ -21,12 +21,15 @@ def _make(hip, algo, P, seed):
         return hip.JADE(mfev=10 ** 8, np=32, tol=1e-12, seed=seed, populations=P)
     if algo == "sansde":
         return hip.SANSDE(mfev=10 ** 8, np=32, tol=1e-12, seed=seed, populations=P)
+    if algo == "ccpso":
+        return hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=12, pps=[2, 3, 4], seed=seed,
+                         populations=P)
     if algo == "cso":
         return hip.CSO(mfev=10 ** 8, stol=1e-12, np=33, seed=seed, populations=P)
     return hip.APSO(mfev=10 ** 8, tol=1e-12, np=32, seed=seed, populations=P)
 
 
-@pytest.mark.parametrize("algo", ["active", "cmaes", "sep", "shade", "jade", "sansde", "apso", "cso"])
+@pytest.mark.parametrize("algo", ["active", "cmaes", "sep", "shade", "jade", "sansde", "apso", "cso", "ccpso"])
 def test_population_zero_is_the_single_run(hip, algo):
     n, P, seed, gens = 12, 5, 77, 30
     lo, up = -5. * np.ones(n), 5. * np.ones(n)

@@ -1,0 +1,88 @@
+"""GPU parity: one CCPSO2 generation (regrouping, the 2 nswarm np context-vector evaluations,
+personal / swarm / ring bests, the yhat re-evaluation, the Cauchy rate, the resampling) against
+the oracle in Philox mode.  The oracle's mt19937 form is pinned bit for bit to the compiled
+reference; the Philox form differs only in where the random numbers come from and in regrouping
+with the keyed Feistel bijection instead of std::shuffle."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, what):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    if a.size == 0:
+        return
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert err <= rtol, "%s: rel err %.3e > %.1e" % (what, err, rtol)
+
+
+@pytest.mark.parametrize("n,npp,obj,pps,kw", [
+    (12, 8, "rastrigin", [2, 3, 6], {}),
+    (20, 10, "rosenbrock", [5, 10], dict(correct=False)),
+    (16, 6, "sphere", [1, 2, 4, 8, 16], dict(pcauchy=0.3)),
+    (300, 24, "ellipsoid", [5, 10, 50], {}),             # ld > 256: 64 lanes per candidate
+])
+def test_generations_match_oracle(hip, oracle_lib, n, npp, obj, pps, kw):
+    seed = 555
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    g = hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=npp, pps=pps, seed=seed, **kw)
+    o = po.ccpso(oracle_lib, 10 ** 8, 1e-12, npp, pps, **kw)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    g.initialize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
+    o.init(obj, lo, up, np.zeros(n))
+    np.testing.assert_array_equal(g.get_state("x"), o.get("x"))
+    np.testing.assert_array_equal(g.get_state("yhat"), o.get("yhat"))
+    for gen in range(15 if n > 100 else 30):
+        g.iterate()
+        o.iterate()
+        tag = "gen %d" % gen
+        for k in ("is", "nswarm", "cpswarm", "fev", "improved"):
+            assert int(g.get_state(k)[0]) == int(o.scalar(k)), tag + " " + k
+        np.testing.assert_array_equal(g.get_state("k"), o.get("k"), err_msg=tag + " grouping")
+        np.testing.assert_array_equal(g.get_state("ibest"), o.get("ibest"), err_msg=tag + " ibest")
+        np.testing.assert_array_equal(g.get_state("strat"), o.get("strat"), err_msg=tag + " strat")
+        _close(g.get_state("fx"), o.get("fx"), 1e-11, tag + " fx")
+        _close(g.get_state("fy"), o.get("fy"), 1e-11, tag + " fy")
+        _close(g.get_state("y"), o.get("y"), 1e-13, tag + " y")
+        _close(g.get_state("x"), o.get("x"), 1e-10, tag + " x")
+        _close(g.get_state("yhat"), o.get("yhat"), 1e-13, tag + " yhat")
+        _close(g.get_state("fyhat"), [o.scalar("fyhat")], 1e-11, tag + " fyhat")
+        assert abs(g.get_state("phat")[0] - o.scalar("phat")) <= 1e-12, tag + " phat"
+
+
+def test_whole_run_same_seed_matches_oracle(hip, oracle_lib):
+    n = 20
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    g = hip.CCPSO(mfev=150000, sigmatol=1e-6, np=12, pps=[2, 5, 10], seed=8)
+    sol = g.optimize(hip.objectives.sphere, lo, up, np.zeros(n))
+    o = po.ccpso(oracle_lib, 150000, 1e-6, 12, [2, 5, 10])
+    o.set_mode(True, po.RNG_PHILOX, 8)
+    xo, fevo, convo = o.optimize("sphere", lo, up, np.zeros(n))
+    assert sol.n_evals == fevo and sol.converged == convo
+    np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-9)
+
+
+def test_python_callback_objective(hip):
+    n = 6
+    calls = [0]
+
+    def fx(x):
+        calls[0] += 1
+        return float(np.sum((x - 1.) ** 2))
+
+    g = hip.CCPSO(mfev=20000, sigmatol=1e-5, np=10, pps=[2, 3], seed=3)
+    sol = g.optimize(fx, -5. * np.ones(n), 5. * np.ones(n), np.zeros(n))
+    assert calls[0] == sol.n_evals
+    assert np.abs(sol.x - 1.).max() < 0.1
+
+
+def test_invalid_swarm_size_is_rejected(hip):
+    g = hip.CCPSO(mfev=1000, sigmatol=1e-5, np=10, pps=[4], seed=3)
+    with pytest.raises(Exception):
+        g.initialize(hip.objectives.sphere, -np.ones(6), np.ones(6), np.zeros(6))
+    with pytest.raises(NotImplementedError):
+        hip.CCPSO(mfev=1000, sigmatol=1e-5, np=10, pps=[2], local=object())
