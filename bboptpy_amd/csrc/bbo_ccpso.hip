@@ -108,14 +108,8 @@ void CcpsoEngine::init(int n, const double *lower, const double *upper, const do
     c.honor_stop = 0;
     inited_ = true;
 
-    static bool attr_done = false;
-    if (!attr_done) {
-        BBO_HIP(hipFuncSetAttribute((const void*) ccp_init,
-                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        BBO_HIP(hipFuncSetAttribute((const void*) ccp_eval<16>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
-    }
+    allow_lds((const void*) ccp_init, 128 * 1024);
+    allow_lds((const void*) ccp_eval<16>, 128 * 1024);
     hipLaunchKernelGGL(ccp_init, dim3((c.np + 15) / 16, P), dim3(256),
             (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
     BBO_HIP(hipGetLastError());

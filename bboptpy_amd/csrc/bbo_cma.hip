@@ -287,14 +287,8 @@ void CmaEngine::launch_post(int mode)
     const CmaConst &c = c_;
     if (c.ld <= 128) {
         const size_t lds = (size_t) (c.ld * (c.ld + 2) + c.ld) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma<1>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_post_mfma<4>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_post_mfma<1>, 140 * 1024);
+        allow_lds((const void*) cma_post_mfma<4>, 140 * 1024);
         // few populations: four workgroups each (latency); many: one (no redundant staging)
         if (c.npop < 32)
             hipLaunchKernelGGL(cma_post_mfma<4>, dim3(c.npop, 4), dim3(256), lds, stream_, d_, c_,
@@ -315,14 +309,8 @@ void CmaEngine::launch_sample_eval()
     timer_.begin(stream_, K_SAMPLE);
     if (c.variant == 2) {
         // separable: 16 lanes per candidate for short rows, one wavefront per candidate beyond
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) sep_sample_eval<16>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            BBO_HIP(hipFuncSetAttribute((const void*) sep_sample_eval<64>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_done = true;
-        }
+        allow_lds((const void*) sep_sample_eval<16>, 128 * 1024);
+        allow_lds((const void*) sep_sample_eval<64>, 128 * 1024);
         if (c.ld <= 256) {   // (beyond that the 16-row LDS tile would leave one workgroup per CU)
             const size_t lds = (size_t) 16 * c.ld * sizeof(double);
             hipLaunchKernelGGL(sep_sample_eval<16>, dim3((c.lambda_pad + 15) / 16, c.npop),
@@ -343,12 +331,7 @@ void CmaEngine::launch_sample_eval()
         // one workgroup per CU when the populations allow it: long tile loops amortise the fill
         int rw = (int) (((long) c.npop * c.lambda_pad / 256 + 127) / 128) * 128;
         rw = std::max(128, std::min(4096, rw));
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval128,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_sample_eval128, 128 * 1024);
         dim3 grid((c.lambda_pad + rw - 1) / rw, c.npop);
         hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw);
         zn_valid = true;
@@ -356,14 +339,8 @@ void CmaEngine::launch_sample_eval()
         // 64 candidates per workgroup, packed operand held in registers
         dim3 grid((c.lambda_pad + 63) / 64, c.npop);
         const size_t lds = (size_t) 64 * (c.ld + 2) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval64<1>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_sample_eval64<2>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_sample_eval64<1>, 80 * 1024);
+        allow_lds((const void*) cma_sample_eval64<2>, 80 * 1024);
         if (c.ld <= 64)
             hipLaunchKernelGGL(cma_sample_eval64<1>, grid, dim3(256), lds, stream_, d_, c_);
         else
@@ -394,12 +371,7 @@ void CmaEngine::launch_rank()
     if (c.lambda <= SORT_LDS_MAX && c.npop >= 4) {
         int m = 2;
         while (m < c.lambda) m <<= 1;
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_rank_sort,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX * 12));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_rank_sort, SORT_LDS_MAX * 12);
         hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(1024), (size_t) m * 12, stream_, d_,
                 c_, m);
     } else {
@@ -430,12 +402,7 @@ void CmaEngine::launch_update()
             int rw = (int) (((long) c.npop * c.mu_pad / 256 + 127) / 128) * 128;
             rw = std::max(128, std::min(2048, rw));
             const size_t lds = (size_t) (128 * 128 + 128) * sizeof(double);
-            static bool attr_done = false;
-            if (!attr_done) {
-                BBO_HIP(hipFuncSetAttribute((const void*) cma_whiten128,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
-                attr_done = true;
-            }
+            allow_lds((const void*) cma_whiten128, 132 * 1024);
             dim3 grid128((c.mu_pad + rw - 1) / rw, c.npop);
             hipLaunchKernelGGL(cma_whiten128, grid128, dim3(512), lds, stream_, d_, c_, rw);
         } else {
@@ -453,12 +420,7 @@ void CmaEngine::launch_update()
     }
     if (c.ld == 128) {
         const size_t lds = (size_t) (2 * G128_CH * G128_LDY + 4 * G128_CH) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_gram128,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_gram128, 80 * 1024);
         timer_.begin(stream_, K_GRAM);
         hipLaunchKernelGGL(cma_gram128, dim3(c.splits, c.npop), dim3(256), lds, stream_, d_, c_);
         timer_.end(stream_);
@@ -469,12 +431,7 @@ void CmaEngine::launch_update()
         dim3 grid(c.splits, (LT + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW), c.npop);
         const int rpp = 256 / (c.ld / 4) > 0 ? 256 / (c.ld / 4) : 1;
         const size_t lds = (size_t) (c.rps * ldy + 2 * c.rps + (size_t) rpp * c.ld) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) cma_gram,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            attr_done = true;
-        }
+        allow_lds((const void*) cma_gram, 160 * 1024 - 64);
         timer_.begin(stream_, K_GRAM);
         hipLaunchKernelGGL(cma_gram, grid, dim3(256), lds, stream_, d_, c_, ldy);
         timer_.end(stream_);
@@ -499,12 +456,7 @@ void CmaEngine::launch_eigen()
     const CmaConst &c = c_;
     if (c.variant == 2) return;        // diagonal covariance: d = sqrt(c) is part of sep_paths
     const EigPlan pl = eig_plan(c.n, c.ld);
-    static bool attr_done = false;
-    if (!attr_done) {
-        BBO_HIP(hipFuncSetAttribute((const void*) cma_eigen,
-                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 768));
-        attr_done = true;
-    }
+    allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
     hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
             c_, pl, 0);

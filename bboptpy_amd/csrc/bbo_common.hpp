@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -140,6 +142,21 @@ private:
     size_t used_ = 0;
     bool on_ = false;
 };
+
+// Raises a kernel's dynamic-LDS ceiling (hipFuncAttributeMaxDynamicSharedMemorySize), once
+// per (device, kernel): the attribute belongs to the device the call is made on, and a process
+// may hold handles on several devices.
+inline void allow_lds(const void *fn, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    BBO_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({ dev, fn })) return;
+    BBO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({ dev, fn });
+}
 
 // how the population's fitness is obtained
 struct ObjectiveSpec {

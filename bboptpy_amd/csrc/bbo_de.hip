@@ -155,12 +155,7 @@ void DeEngine::launch_rank(int which_next, int np_bound)
     if (np_bound <= SORT_LDS_MAX && c.npop >= 4) {
         int m = 2;
         while (m < np_bound) m <<= 1;
-        static bool attr_done = false;
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) de_rank_sort,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX * 12));
-            attr_done = true;
-        }
+        allow_lds((const void*) de_rank_sort, SORT_LDS_MAX * 12);
         hipLaunchKernelGGL(de_rank_sort, dim3(c.npop), dim3(1024), (size_t) m * 12, stream_, d_,
                 c_, which_next, m);
     } else {

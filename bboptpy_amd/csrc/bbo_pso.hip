@@ -169,13 +169,8 @@ void PsoEngine::generation(bool honor_stop)
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_ESE);
     {
-        static bool attr_done = false;
         const size_t lds = (size_t) (4 * ESE2_TILE + 256) * sizeof(double);
-        if (!attr_done) {
-            BBO_HIP(hipFuncSetAttribute((const void*) pso_ese_sym,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            attr_done = true;
-        }
+        allow_lds((const void*) pso_ese_sym, (int) lds);
         hipLaunchKernelGGL(pso_ese_sym, dim3((c.np + 127) / 128, P), dim3(256), lds, stream_, d_,
                 c_);
         hipLaunchKernelGGL(pso_ese_finish, dim3((c.np + 255) / 256, P), dim3(256), 0, stream_, d_,
