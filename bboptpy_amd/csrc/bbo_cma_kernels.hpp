@@ -41,6 +41,36 @@ __device__ inline bool pop_frozen(const CmaConst &c, const CmaScal *sc)
     return c.honor_stop && sc->stop != 0;
 }
 
+// The four normals Philox call q of candidate `row` delivers: columns cma_quad_col0(q) + 4 i,
+// i = 0..3 -- one lane's A-fragment elements of four consecutive k-steps.  Injected Z
+// (parity tests) and the Z recorder go through the same mapping.  tab: normal_table_fill'ed.
+__device__ inline void cma_draw_quad(const CmaDev &d, const CmaConst &c, int p, int row, int q,
+        int gen, uint32_t sw, const double2 *tab, double (&z)[4])
+{
+    const int j0 = cma_quad_col0(q);
+    z[0] = z[1] = z[2] = z[3] = 0.;
+    if (row < c.lambda && j0 < c.n) {
+        if (d.zinject) {
+            const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (j0 + 4 * i < c.n) z[i] = zi[j0 + 4 * i];
+        } else {
+            normal_quad(c.seed, (uint32_t) row, (uint32_t) q, (uint32_t) gen, sw, tab, z[0], z[1],
+                    z[2], z[3]);
+#pragma unroll
+            for (int i = 1; i < 4; i++)
+                if (j0 + 4 * i >= c.n) z[i] = 0.;
+        }
+        if (d.zrecord) {
+            double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (j0 + 4 * i < c.n) zr[j0 + 4 * i] = z[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // sample + evaluate: X = m + sigma * Z (B diag D)^T, f = objective(X)
 // grid (lambda_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles
@@ -56,30 +86,19 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     const int ld = c.ld, ldz = ld + 2;
     const int gen = sc->it;
 
-    // 1. the standard normals of these 16 candidates (Box-Muller pairs)
-    const int npairs = ld >> 1;
-    for (int q = tid; q < 16 * npairs; q += 256) {
-        const int r = q / npairs, pj = q - r * npairs;
-        const int row = mt * 16 + r, j0 = cma_pair_col0(pj), j1 = j0 + 4;
-        double z0 = 0., z1 = 0.;
-        if (row < c.lambda && j0 < c.n) {
-            if (d.zinject) {
-                const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                z0 = zi[j0];
-                z1 = (j1 < c.n) ? zi[j1] : 0.;
-            } else {
-                normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
-                        stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
-                if (j1 >= c.n) z1 = 0.;
-            }
-            if (d.zrecord) {
-                double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                zr[j0] = z0;
-                if (j1 < c.n) zr[j1] = z1;
-            }
-        }
-        lds[r * ldz + j0] = z0;
-        lds[r * ldz + j1] = z1;
+    // 1. the standard normals of these 16 candidates (four per Philox call)
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    normal_table_fill(ntab, tid, 256);
+    __syncthreads();
+    const int nquads = ld >> 2;
+    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+    for (int qi = tid; qi < 16 * nquads; qi += 256) {
+        const int r = qi / nquads, q = qi - r * nquads;
+        double z[4];
+        cma_draw_quad(d, c, p, mt * 16 + r, q, gen, sw, ntab, z);
+        const int j0 = cma_quad_col0(q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) lds[r * ldz + j0 + 4 * i] = z[i];
     }
     __syncthreads();
 
@@ -168,30 +187,19 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
             bfr[t][ks] = (nt < NT && ks < KS) ? bdp[((size_t) nt * KS + ks) * 64 + lane] : 0.;
     }
 
-    // standard normals of the 64 candidates (Box-Muller pairs)
-    const int npairs = ld >> 1;
-    for (int q = tid; q < 64 * npairs; q += 256) {
-        const int r = q / npairs, pj = q - r * npairs;
-        const int row = row0 + r, j0 = cma_pair_col0(pj), j1 = j0 + 4;
-        double z0 = 0., z1 = 0.;
-        if (row < c.lambda && j0 < c.n) {
-            if (d.zinject) {
-                const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                z0 = zi[j0];
-                z1 = (j1 < c.n) ? zi[j1] : 0.;
-            } else {
-                normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen,
-                        stream_word(STREAM_CMA_NORMAL, (uint32_t) p), z0, z1);
-                if (j1 >= c.n) z1 = 0.;
-            }
-            if (d.zrecord) {
-                double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                zr[j0] = z0;
-                if (j1 < c.n) zr[j1] = z1;
-            }
-        }
-        lds[r * ldz + j0] = z0;
-        lds[r * ldz + j1] = z1;
+    // standard normals of the 64 candidates (four per Philox call)
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    normal_table_fill(ntab, tid, 256);
+    __syncthreads();
+    const int nquads = ld >> 2;
+    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+    for (int qi = tid; qi < 64 * nquads; qi += 256) {
+        const int r = qi / nquads, q = qi - r * nquads;
+        double z[4];
+        cma_draw_quad(d, c, p, row0 + r, q, gen, sw, ntab, z);
+        const int j0 = cma_quad_col0(q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) lds[r * ldz + j0 + 4 * i] = z[i];
     }
     __syncthreads();
 
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 // the packed (B D) operand of the population sits in LDS (128 KB, loaded once per
 // workgroup), each wavefront owns whole 16-candidate tiles: it DRAWS the normals straight
 // into its MFMA A fragments (the Philox column layout is the fragment layout, see
-// cma_pair_col0), sweeps the 8 column tiles, and evaluates the objective on the
+// cma_quad_col0), sweeps the 8 column tiles, and evaluates the objective on the
 // accumulators.  No LDS traffic besides the B fragments, no barrier after the fill.
 // grid (ceil(lambda_pad / rows_per_wg), P), 512 threads, dynamic LDS 128 KB
 // ---------------------------------------------------------------------------
@@ -320,6 +328,8 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
 #pragma unroll
         for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
     }
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    normal_table_fill(ntab, tid, 512);
     __syncthreads();
     // (fp64 MFMA and fp64 VALU do not overlap on gfx950 -- measured: draw-only + sweep-only
     // times add up to the full kernel whatever the wave priorities -- so the draw is priced in
@@ -338,34 +348,20 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
         double zz = 0.;
-        // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk], then sweep them
+        // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk] (two Philox calls),
+        // then sweep them
 #pragma unroll 1
         for (int kc = 0; kc < 4; kc++) {
             double a[8];
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const int q = 4 * kc + qq;
-                const int j0 = 8 * q + fk, j1 = j0 + 4;
-                double z0 = 0., z1 = 0.;
-                if (row < c.lambda && j0 < c.n) {
-                    if (d.zinject) {
-                        const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                        z0 = zi[j0];
-                        z1 = (j1 < c.n) ? zi[j1] : 0.;
-                    } else {
-                        normal_pair(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk),
-                                (uint32_t) gen, sw, z0, z1);
-                        if (j1 >= c.n) z1 = 0.;
-                    }
-                    if (d.zrecord) {
-                        double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                        zr[j0] = z0;
-                        if (j1 < c.n) zr[j1] = z1;
-                    }
+            for (int h = 0; h < 2; h++) {
+                double z[4];
+                cma_draw_quad(d, c, p, row, 4 * (2 * kc + h) + fk, gen, sw, ntab, z);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    a[4 * h + i] = z[i];
+                    zz = __builtin_fma(z[i], z[i], zz);
                 }
-                a[2 * qq] = z0;
-                a[2 * qq + 1] = z1;
-                zz += z0 * z0 + z1 * z1;
             }
             const double *bk = bd + kc * 8 * 64 + lane;
 #pragma unroll

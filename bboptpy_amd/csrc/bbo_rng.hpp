@@ -153,9 +153,98 @@ __device__ inline void normal_pair(uint64_t seed, uint32_t c0, uint32_t c1, uint
     z1 = r * s;
 }
 
-// CMA-ES sampling: pair pj of a candidate fills columns 8 (pj >> 2) + (pj & 3) and that + 4,
-// i.e. exactly the two k-steps lane group (pj & 3) feeds to the MFMA A operand
-__host__ __device__ inline int cma_pair_col0(int pj) { return 8 * (pj >> 2) + (pj & 3); }
+// ---------------------------------------------------------------------------
+// normal_quad: the samplers' generator -- ONE Philox call -> FOUR standard normals (two
+// Box-Muller pairs from 32 + 32 bits each), about half the instructions of two normal_pair
+// calls.  Per pair:
+//   radius  r = sqrt(-2 ln u), u = (a + 1) 2^-32 in (0, 1]      (|z| <= 6.66)
+//           -2 ln u from a 91-entry table in LDS (bbo_normal_table.inc; bin width 1/128 on
+//           m in [0.70703125, 1.4140625), centre 1 exactly in bin 37) and a degree-8
+//           polynomial in r = m inv_i - 1, |r| < 2^-7.5: no division
+//   angle   x = (k + 1/2) (pi/4) 2^-29 in (0, pi/4) from 29 bits, fdlibm kernels, and three
+//           more bits pick one of the 8 symmetries of the square (swap, -sin, -cos): a
+//           uniform direction without the octant bookkeeping
+// Only +, *, fma, frexp/ldexp, sqrt: oracle/philox.h (bbo_normal_quad) gets the same bits.
+// ---------------------------------------------------------------------------
+static __device__ const double NORMAL_TABLE[91][2] = {
+#include "bbo_normal_table.inc"
+};
+constexpr int NORMAL_TABLE_N = 91;
+
+// cooperative copy of the table into LDS (caller synchronises)
+__device__ inline void normal_table_fill(double2 *tab, int tid, int nthreads)
+{
+    for (int i = tid; i < NORMAL_TABLE_N; i += nthreads)
+        tab[i] = make_double2(NORMAL_TABLE[i][0], NORMAL_TABLE[i][1]);
+}
+
+// -2 ln((a + 1) 2^-32)
+__device__ inline double neg2log32(uint32_t a, const double2 *tab)
+{
+    const double d = (double) a + 1.;                       // 1 .. 2^32, exact
+    double m = __builtin_amdgcn_frexp_mant(d);              // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(d);                  // d = m 2^e
+    const int s = m < 0.70703125 ? 1 : 0;
+    m = __builtin_amdgcn_ldexp(m, s);                       // [0.70703125, 1.4140625)
+    e -= s;
+    const int i = (int) __builtin_fma(m, 128., -90.5);      // exact; floor
+    const double2 ent = tab[i];
+    const double r = __builtin_fma(m, ent.x, -1.);
+    double p = 2. / 8.;
+    p = __builtin_fma(p, r, -2. / 7.);
+    p = __builtin_fma(p, r, 2. / 6.);
+    p = __builtin_fma(p, r, -2. / 5.);
+    p = __builtin_fma(p, r, 2. / 4.);
+    p = __builtin_fma(p, r, -2. / 3.);
+    p = __builtin_fma(p, r, 1.);
+    p = __builtin_fma(p, r, -2.);
+    const double base = __builtin_fma((double) (32 - e), 0x1.62e42fefa39efp+0, ent.y);
+    return __builtin_fma(p, r, base);
+}
+
+// (sin, cos) of a uniform direction from 32 bits
+__device__ inline void sincos_oct(uint32_t b, double &sn, double &cs)
+{
+    const double x = __builtin_fma((double) (b >> 3), 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sx = __builtin_fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cx = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.));
+    const bool sw = (b & 1u) != 0;
+    const double s0 = sw ? cx : sx, c0 = sw ? sx : cx;
+    sn = __longlong_as_double(__double_as_longlong(s0) ^ ((long long) (b & 2u) << 62));
+    cs = __longlong_as_double(__double_as_longlong(c0) ^ ((long long) (b & 4u) << 61));
+}
+
+__device__ inline void normal_quad(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
+        uint32_t c3, const double2 *tab, double &z0, double &z1, double &z2, double &z3)
+{
+    const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
+    double s, c;
+    const double ra = sqrt(neg2log32(w.x, tab));
+    sincos_oct(w.y, s, c);
+    z0 = ra * c;
+    z1 = ra * s;
+    const double rb = sqrt(neg2log32(w.z, tab));
+    sincos_oct(w.w, s, c);
+    z2 = rb * c;
+    z3 = rb * s;
+}
+
+// CMA-ES sampling: Philox call q of a candidate fills columns 16 (q >> 2) + (q & 3) + 4 i,
+// i = 0..3, i.e. exactly the four k-steps lane group (q & 3) feeds to the MFMA A operand
+__host__ __device__ inline int cma_quad_col0(int q) { return 16 * (q >> 2) + (q & 3); }
 
 // Keyed bijection of [0, np): 4-round Feistel network on 2 kb bits (kb = half the bits of
 // np - 1, rounded up), one Philox word per round keyed by (half-word, 8 + round, generation),

@@ -22,7 +22,7 @@ namespace bbo {
 // sample + evaluate: x = m + sigma d z (sep_cmaes.cpp:73), G lanes per candidate, the row
 // staged in LDS for the objective.  grid (ceil(lambda_pad / (256/G)), P), 256 threads,
 // dynamic LDS (256/G) * ld doubles.  Normals: the same (candidate, column) -> Philox mapping
-// as the full-covariance sampler (cma_pair_col0), so the oracle's statement covers both.
+// as the full-covariance sampler (cma_quad_col0), so the oracle's statement covers both.
 // ---------------------------------------------------------------------------
 template<int G>
 __global__ __launch_bounds__(256) void sep_sample_eval(CmaDev d, CmaConst c)
@@ -40,38 +40,25 @@ __global__ __launch_bounds__(256) void sep_sample_eval(CmaDev d, CmaConst c)
     const double *xm = d.xmean + (size_t) p * ld, *dd = d.D + (size_t) p * ld;
     double *Xp = d.X + ((size_t) p * c.lambda_pad + row) * ld;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    normal_table_fill(ntab, tid, 256);
+    __syncthreads();
     if (row < c.lambda_pad) {
-        for (int pj = g; pj < ld / 2; pj += G) {
-            const int j0 = cma_pair_col0(pj), j1 = j0 + 4;
-            double z0 = 0., z1 = 0.;
-            if (row < c.lambda && j0 < c.n) {
-                if (d.zinject) {
-                    const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
-                    z0 = zi[j0];
-                    z1 = j1 < c.n ? zi[j1] : 0.;
-                } else {
-                    normal_pair(c.seed, (uint32_t) row, (uint32_t) pj, (uint32_t) gen, sw, z0, z1);
-                    if (j1 >= c.n) z1 = 0.;
+        for (int q = g; q < ld / 4; q += G) {
+            double z[4];
+            cma_draw_quad(d, c, p, row, q, gen, sw, ntab, z);
+            const int j0 = cma_quad_col0(q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = j0 + 4 * i;
+                double v = 0.;
+                if (j < c.n) {
+                    v = xm[j] + sigma * dd[j] * z[i];
+                    if (c.bound) v = fmax(d.lower[j], fmin(v, d.upper[j]));
                 }
-                if (d.zrecord) {
-                    double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
-                    zr[j0] = z0;
-                    if (j1 < c.n) zr[j1] = z1;
-                }
+                xr[j] = v;
+                Xp[j] = v;
             }
-            double v0 = 0., v1 = 0.;
-            if (j0 < c.n) {
-                v0 = xm[j0] + sigma * dd[j0] * z0;
-                if (c.bound) v0 = fmax(d.lower[j0], fmin(v0, d.upper[j0]));
-            }
-            if (j1 < c.n) {
-                v1 = xm[j1] + sigma * dd[j1] * z1;
-                if (c.bound) v1 = fmax(d.lower[j1], fmin(v1, d.upper[j1]));
-            }
-            xr[j0] = v0;
-            xr[j1] = v1;
-            Xp[j0] = v0;
-            Xp[j1] = v1;
         }
     }
     __syncthreads();

@@ -101,9 +101,13 @@ def cma_kernel_costs(n, lam, P):
     """algorithmic work of ONE launch (all P populations), SURVEY.md section 8d:
     flops for the MFMA-bound kernels, bytes for the bandwidth-bound ones"""
     mu = lam // 2
+    # n <= 128, unbounded: the sampler hands down ||z||^2 and the whitening GEMM (mu 2n^2
+    # flops) is not executed at all -- the kernel gathers mu norms through the ranking
+    # (DESIGN.md "whitened norms"); beyond that it is the GEMM
+    whiten = ("hbm", P * mu * 12) if n <= 128 else ("mfma", P * mu * 2 * n * n)
     return {
         "cma_sample_eval": ("mfma", P * lam * (2 * n * n + 8 * n)),
-        "cma_whiten": ("mfma", P * mu * 2 * n * n),
+        "cma_whiten": whiten,
         "cma_gram": ("mfma", P * lam * n * (n + 1)),      # lower triangle only, like the reference
         "cma_eigen": ("mfma", P * 9 * n ** 3),
         "cma_post": ("mfma", P * 2 * n ** 3),

@@ -423,10 +423,10 @@ struct Cma {
         if (rng_mode == RNG_MT) return Z.draw();
         if (rng_mode == RNG_INJECT) return zinject[(size_t) k * n + j];
         /* RNG_PHILOX: column j of candidate k in generation `it` (layout: philox.h) */
-        double z0, z1;
-        bbo_normal_pair(seed, (uint32_t) k, (uint32_t) bbo_cma_pair_of_column(j), (uint32_t) it,
-                bbo_stream(BBO_STREAM_CMA_NORMAL, 0), &z0, &z1);
-        return bbo_cma_half_of_column(j) ? z1 : z0;
+        double z[4];
+        bbo_normal_quad(seed, (uint32_t) k, (uint32_t) bbo_cma_quad_of_column(j), (uint32_t) it,
+                bbo_stream(BBO_STREAM_CMA_NORMAL, 0), z);
+        return z[bbo_cma_slot_of_column(j)];
     }
 
     /* cmaes.cpp:65-80 */
@@ -1048,14 +1048,16 @@ void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 }
 double orc_log_unit(double u) { return bbo_log_unit(u); }
 void orc_sincos_turn(double t, double *s, double *c) { bbo_sincos_turn(t, s, c); }
+double orc_neg2log32(uint32_t a) { return bbo_neg2log32(a); }
+void orc_sincos_oct(uint32_t b, double *s, double *c) { bbo_sincos_oct(b, s, c); }
 void orc_philox_normals(uint64_t seed, int gen, int rows, int n, double *out)
 {
     for (int k = 0; k < rows; k++)
         for (int j = 0; j < n; j++) {
-            double z0, z1;
-            bbo_normal_pair(seed, (uint32_t) k, (uint32_t) bbo_cma_pair_of_column(j),
-                    (uint32_t) gen, bbo_stream(BBO_STREAM_CMA_NORMAL, 0), &z0, &z1);
-            out[(size_t) k * n + j] = bbo_cma_half_of_column(j) ? z1 : z0;
+            double z[4];
+            bbo_normal_quad(seed, (uint32_t) k, (uint32_t) bbo_cma_quad_of_column(j),
+                    (uint32_t) gen, bbo_stream(BBO_STREAM_CMA_NORMAL, 0), z);
+            out[(size_t) k * n + j] = z[bbo_cma_slot_of_column(j)];
         }
 }
 

@@ -175,11 +175,88 @@ static inline void bbo_normal_pair(uint64_t seed, uint32_t c0, uint32_t c1,
 }
 
 /*
- * CMA-ES sampling: which columns of a candidate the pair `pj` fills.  The layout follows the
- * MFMA A-fragment of the device kernel (lane k-group kk = pj & 3 of k-block pair q = pj >> 2
- * holds columns 8q + kk and 8q + 4 + kk), so a lane draws exactly the normals it multiplies.
+ * The samplers' generator (device twin: normal_quad in bbo_rng.hpp): ONE Philox call -> FOUR
+ * standard normals, two Box-Muller pairs from 32 + 32 bits each.
+ *   radius^2 = -2 ln u, u = (a + 1) 2^-32: table of 91 (1/c_i, 2 ln(1/c_i)) pairs on
+ *              m in [0.70703125, 1.4140625) (normal_table.inc, generated by
+ *              scripts/gen_normal_table.py) + degree-8 polynomial in r = m/c_i - 1
+ *   direction  x = (k + 1/2)(pi/4) 2^-29 from 29 bits, fdlibm kernels on (0, pi/4), three
+ *              more bits choose among the 8 symmetries of the square
  */
-static inline int bbo_cma_pair_of_column(int j) { return ((j >> 3) << 2) | (j & 3); }
-static inline int bbo_cma_half_of_column(int j) { return (j >> 2) & 1; }
+static const double bbo_normal_table[91][2] = {
+#include "normal_table.inc"
+};
+
+static inline double bbo_neg2log32(uint32_t a)
+{
+    const double d = (double) a + 1.;
+    int e;
+    double m = frexp(d, &e);                 /* [1/2, 1) */
+    if (m < 0.70703125) {
+        m *= 2.;
+        e -= 1;
+    }
+    const int i = (int) fma(m, 128., -90.5);
+    const double inv = bbo_normal_table[i][0], t2 = bbo_normal_table[i][1];
+    const double r = fma(m, inv, -1.);
+    double p = 2. / 8.;
+    p = fma(p, r, -2. / 7.);
+    p = fma(p, r, 2. / 6.);
+    p = fma(p, r, -2. / 5.);
+    p = fma(p, r, 2. / 4.);
+    p = fma(p, r, -2. / 3.);
+    p = fma(p, r, 1.);
+    p = fma(p, r, -2.);
+    const double base = fma((double) (32 - e), 0x1.62e42fefa39efp+0, t2);
+    return fma(p, r, base);
+}
+
+static inline void bbo_sincos_oct(uint32_t b, double *sn, double *cs)
+{
+    const double x = fma((double) (b >> 3), 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sx = fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cx = fma(z * z, pc, fma(z, -0.5, 1.));
+    const double s0 = (b & 1u) ? cx : sx, c0 = (b & 1u) ? sx : cx;
+    *sn = (b & 2u) ? -s0 : s0;
+    *cs = (b & 4u) ? -c0 : c0;
+}
+
+static inline void bbo_normal_quad(uint64_t seed, uint32_t c0, uint32_t c1,
+        uint32_t c2, uint32_t c3, double z[4])
+{
+    uint32_t w[4];
+    bbo_philox(seed, c0, c1, c2, c3, w);
+    double sn, cs;
+    const double ra = sqrt(bbo_neg2log32(w[0]));
+    bbo_sincos_oct(w[1], &sn, &cs);
+    z[0] = ra * cs;
+    z[1] = ra * sn;
+    const double rb = sqrt(bbo_neg2log32(w[2]));
+    bbo_sincos_oct(w[3], &sn, &cs);
+    z[2] = rb * cs;
+    z[3] = rb * sn;
+}
+
+/*
+ * CMA-ES sampling: Philox call q of a candidate fills columns 16 (q >> 2) + (q & 3) + 4 i,
+ * i = 0..3, with its four normals.  The layout follows the MFMA A fragment of the device
+ * kernel (lane k-group q & 3 feeds k-steps 4 (q >> 2) .. + 3), so a lane draws exactly the
+ * normals it multiplies.
+ */
+static inline int bbo_cma_quad_of_column(int j) { return ((j >> 4) << 2) | (j & 3); }
+static inline int bbo_cma_slot_of_column(int j) { return (j >> 2) & 3; }
 
 #endif /* BBO_ORACLE_PHILOX_H_ */

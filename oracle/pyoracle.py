@@ -149,6 +149,12 @@ class _Lib:
                 f("sincos_turn").argtypes = [C.c_double, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]
                 f("sincos_turn").restype = None
+            if hasattr(L, p + "neg2log32"):
+                f("neg2log32").argtypes = [C.c_uint32]
+                f("neg2log32").restype = C.c_double
+                f("sincos_oct").argtypes = [C.c_uint32, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double)]
+                f("sincos_oct").restype = None
             if hasattr(L, p + "pop_set_mode"):
                 f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
                 f("pop_set_mode").restype = None

@@ -8,6 +8,9 @@ template<int V>
 __global__ __launch_bounds__(256) void k(double *out, int reps)
 {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double2 tab[NORMAL_TABLE_N];
+    normal_table_fill(tab, threadIdx.x, 256);
+    __syncthreads();
     double acc = 0.;
     for (int i = 0; i < reps; i++) {
         if (V == 0) {
@@ -28,6 +31,16 @@ __global__ __launch_bounds__(256) void k(double *out, int reps)
             double s, c;
             sincospi(2. * u2, &s, &c);
             acc += r * c + r * s;
+        } else if (V == 12) {
+            double a, b, c2, d2;
+            normal_quad(1234, tid, i, 7, 1 << 24, tab, a, b, c2, d2);
+            acc += a + b + c2 + d2;
+        } else if (V == 13) {
+            acc += neg2log32(tid * 977u + i * 31u, tab);
+        } else if (V == 14) {
+            double s, c;
+            sincos_oct(tid * 977u + i * 31u, s, c);
+            acc += s + c;
         } else if (V == 7) {
             const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
             acc += log_unit(u1);
@@ -99,5 +112,8 @@ int main()
     run<9>("sqrt", out);
     run<10>("division", out);
     run<11>("philox+u01 x2", out);
+    run<12>("normal_quad (4 normals)", out);
+    run<13>("neg2log32", out);
+    run<14>("sincos_oct", out);
     return 0;
 }

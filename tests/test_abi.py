@@ -150,6 +150,39 @@ def test_device_normal_arithmetic_is_accurate(oracle_lib):
     assert float(np.abs(np.array(Cc) - np.cos(ang)).max()) <= 4 * 2.0 ** -53
 
 
+def test_sampler_normal_arithmetic_is_accurate(oracle_lib):
+    """The pieces of the samplers' four-normals-per-Philox-call generator (normal_quad in
+    bbo_rng.hpp, bbo_normal_quad in oracle/philox.h): table-driven -2 ln((a+1) 2^-32) and the
+    direction from 32 bits, against long-double libm."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.integers(0, 2 ** 32, 20000, dtype=np.uint64),
+                        [0, 1, 2, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1],
+                        2 ** rng.integers(0, 32, 200, dtype=np.uint64) - 1]).astype(np.uint64)
+    got = np.array([oracle_lib.f("neg2log32")(int(x)) for x in a])
+    ref = -2 * np.log((a.astype(np.longdouble) + 1) / np.longdouble(2 ** 32))
+    rel = np.abs((got - ref) / np.where(ref == 0, 1, ref)).astype(float)
+    assert rel.max() <= 4 * 2.0 ** -53
+    assert oracle_lib.f("neg2log32")(2 ** 32 - 1) == 0.0           # u = 1
+    assert (got >= 0).all()
+    s, c = ctypes.c_double(), ctypes.c_double()
+    worst = 0.
+    quarter_pi = np.arctan(np.longdouble(1))
+    for b in rng.integers(0, 2 ** 32, 20000, dtype=np.uint64):
+        b = int(b)
+        oracle_lib.f("sincos_oct")(b, ctypes.byref(s), ctypes.byref(c))
+        x = (np.longdouble(b >> 3) + np.longdouble(0.5)) * quarter_pi / np.longdouble(2 ** 29)
+        ss, cc = np.sin(x), np.cos(x)
+        if b & 1:
+            ss, cc = cc, ss
+        if b & 2:
+            ss = -ss
+        if b & 4:
+            cc = -cc
+        worst = max(worst, abs(float(ss - s.value)), abs(float(cc - c.value)))
+    assert worst <= 4 * 2.0 ** -53
+
+
 def test_philox_normals_are_standard_normal(oracle_lib):
     """Distribution check of the generator the device uses (mean, variance, KS distance) and of
     the CMA column layout (every column of a row is filled exactly once)."""
