@@ -16,6 +16,8 @@
 // The matrix lives in LDS when it fits (n <= 128), else in HBM/L2.
 #pragma once
 
+#include <type_traits>
+
 #include "bbo_cma.hpp"
 #include "bbo_eig_ql.hpp"
 #include "bbo_eig_dc.hpp"
@@ -183,13 +185,17 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         hvec[k] = 0.;
     }
 
-    for (int i = n - 1; i > 0; i--) {
+    // One Householder step, specialised on how many 32-column groups the active block (rows and
+    // columns < i) still covers: the matrix-vector product and the rank-2 update then shrink with
+    // it instead of multiplying the zeros beyond column i.
+    auto step = [&](int i, auto amax_tag) {
+        constexpr int AMAX = decltype(amax_tag)::value;
         if ((tid >> 6) * 16 >= i) {
             // this wavefront's 16 rows are finished (the active block is rows < i): it only
             // keeps the two barriers of the step company and leaves the SIMD to the others
             __syncthreads();
             __syncthreads();
-            continue;
+            return;
         }
         __syncthreads();
         const double d0 = lane < i ? dv[lane] : 0.;
@@ -204,50 +210,57 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
             }
             if (j == i - 1) {
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                for (int a = 0; a < AMAX; a++)
 #pragma unroll
                     for (int b = 0; b < 8; b++) dv[32 * a + 8 * q + b] = a_[a][b];
             }
-            continue;
+            return;
         }
         double g = sqrt(h0);
         if (f > 0) g = -g;
         const double h = h0 - f * g;
+        const double rh = 1. / h;
         // every wavefront writes the SAME u (one store per element), so a wavefront may read
         // what it wrote without waiting for the others
         uv[lane] = lane < i ? (lane == i - 1 ? f - g : d0) : 0.;
         uv[lane + 64] = lane + 64 < i ? (lane + 64 == i - 1 ? f - g : d1) : 0.;
         if (tid == 0) ev[i] = g;
-        // g = A u (no bounds tests: u is zero beyond the active block); this thread's 32
+        // g = A u (no bounds tests: u is zero beyond the active block); this thread's
         // entries of u stay in registers for the rank-2 update below
         double ur[4][8];
         {
-            const double acc = tred_matvec<4>(a_, ur, uv, q);
+            const double acc = tred_matvec<AMAX>(a_, ur, uv, q);
             if (q == 0 && j < i) {
                 gv[j] = acc;
                 As(i, j) = uv[j];          // stash: row i = the Householder vector of step i
             }
         }
         __syncthreads();
-        const double rh = 1. / h;
         const double e0 = lane < i ? gv[lane] * rh : 0.;
         const double e1 = lane + 64 < i ? gv[lane + 64] * rh : 0.;
         const double uu0 = uv[lane], uu1 = uv[lane + 64];
-        const double hh = eig_wave_sum(e0 * uu0 + e1 * uu1) / (h + h);
+        const double hh = eig_wave_sum(e0 * uu0 + e1 * uu1) * (0.5 * rh);
         wv[lane] = lane < i ? e0 - hh * uu0 : 0.;
         wv[lane + 64] = lane + 64 < i ? e1 - hh * uu1 : 0.;
         // A -= u w^T + w u^T; rows >= i and columns >= i see zeros and do not move
         {
             const double uj = uv[j], wj = wv[j];
-            tred_rank2<4>(a_, ur, wv, uj, wj, q);
+            tred_rank2<AMAX>(a_, ur, wv, uj, wj, q);
             if (j == i - 1) {
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                for (int a = 0; a < AMAX; a++)
 #pragma unroll
                     for (int b = 0; b < 8; b++) dv[32 * a + 8 * q + b] = a_[a][b];
             }
         }
         if (tid == 0) hvec[i] = h;
+    };
+    {
+        int i = n - 1;
+        for (; i > 96; i--) step(i, std::integral_constant<int, 4>());
+        for (; i > 64; i--) step(i, std::integral_constant<int, 3>());
+        for (; i > 32; i--) step(i, std::integral_constant<int, 2>());
+        for (; i > 0; i--) step(i, std::integral_constant<int, 1>());
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[1] = wall_clock64();

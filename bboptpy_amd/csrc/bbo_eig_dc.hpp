@@ -82,8 +82,9 @@ struct DcWork {
     int *rotp, *rotj;     // rotation row pairs
     int *rowmap;          // original column -> kept index i, or -(1 + output column)
     int *colroot;         // output column -> root j, or -1
-    int *cnt;             // [team][4]: k, ndefl, nrot
+    int *cnt;             // [team][4]: k, ndefl, nrot, 'needs the sequential scan'
     double *red;          // [16] reduction scratch (one slot per wavefront)
+    unsigned long long *balk, *bald;   // [8] per-wavefront ballots: kept / deflated poles
     int *maxnr;           // [1]
 };
 
@@ -173,12 +174,53 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     __syncthreads();
 
     MG_STAMP(25);
-    // ---- deflation (sequential scan, LAPACK dlaed2's rules) ---------------------------
-    if (on && ttid == 0) {
+    // ---- deflation (LAPACK dlaed2's rules).  Fast path, all lanes: drop the poles with a
+    // negligible z, keep the others in order, and test every pair of NEIGHBOURING kept poles
+    // for the close-pole rotation; only if some pair asks for one does lane 0 redo the scan
+    // sequentially (the rotations chain).  Same outcome as the scan whenever none fires.
+    const bool alltiny = rho * zmax <= tol;
+    {
+        const bool mine = ttid < m;
+        const bool tiny = mine && (alltiny || rho * fabs(W.zS[ttid]) <= tol);
+        const unsigned long long bk = __ballot(mine && !tiny), bd = __ballot(tiny);
+        if (lane == 0) {
+            W.balk[tm.wave0 + tm.twave] = bk;
+            W.bald[tm.wave0 + tm.twave] = bd;
+        }
+        if (ttid == 0) W.cnt[3] = 0;
+        __syncthreads();
+        int pk = 0, pd = 0, tk = 0, td = 0;
+        for (int w = 0; w < tm.nwaves; w++) {
+            const int ck = __popcll(W.balk[tm.wave0 + w]), cd = __popcll(W.bald[tm.wave0 + w]);
+            if (w < tm.twave) {
+                pk += ck;
+                pd += cd;
+            }
+            tk += ck;
+            td += cd;
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        pk += __popcll(bk & below);
+        pd += __popcll(bd & below);
+        if (mine && !tiny) W.kp[pk] = ttid;
+        if (tiny) W.dp[pd] = ttid;
+        if (on && ttid == 0) {
+            W.cnt[0] = tk;
+            W.cnt[1] = td;
+            W.cnt[2] = 0;
+        }
+        __syncthreads();
+        if (on && ttid >= 1 && ttid < tk) {
+            const int pj = W.kp[ttid - 1], j = W.kp[ttid];
+            const double zj = W.zS[j], zp = W.zS[pj];
+            const double t = W.dS[j] - W.dS[pj];
+            if (fabs(t * zj * zp) <= tol * (zj * zj + zp * zp)) W.cnt[3] = 1;
+        }
+        __syncthreads();
+    }
+    if (on && ttid == 0 && W.cnt[3]) {
         int k = 0, nd = 0, nr = 0;
-        if (rho * zmax <= tol) {
-            for (int j = 0; j < m; j++) W.dp[nd++] = j;
-        } else {
+        {
             int pj = -1;
             for (int j = 0; j < m; j++) {
                 const double zj = W.zS[j];
@@ -275,17 +317,36 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         for (int it = 0; it < 64; it++) {
             double psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;
             if (!done) {
-                for (int i = sub; i < k; i += LPR) {
-                    const double r = dc_rcp((W.dl[i] - dorg) - mu);
-                    const double t = W.w2[i] * r;
-                    const double tp = t * r;
-                    fabs_ += fabs(t);
-                    if (i <= j) {
-                        psi += t;
-                        dpsi += tp;
+                // the poles up to j feed psi, the rest phi: two runs, four poles at a time
+                // (independent reciprocal chains; fp64 issue is what this loop costs)
+                const int isplit = sub + ((j + 1 - sub + LPR - 1) / LPR) * LPR;   // first i > j
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int ibeg = half ? isplit : sub, iend = half ? k : min(j + 1, k);
+                    double sa = 0., sb = 0.;
+                    for (int i0 = ibeg; i0 < iend; i0 += 4 * LPR) {
+                        double rr[4], ww[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int i = i0 + u * LPR;
+                            const bool in = i < iend;
+                            ww[u] = in ? W.w2[i] : 0.;
+                            rr[u] = dc_rcp(in ? (W.dl[i] - dorg) - mu : 1.);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const double t = ww[u] * rr[u];
+                            fabs_ += fabs(t);
+                            sa += t;
+                            sb = __builtin_fma(t, rr[u], sb);
+                        }
+                    }
+                    if (half) {
+                        phi = sa;
+                        dphi = sb;
                     } else {
-                        phi += t;
-                        dphi += tp;
+                        psi = sa;
+                        dpsi = sb;
                     }
                 }
             }
@@ -330,7 +391,10 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                     else mu = nmu;
                 }
             }
-            if (__syncthreads_count(done ? 0 : 1) == 0) break;
+            if (__syncthreads_count(done ? 0 : 1) == 0) {
+                if (stamps && threadIdx.x == 0 && b - a > 64) stamps[31] = it + 1;
+                break;
+            }
         }
         if (act && sub == 0) {
             W.mu[j] = mu;
@@ -561,6 +625,8 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
         W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
         W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
         W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
+        W.balk = reinterpret_cast<unsigned long long*>(p); p += 8;
+        W.bald = reinterpret_cast<unsigned long long*>(p); p += 8;
         int *ip = reinterpret_cast<int*>(p);
         W.srcS = ip; ip += M; W.kp = ip; ip += M; W.dp = ip; ip += M; W.org = ip; ip += M;
         W.outpos = ip; ip += M; W.rotp = ip; ip += M; W.rotj = ip; ip += M;
