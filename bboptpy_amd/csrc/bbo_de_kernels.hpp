@@ -227,41 +227,58 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
         }
     }
 
-    // ---- mutation + binomial crossover + midpoint bound repair, into LDS ------------------
+    // ---- mutation + binomial crossover + midpoint bound repair, into LDS.  Four column pairs
+    // per lane at a time: all sixteen row loads of the four partners go out before the first
+    // Philox call (the gathers are what this kernel waits for), the arithmetic is select-only ---
     double cnt = 0.;
     const double *xi = nullptr;
+    const int npair = ld >> 1;
+    double2 akeep[4];          // the parent's columns of the first pass (all of them if ld <= 128)
+#pragma unroll
+    for (int u = 0; u < 4; u++) akeep[u] = make_double2(0., 0.);
     if (live) {
         xi = Xc + (size_t) order[i] * ld;
         const double *xb = Xc + (size_t) order[ibest] * ld;
         const double *x1 = Xc + (size_t) order[r1] * ld;
         const double *x2 = r2 >= np ? d.arch + (pbase + (r2 - np)) * ld
                                     : Xc + (size_t) order[r2] * ld;
-        for (int pj = g; pj < ld / 2; pj += 16) {
-            const int j = 2 * pj;
-            const double2 a = *reinterpret_cast<const double2*>(&xi[j]);
-            const double2 b = *reinterpret_cast<const double2*>(&xb[j]);
-            const double2 q1 = *reinterpret_cast<const double2*>(&x1[j]);
-            const double2 q2 = *reinterpret_cast<const double2*>(&x2[j]);
-            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen,
-                    stream_word(STREAM_DE_CROSS, sub));
-            double2 v = a;
-            if (j < n && (j == jrand || u01(w.x, w.y) < CR)) {
-                v.x = a.x + F * (b.x - a.x) + F * (q1.x - q2.x);
-                cnt += 1.;
+        const uint32_t swc = stream_word(STREAM_DE_CROSS, sub);
+        for (int pj0 = g; pj0 < npair; pj0 += 64) {
+            double2 a[4], b[4], q1[4], q2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pj = pj0 + 16 * u;
+                const int j = pj < npair ? 2 * pj : 0;
+                a[u] = *reinterpret_cast<const double2*>(&xi[j]);
+                b[u] = *reinterpret_cast<const double2*>(&xb[j]);
+                q1[u] = *reinterpret_cast<const double2*>(&x1[j]);
+                q2[u] = *reinterpret_cast<const double2*>(&x2[j]);
             }
-            if (j + 1 < n && (j + 1 == jrand || u01(w.z, w.w) < CR)) {
-                v.y = a.y + F * (b.y - a.y) + F * (q1.y - q2.y);
-                cnt += 1.;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pj = pj0 + 16 * u;
+                if (pj < npair) {
+                    const int j = 2 * pj;
+                    if (pj0 == g) akeep[u] = a[u];
+                    const double2 lo = *reinterpret_cast<const double2*>(&d.lower[j]);
+                    const double2 up = *reinterpret_cast<const double2*>(&d.upper[j]);
+                    const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj,
+                            (uint32_t) gen, swc);
+                    const bool cx = j < n && (j == jrand || u01(w.x, w.y) < CR);
+                    const bool cy = j + 1 < n && (j + 1 == jrand || u01(w.z, w.w) < CR);
+                    const double mx = a[u].x + F * (b[u].x - a[u].x) + F * (q1[u].x - q2[u].x);
+                    const double my = a[u].y + F * (b[u].y - a[u].y) + F * (q1[u].y - q2[u].y);
+                    double2 v;
+                    v.x = cx ? mx : a[u].x;
+                    v.y = cy ? my : a[u].y;
+                    cnt += (cx ? 1. : 0.) + (cy ? 1. : 0.);
+                    const double rlx = (lo.x + a[u].x) / 2., rux = (up.x + a[u].x) / 2.;
+                    const double rly = (lo.y + a[u].y) / 2., ruy = (up.y + a[u].y) / 2.;
+                    v.x = j < n ? (v.x < lo.x ? rlx : (v.x > up.x ? rux : v.x)) : v.x;
+                    v.y = j + 1 < n ? (v.y < lo.y ? rly : (v.y > up.y ? ruy : v.y)) : v.y;
+                    *reinterpret_cast<double2*>(&trial[j]) = v;
+                }
             }
-            if (j < n) {
-                if (v.x < d.lower[j]) v.x = (d.lower[j] + a.x) / 2.;
-                else if (v.x > d.upper[j]) v.x = (d.upper[j] + a.x) / 2.;
-            }
-            if (j + 1 < n) {
-                if (v.y < d.lower[j + 1]) v.y = (d.lower[j + 1] + a.y) / 2.;
-                else if (v.y > d.upper[j + 1]) v.y = (d.upper[j + 1] + a.y) / 2.;
-            }
-            *reinterpret_cast<double2*>(&trial[j]) = v;
         }
     }
     __syncthreads();
@@ -291,7 +308,18 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     if (live) {
         fold = fc[order[i]];
         accept = ft <= fold;
-        for (int pj = g; pj < ld / 2; pj += 16) {
+        // (the parent's first 128 columns are still in registers)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pj = g + 16 * u;
+            if (pj < npair) {
+                const int j = 2 * pj;
+                const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j]) : akeep[u];
+                *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + j]) = v;
+                ssq += v.x * v.x + v.y * v.y;
+            }
+        }
+        for (int pj = g + 64; pj < npair; pj += 16) {
             const int j = 2 * pj;
             const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j])
                                      : *reinterpret_cast<const double2*>(&xi[j]);
@@ -389,49 +417,62 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
     r3 = __shfl(r3, 0, 16);
     jrand = __shfl(jrand, 0, 16);
 
+    // (same shape as de_generation: four column pairs per lane, the sixteen gathers first)
     double cnt = 0.;
+    const int npair = ld >> 1;
+    double2 akeep[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) akeep[u] = make_double2(0., 0.);
     if (live) {
         const double *xi = Xc + (size_t) order[i] * ld;
-        const double *xb = Xc + (size_t) order[0] * ld;
         const double *x1 = Xc + (size_t) order[r1] * ld;
         const double *x2 = Xc + (size_t) order[r2] * ld;
-        const double *x3 = Xc + (size_t) order[r3] * ld;
         const bool rand1 = (strat & 1) == 0;
-        for (int pj = g; pj < ld / 2; pj += 16) {
-            const int j = 2 * pj;
-            const double2 a = *reinterpret_cast<const double2*>(&xi[j]);
-            const double2 q1 = *reinterpret_cast<const double2*>(&x1[j]);
-            const double2 q2 = *reinterpret_cast<const double2*>(&x2[j]);
-            double2 m;
-            if (rand1) {
-                const double2 q3 = *reinterpret_cast<const double2*>(&x3[j]);
-                m.x = q1.x + F * (q2.x - q3.x);
-                m.y = q1.y + F * (q2.y - q3.y);
-            } else {
-                const double2 b = *reinterpret_cast<const double2*>(&xb[j]);
-                m.x = a.x + F * (b.x - a.x) + F * (q1.x - q2.x);
-                m.y = a.y + F * (b.y - a.y) + F * (q1.y - q2.y);
+        // fourth partner: r3 for DE/rand/1, the best individual for DE/current-to-best/2
+        const double *x4 = Xc + (size_t) order[rand1 ? r3 : 0] * ld;
+        const uint32_t swc = stream_word(STREAM_DE_CROSS, (uint32_t) p);
+        for (int pj0 = g; pj0 < npair; pj0 += 64) {
+            double2 a[4], q1[4], q2[4], q4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pj = pj0 + 16 * u;
+                const int j = pj < npair ? 2 * pj : 0;
+                a[u] = *reinterpret_cast<const double2*>(&xi[j]);
+                q1[u] = *reinterpret_cast<const double2*>(&x1[j]);
+                q2[u] = *reinterpret_cast<const double2*>(&x2[j]);
+                q4[u] = *reinterpret_cast<const double2*>(&x4[j]);
             }
-            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen,
-                    stream_word(STREAM_DE_CROSS, (uint32_t) p));
-            double2 v = a;
-            if (j < n && (u01(w.x, w.y) <= CR || j == jrand)) {
-                v.x = m.x;
-                cnt += 1.;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pj = pj0 + 16 * u;
+                if (pj < npair) {
+                    const int j = 2 * pj;
+                    if (pj0 == g) akeep[u] = a[u];
+                    const double2 lo = *reinterpret_cast<const double2*>(&d.lower[j]);
+                    const double2 up = *reinterpret_cast<const double2*>(&d.upper[j]);
+                    double2 m;
+                    if (rand1) {
+                        m.x = q1[u].x + F * (q2[u].x - q4[u].x);
+                        m.y = q1[u].y + F * (q2[u].y - q4[u].y);
+                    } else {
+                        m.x = a[u].x + F * (q4[u].x - a[u].x) + F * (q1[u].x - q2[u].x);
+                        m.y = a[u].y + F * (q4[u].y - a[u].y) + F * (q1[u].y - q2[u].y);
+                    }
+                    const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj,
+                            (uint32_t) gen, swc);
+                    const bool cx = j < n && (u01(w.x, w.y) <= CR || j == jrand);
+                    const bool cy = j + 1 < n && (u01(w.z, w.w) <= CR || j + 1 == jrand);
+                    double2 v;
+                    v.x = cx ? m.x : a[u].x;
+                    v.y = cy ? m.y : a[u].y;
+                    cnt += (cx ? 1. : 0.) + (cy ? 1. : 0.);
+                    const double rlx = (lo.x + a[u].x) / 2., rux = (up.x + a[u].x) / 2.;
+                    const double rly = (lo.y + a[u].y) / 2., ruy = (up.y + a[u].y) / 2.;
+                    v.x = j < n ? (v.x < lo.x ? rlx : (v.x > up.x ? rux : v.x)) : v.x;
+                    v.y = j + 1 < n ? (v.y < lo.y ? rly : (v.y > up.y ? ruy : v.y)) : v.y;
+                    *reinterpret_cast<double2*>(&trial[j]) = v;
+                }
             }
-            if (j + 1 < n && (u01(w.z, w.w) <= CR || j + 1 == jrand)) {
-                v.y = m.y;
-                cnt += 1.;
-            }
-            if (j < n) {
-                if (v.x < d.lower[j]) v.x = (d.lower[j] + a.x) / 2.;
-                else if (v.x > d.upper[j]) v.x = (d.upper[j] + a.x) / 2.;
-            }
-            if (j + 1 < n) {
-                if (v.y < d.lower[j + 1]) v.y = (d.lower[j + 1] + a.y) / 2.;
-                else if (v.y > d.upper[j + 1]) v.y = (d.upper[j + 1] + a.y) / 2.;
-            }
-            *reinterpret_cast<double2*>(&trial[j]) = v;
         }
     }
     __syncthreads();
@@ -459,7 +500,17 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
         const double *xi = Xc + (size_t) order[i] * ld;
         fold = fc[order[i]];
         accept = ft < fold;
-        for (int pj = g; pj < ld / 2; pj += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pj = g + 16 * u;
+            if (pj < npair) {
+                const int j = 2 * pj;
+                const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j]) : akeep[u];
+                *reinterpret_cast<double2*>(&Xn[(size_t) i * ld + j]) = v;
+                ssq += v.x * v.x + v.y * v.y;
+            }
+        }
+        for (int pj = g + 64; pj < npair; pj += 16) {
             const int j = 2 * pj;
             const double2 v = accept ? *reinterpret_cast<const double2*>(&trial[j])
                                      : *reinterpret_cast<const double2*>(&xi[j]);

@@ -14,3 +14,4 @@ print("total eigen %.1f | tred %.1f accum %.1f | dc total %.1f" % (us(0,5), us(0
 print("dc: copy/scale %.1f leaves %.1f merges L1 %.1f L2 %.1f L3 %.1f finalGEMM %.1f" % (us(16,17),us(17,18),us(18,19),us(19,20),us(20,21),us(22,23)))
 print("top merge: sort %.1f deflate %.1f secular %.1f loewner %.1f order+F %.1f gemm %.1f" % (us(24,25),us(25,26),us(26,27),us(27,28),us(28,29),us(29,30)))
 print("top secular iterations", t[31], "k/nd/nr?")
+print("leaf batches (blk 0..3)", t[12:16])
