@@ -65,6 +65,7 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     c.vmax = params_.vmax;
     c.seed = params_.seed;
     c.parts = std::max(1, std::min(256, c.np / 64));
+    c.fparts = std::max(1, std::min(64, c.np / 1024));
     // cso.cpp:196-217
     if (c.pc == 2) {
         if (c.np <= 100) {
@@ -89,6 +90,7 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     mean_.alloc(P * ld);
     meanw_.alloc(P * ld);
     colpart_.alloc((size_t) P * c.parts * ld);
+    fpart_.alloc((size_t) P * c.fparts * CSO_FPART);
     lower_.alloc(ld);
     upper_.alloc(ld);
     aux_.alloc(ld);
@@ -113,7 +115,7 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     d = CsoDev {};
     d.X = X_.p; d.V = V_.p; d.PM = PM_.p; d.f = f_.p; d.radius = radius_.p;
     d.occ = occ_.p; d.occ2 = occ2_.p;
-    d.mean = mean_.p; d.meanw = meanw_.p; d.colpart = colpart_.p;
+    d.mean = mean_.p; d.meanw = meanw_.p; d.colpart = colpart_.p; d.fpart = fpart_.p;
     d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
     c.honor_stop = 0;
     inited_ = true;
@@ -122,7 +124,8 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
             (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(false);
-    hipLaunchKernelGGL(cso_finish, dim3(P), dim3(1024), 0, stream_, d_, c_, 1);
+    hipLaunchKernelGGL(cso_finish_part, dim3(c_.fparts, P), dim3(256), 0, stream_, d_, c_);
+    hipLaunchKernelGGL(cso_finish, dim3(P), dim3(64), 0, stream_, d_, c_, 1);
     BBO_HIP(hipGetLastError());
     BBO_HIP(hipStreamSynchronize(stream_));
 }
@@ -190,7 +193,8 @@ void CsoEngine::generation(bool honor_stop)
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(true);
     timer_.begin(stream_, K_FINISH);
-    hipLaunchKernelGGL(cso_finish, dim3(P), dim3(1024), 0, stream_, d_, c_, 0);
+    hipLaunchKernelGGL(cso_finish_part, dim3(c_.fparts, P), dim3(256), 0, stream_, d_, c_);
+    hipLaunchKernelGGL(cso_finish, dim3(P), dim3(64), 0, stream_, d_, c_, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }

@@ -21,7 +21,7 @@ struct CsoScal {
 };
 
 struct CsoConst {
-    int n, ld, np, pc, ngroup, ring, correct, obj, mfev, honor_stop, npop, parts;
+    int n, ld, np, pc, ngroup, ring, correct, obj, mfev, honor_stop, npop, parts, fparts;
     double stol, vmax, phil, phih;
     uint64_t seed;
 };
@@ -32,6 +32,7 @@ struct CsoDev {
     int *occ, *occ2;         // [P][np] slot -> row: current order, and scratch for the shuffle
     double *mean, *meanw;    // [P][ld] swarm mean, winners' mean
     double *colpart;         // [P][parts][ld]
+    double *fpart;           // [P][fparts][5] slab results of cso_finish_part
     const double *lower, *upper, *aux;
     CsoScal *scal;
 };
@@ -63,7 +64,7 @@ private:
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
     std::vector<double> aux_h_;
-    DevBuf<double> X_, V_, PM_, f_, radius_, mean_, meanw_, colpart_, lower_, upper_, aux_;
+    DevBuf<double> X_, V_, PM_, f_, radius_, mean_, meanw_, colpart_, fpart_, lower_, upper_, aux_;
     DevBuf<int> occ_, occ2_;
     DevBuf<CsoScal> scal_;
     KernelTimer timer_;

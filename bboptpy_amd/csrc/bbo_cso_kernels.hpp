@@ -210,43 +210,57 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
                     stream_word(STREAM_PSO_CTRL, (uint32_t) p));
             const double phi = u01(wp.x, wp.y) * (c.phih - c.phil) + c.phil;
             const uint32_t swr = stream_word(STREAM_PSO_R, (uint32_t) p);
-            for (int pj = g; pj < ld / 2; pj += 16) {
-                const int j = 2 * pj;
-                const u32x4 wa = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj),
-                        (uint32_t) gen, swr);
-                const u32x4 wb = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj + 1),
-                        (uint32_t) gen, swr);
-                const u32x4 wc = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj + 2),
-                        (uint32_t) gen, swr);
-                const double2 xi = *reinterpret_cast<const double2*>(&x[j]);
-                const double2 vi = *reinterpret_cast<const double2*>(&v[j]);
-                const double2 pa = *reinterpret_cast<const double2*>(&xp[j]);
-                const double2 me = *reinterpret_cast<const double2*>(&xm[j]);
-                double2 xn = make_double2(0., 0.), vn = make_double2(0., 0.);
-                if (j < n) {
-                    double vv = u01(wa.x, wa.y) * vi.x + u01(wa.z, wa.w) * (pa.x - xi.x)
-                            + phi * u01(wc.x, wc.y) * (me.x - xi.x);
-                    const double maxv = c.vmax * (d.upper[j] - d.lower[j]);
-                    vv = fmax(-maxv, fmin(vv, maxv));
-                    double xx = xi.x + vv;
-                    if (c.correct) xx = fmax(d.lower[j], fmin(xx, d.upper[j]));
-                    vn.x = vv;
-                    xn.x = xx;
+            // four column pairs per lane at a time, their sixteen row loads issued first
+            const int npair = ld >> 1;
+            for (int pj0 = g; pj0 < npair; pj0 += 64) {
+                double2 xi4[4], vi4[4], pa4[4], me4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pj = pj0 + 16 * u;
+                    const int j = pj < npair ? 2 * pj : 0;
+                    xi4[u] = *reinterpret_cast<const double2*>(&x[j]);
+                    vi4[u] = *reinterpret_cast<const double2*>(&v[j]);
+                    pa4[u] = *reinterpret_cast<const double2*>(&xp[j]);
+                    me4[u] = *reinterpret_cast<const double2*>(&xm[j]);
                 }
-                if (j + 1 < n) {
-                    double vv = u01(wb.x, wb.y) * vi.y + u01(wb.z, wb.w) * (pa.y - xi.y)
-                            + phi * u01(wc.z, wc.w) * (me.y - xi.y);
-                    const double maxv = c.vmax * (d.upper[j + 1] - d.lower[j + 1]);
-                    vv = fmax(-maxv, fmin(vv, maxv));
-                    double xx = xi.y + vv;
-                    if (c.correct) xx = fmax(d.lower[j + 1], fmin(xx, d.upper[j + 1]));
-                    vn.y = vv;
-                    xn.y = xx;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pj = pj0 + 16 * u;
+                    if (pj >= npair) continue;
+                    const int j = 2 * pj;
+                    const double2 xi = xi4[u], vi = vi4[u], pa = pa4[u], me = me4[u];
+                    const u32x4 wa = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj),
+                            (uint32_t) gen, swr);
+                    const u32x4 wb = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj + 1),
+                            (uint32_t) gen, swr);
+                    const u32x4 wc = philox4x32_10(c.seed, (uint32_t) slot, (uint32_t) (3 * pj + 2),
+                            (uint32_t) gen, swr);
+                    double2 xn = make_double2(0., 0.), vn = make_double2(0., 0.);
+                    if (j < n) {
+                        double vv = u01(wa.x, wa.y) * vi.x + u01(wa.z, wa.w) * (pa.x - xi.x)
+                                + phi * u01(wc.x, wc.y) * (me.x - xi.x);
+                        const double maxv = c.vmax * (d.upper[j] - d.lower[j]);
+                        vv = fmax(-maxv, fmin(vv, maxv));
+                        double xx = xi.x + vv;
+                        if (c.correct) xx = fmax(d.lower[j], fmin(xx, d.upper[j]));
+                        vn.x = vv;
+                        xn.x = xx;
+                    }
+                    if (j + 1 < n) {
+                        double vv = u01(wb.x, wb.y) * vi.y + u01(wb.z, wb.w) * (pa.y - xi.y)
+                                + phi * u01(wc.z, wc.w) * (me.y - xi.y);
+                        const double maxv = c.vmax * (d.upper[j + 1] - d.lower[j + 1]);
+                        vv = fmax(-maxv, fmin(vv, maxv));
+                        double xx = xi.y + vv;
+                        if (c.correct) xx = fmax(d.lower[j + 1], fmin(xx, d.upper[j + 1]));
+                        vn.y = vv;
+                        xn.y = xx;
+                    }
+                    *reinterpret_cast<double2*>(&x[j]) = xn;
+                    *reinterpret_cast<double2*>(&v[j]) = vn;
+                    *reinterpret_cast<double2*>(&trial[j]) = xn;
+                    ssq += xn.x * xn.x + xn.y * xn.y;
                 }
-                *reinterpret_cast<double2*>(&x[j]) = xn;
-                *reinterpret_cast<double2*>(&v[j]) = vn;
-                *reinterpret_cast<double2*>(&trial[j]) = xn;
-                ssq += xn.x * xn.x + xn.y * xn.y;
             }
         }
         __syncthreads();
@@ -266,31 +280,36 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
     }
 }
 
-// incumbent (first slot holding the smallest f, cso.cpp:150-156), evaluation count, stop test
-// on the spread of the radii (:177-194).  One workgroup of 1024 threads per population.
-__global__ __launch_bounds__(1024) void cso_finish(CsoDev d, CsoConst c, int init_only)
+// incumbent (first slot holding the smallest f, cso.cpp:150-156) and the spread of the radii
+// (:177-194), first over slabs of the swarm: slab s covers slots AND rows [s*per, (s+1)*per).
+// fpart[p][s] = { best f, its slot, count, mean radius, sum of squared deviations }.
+// grid (fparts, P), 256 threads
+constexpr int CSO_FPART = 5;
+__global__ __launch_bounds__(256) void cso_finish_part(CsoDev d, CsoConst c)
 {
-    const int p = blockIdx.x;
-    CsoScal *sc = d.scal + p;
+    const int p = blockIdx.y, part = blockIdx.x;
+    const CsoScal *sc = d.scal + p;
     if (cso_frozen(c, sc)) return;
-    __shared__ double sval[16];
-    __shared__ int sidx[16];
-    __shared__ double scratch[16];
+    __shared__ double sval[4];
+    __shared__ int sidx[4];
+    __shared__ double scratch[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t pb = (size_t) p * c.np;
+    const int per = (c.np + c.fparts - 1) / c.fparts;
+    const int lo = part * per, hi = min(c.np, lo + per);
     double best = CSO_INF;
     int bslot = 0x7fffffff;
-    for (int s0 = tid; s0 < c.np; s0 += 4 * 1024) {      // four gathers in flight
+    for (int s0 = lo + tid; s0 < hi; s0 += 4 * 256) {      // four gathers in flight
         double fv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int s = s0 + 1024 * u;
-            fv[u] = s < c.np ? d.f[pb + d.occ[pb + s]] : CSO_INF;
+            const int s = s0 + 256 * u;
+            fv[u] = s < hi ? d.f[pb + d.occ[pb + s]] : CSO_INF;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int s = s0 + 1024 * u;
-            if (s < c.np && (fv[u] < best || (fv[u] == best && s < bslot))) {
+            const int s = s0 + 256 * u;
+            if (s < hi && (fv[u] < best || (fv[u] == best && s < bslot))) {
                 best = fv[u];
                 bslot = s;
             }
@@ -312,47 +331,91 @@ __global__ __launch_bounds__(1024) void cso_finish(CsoDev d, CsoConst c, int ini
     __syncthreads();
     best = sval[0];
     bslot = sidx[0];
-    for (int w = 1; w < 16; w++)
+    for (int w = 1; w < 4; w++)
         if (sval[w] < best || (sval[w] == best && sidx[w] < bslot)) {
             best = sval[w];
             bslot = sidx[w];
         }
-    // radius spread, two passes
     auto block_sum = [&](double v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         __syncthreads();
         if (lane == 0) scratch[wave] = v;
         __syncthreads();
-        double s = 0.;
-        for (int w = 0; w < 16; w++) s += scratch[w];
-        return s;
+        return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
     };
-    // (sums over the ROWS: the same set as the slots, coalesced and without the gather)
+    // (radii by ROW: the same set as the slots, coalesced and without the gather)
+    double rv[4];
     double s = 0.;
-    for (int q = tid; q < c.np; q += 1024) s += d.radius[pb + q];
-    const double mean = block_sum(s) / c.np;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int q = lo + tid + 256 * u;
+        rv[u] = q < hi ? d.radius[pb + q] : 0.;
+        s += rv[u];
+    }
+    for (int q = lo + tid + 1024; q < hi; q += 256) s += d.radius[pb + q];
+    const int cnt = max(hi - lo, 0);
+    const double mean = cnt > 0 ? block_sum(s) / cnt : 0.;
     double m2 = 0.;
-    for (int q = tid; q < c.np; q += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int q = lo + tid + 256 * u;
+        const double dd = rv[u] - mean;
+        if (q < hi) m2 += dd * dd;
+    }
+    for (int q = lo + tid + 1024; q < hi; q += 256) {
         const double dd = d.radius[pb + q] - mean;
         m2 += dd * dd;
     }
     m2 = block_sum(m2);
     if (tid == 0) {
-        sc->ibest = bslot < c.np ? d.occ[pb + bslot] : 0;
-        sc->fbest = best;
-        sc->m2 = m2;
-        if (init_only) {
-            sc->conv = m2 <= (c.np - 1) * c.stol * c.stol ? 1 : 0;
-            return;
-        }
-        sc->fev += c.np - c.ngroup;
-        sc->gen += 1;
-        const int conv = m2 <= (c.np - 1) * c.stol * c.stol ? 1 : 0;
-        sc->conv = conv;
-        if (conv) sc->stop = 1;
-        else if (sc->fev >= c.mfev) sc->stop = 2;
+        double *out = d.fpart + ((size_t) p * c.fparts + part) * CSO_FPART;
+        out[0] = best;
+        out[1] = (double) bslot;
+        out[2] = (double) cnt;
+        out[3] = mean;
+        out[4] = m2;
     }
+}
+
+// combines the slabs (arg-min lexicographic in (f, slot); mean / M2 by the pairwise update of
+// Chan et al.), then evaluation count and stop test.  One wavefront per population.
+__global__ __launch_bounds__(64) void cso_finish(CsoDev d, CsoConst c, int init_only)
+{
+    const int p = blockIdx.x;
+    CsoScal *sc = d.scal + p;
+    if (cso_frozen(c, sc)) return;
+    if (threadIdx.x != 0) return;
+    const size_t pb = (size_t) p * c.np;
+    const double *in = d.fpart + (size_t) p * c.fparts * CSO_FPART;
+    double best = CSO_INF, bslot = 2147483647., cnt = 0., mean = 0., m2 = 0.;
+    for (int s = 0; s < c.fparts; s++) {
+        const double *e = in + (size_t) s * CSO_FPART;
+        if (e[0] < best || (e[0] == best && e[1] < bslot)) {
+            best = e[0];
+            bslot = e[1];
+        }
+        if (e[2] > 0.) {
+            const double nb = e[2], tot = cnt + nb, delta = e[3] - mean;
+            m2 += e[4] + delta * delta * (cnt * nb / tot);
+            mean += delta * (nb / tot);
+            cnt = tot;
+        }
+    }
+    const int islot = (int) bslot;
+    sc->ibest = islot < c.np ? d.occ[pb + islot] : 0;
+    sc->fbest = best;
+    sc->m2 = m2;
+    if (init_only) {
+        sc->conv = m2 <= (c.np - 1) * c.stol * c.stol ? 1 : 0;
+        return;
+    }
+    sc->fev += c.np - c.ngroup;
+    sc->gen += 1;
+    const int conv = m2 <= (c.np - 1) * c.stol * c.stol ? 1 : 0;
+    sc->conv = conv;
+    if (conv) sc->stop = 1;
+    else if (sc->fev >= c.mfev) sc->stop = 2;
 }
 
 } // namespace bbo
