@@ -167,7 +167,7 @@ __device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row,
 // the accumulated Q goes to (qdst, ldq), which may be As itself.
 __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, const EigMat &As,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
-        int tid, long long *stamps, double *qdst, int ldq, bool finish)
+        int tid, long long *stamps, double *qdst, int ldq, bool finish, bool accumulate = true)
 {
     const int T = EIG_THREADS, lane = tid & 63;
     const int j = tid >> 2, q = tid & 3;
@@ -271,6 +271,7 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         for (int b = 0; b < 8; b++)
             if (32 * a + 8 * q + b == j && j < n) td[j] = a_[a][b];
 
+    if (accumulate) {
     // ---- phase 2: Q = H(n-1) ... H(1), column-tiled in registers, starting from I.  Column
     // j only needs the stashed vectors (read-only now): no barrier inside the loop ------------
 #pragma unroll
@@ -302,6 +303,8 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
                 if (k < n) qdst[(size_t) k * ldq + j] = a_[a][b];
             }
     }
+    }   // accumulate (else: the caller applies the stashed reflectors itself, eig_dc_phase)
+    __syncthreads();   // td is complete
     if (finish)
         for (int k = tid; k < n; k += T) dv[k] = td[k];
     __syncthreads();
@@ -550,8 +553,11 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         ev[-1 - tid] = 0.;
     }
     if (pl.reg_path) {
+        // (with the D&C stage the reflectors stay stashed in A: eig_dc_phase applies them to the
+        // tridiagonal eigenvectors in blocked form on the matrix cores)
         eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
-                (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true);
+                (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true,
+                !(pl.dc && !(d.dbg & 2)));
     } else {
         const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
         eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg, pl.reg_path ? 0 : 1);
+                d.dbg, pl.reg_path ? 0 : 1, pl.reg_path ? hvec : nullptr);
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {

@@ -524,13 +524,26 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         dc_d4 acc[2] = { { 0., 0., 0., 0. }, { 0., 0., 0., 0. } };
         const int arow = rt * 16 + fr;
         if (rt < ntile) {
+            // (a second column tile only when the merge is wider than 16 columns per wavefront
+            // of its team -- uneven splits; for n = 128 every wavefront has exactly one)
+            if (tm.twave + tm.nwaves < ntile) {
 #pragma unroll
-            for (int ks = 0; ks < DC_KSTEPS; ks++) {
-                if (ks < ksteps) {
-                    const int kk = 4 * ks + fk;
-                    const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[1][ks], acc[1], 0, 0, 0);
+                for (int ks = 0; ks < DC_KSTEPS; ks++) {
+                    if (ks < ksteps) {
+                        const int kk = 4 * ks + fk;
+                        const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[1][ks], acc[1], 0, 0, 0);
+                    }
+                }
+            } else if (tm.twave < ntile) {
+#pragma unroll
+                for (int ks = 0; ks < DC_KSTEPS; ks++) {
+                    if (ks < ksteps) {
+                        const int kk = 4 * ks + fk;
+                        const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -593,6 +606,153 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     dc_wave_sync();
 }
 
+// ---- B = H(n-1) ... H(1) Q_T, the reflectors applied in blocked (compact WY) form on the matrix
+// cores.  V (global, n x n, row i = u_i, zero from column i on), tau[i] = 1 / h_i (0: no
+// reflector), Q (LDS) = Q_T on entry.  Panel b = reflectors 16b .. 16b+15:
+//     H(16b+15) ... H(16b) = I - V_b T_b^T V_b^T,   T_b upper triangular (LAPACK dlarft, forward),
+//     T(0:i, i) = -tau_i T(0:i, 0:i) (V_b^T V_b)(0:i, i),  T(i, i) = tau_i.
+// 1. Wavefront w builds T_w: Gram matrix by MFMA (all of its reflector entries requested up
+//    front: V sits in L2), written to its LDS patch; then lane l < 16 owns ROW l of T in
+//    registers and runs the 16-step recurrence on its own (it needs only its row and column i of
+//    the Gram matrix, a broadcast read): no wavefront hand-overs.  T_w goes to global (Tg).
+// 2. Panels in the order the reflectors act.  The 16 x n panel is staged in LDS once for all
+//    wavefronts (the next one is prefetched into registers meanwhile); wavefront w owns the
+//    16-column tile w of Q: W = V_b^T Q, W <- T_b^T W (the accumulator layout of one product IS
+//    the B-operand layout of the next), Q -= V_b W; rows beyond the reflectors' reach skipped.
+// k index of a contraction over rows: k(ks, fk) = 8 (ks >> 1) + 2 fk + (ks & 1), so a lane's two
+// k-steps read one 16-byte piece of a reflector.
+// scratch (LDS): 16 * 132 doubles; Tg (global): 16 * 256 doubles.
+__device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
+        double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
+{
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = T >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int npanel = (n + 15) >> 4;
+    constexpr int LS = 17, LDV = 132;
+    // (outpos, if any, lives in the work area this stage reuses: n <= 16 then, one entry each)
+    const int ocol = (outpos && tid < n * n) ? outpos[tid % n] : -1;
+    __syncthreads();      // the merge work area is free; tau and V are visible
+    // ---- 1. T_b, one wavefront per panel ------------------------------------------------------
+    for (int b = wave; b < npanel; b += NW) {
+        double *Sb = scratch + (size_t) wave * 16 * LS;
+        const int i0 = 16 * b, reach = min(n, i0 + 16);       // rows < reach can be non-zero
+        const int refl = i0 + fr;
+        const double *vrow = V + (size_t) min(refl, n - 1) * n;
+        double va[DC_KSTEPS];
+#pragma unroll
+        for (int q = 0; q < DC_KSTEPS / 2; q++) {
+            const int k0 = 8 * q + 2 * fk;
+            va[2 * q] = (refl < n && k0 < reach) ? vrow[k0] : 0.;
+            va[2 * q + 1] = (refl < n && k0 + 1 < reach) ? vrow[k0 + 1] : 0.;
+        }
+        dc_d4 acc = { 0., 0., 0., 0. };
+#pragma unroll
+        for (int q = 0; q < DC_KSTEPS / 2; q++) {
+            if (8 * q < reach) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q], va[2 * q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q + 1], va[2 * q + 1], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sb[(fk + 4 * r) * LS + fr] = acc[r];    // S = V_b^T V_b
+        dc_wave_sync();
+        if (lane < 16) {
+            double t[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double ti = i0 + i < n ? tau[i0 + i] : 0.;
+                double sum = 0.;
+#pragma unroll
+                for (int m = 0; m < i; m++) sum = fma(t[m], Sb[m * LS + i], sum);
+                t[i] = lane < i ? -ti * sum : (lane == i ? ti : 0.);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) Tg[(size_t) b * 256 + lane * 16 + i] = t[i];
+        }
+        dc_wave_sync();
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- 2. panels ---------------------------------------------------------------------------------
+    double *Vp = scratch;
+    const int ctile = wave, col = 16 * ctile + fr;
+    const int pj = tid >> 5, pc = (tid & 31) * 4;     // this thread's piece of a staged panel
+    double pre[4], tpre[4];
+    auto prefetch = [&](int b) {
+        const int i0 = 16 * b, reach = min(n, i0 + 16);
+        const int rf = i0 + pj;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            pre[u] = (rf < n && pc + u < reach) ? V[(size_t) rf * n + pc + u] : 0.;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = 4 * ks + fk;
+            tpre[ks] = kk <= fr ? Tg[(size_t) b * 256 + kk * 16 + fr] : 0.;
+        }
+    };
+    prefetch(0);
+    for (int b = 0; b < npanel; b++) {
+        const int reach = min(n, 16 * b + 16);
+        __syncthreads();                         // the previous panel has been read by everyone
+#pragma unroll
+        for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = pre[u];
+        double tv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) tv[ks] = tpre[ks];
+        __syncthreads();
+        if (b + 1 < npanel) prefetch(b + 1);
+        if (16 * ctile < n) {
+            // W = V_b^T Q[:, tile]
+            dc_d4 w = { 0., 0., 0., 0. };
+#pragma unroll
+            for (int q = 0; q < DC_KSTEPS / 2; q++) {
+                if (8 * q < reach) {
+                    const int k0 = 8 * q + 2 * fk;
+                    const double2 a2 = *reinterpret_cast<const double2*>(&Vp[fr * LDV + k0]);
+                    const double b0 = (k0 < n && col < n) ? Q(k0, col) : 0.;
+                    const double b1 = (k0 + 1 < n && col < n) ? Q(k0 + 1, col) : 0.;
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b0, w, 0, 0, 0);
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b1, w, 0, 0, 0);
+                }
+            }
+            // W <- T_b^T W: A(m = fr, k = 4 ks + fk) = T(4 ks + fk, fr); B operand of k-step ks =
+            // accumulator register ks of W
+            dc_d4 w2 = { 0., 0., 0., 0. };
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[ks], w[ks], w2, 0, 0, 0);
+            // Q[:, tile] -= V_b W, 16 rows at a time
+#pragma unroll
+            for (int rt = 0; rt < DC_KSTEPS / 4; rt++) {
+                if (16 * rt < reach) {
+                    dc_d4 cacc;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * rt + fk + 4 * r;
+                        cacc[r] = (row < n && col < n) ? Q(row, col) : 0.;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++)
+                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                -Vp[(4 * ks + fk) * LDV + 16 * rt + fr], w2[ks], cacc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * rt + fk + 4 * r;
+                        if (row < n && col < n) Q(row, col) = cacc[r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < n * n; q += T) {
+        const int r = q / n, c = q - r * n;
+        Bout[(size_t) r * ldb + (outpos ? ocol : c)] = Q(r, c);
+    }
+    __syncthreads();
+}
+
 // D&C driver.  On entry: dv = diagonal, ev[i] = coupling (i, i+1) (ev[n-1] = 0), Q (LDS) =
 // Householder matrix Q_house.  On exit: dv = eigenvalues ascending, Bout (global, ld) =
 // Q_house * Q_T, i.e. the eigenvectors of the original matrix in columns.
@@ -601,7 +761,8 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
 // exit Q = blockdiag(Q_1, Q_2), F (= G + n*n, n x n) = the top merge's eigenvector factor with
 // columns in ascending eigenvalue order, and the caller forms B = Q_house (Q F).
 __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
-        double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0)
+        double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
+        const double *hv = nullptr)
 {
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
@@ -618,6 +779,12 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
         const int r = q / n, c = q - r * n;
         Qh[q] = Q(r, c);
     }
+    // hv != null: Q holds the STASHED REFLECTORS of the Householder stage (row i = u_i, zero from
+    // column i on; H(i) = I - u_i u_i^T / hv[i]), not the accumulated Q_house: Qh is V then, and
+    // the scalars 1 / h move out of the way of the work area (hv lives inside `scratch`)
+    double *taug = G + (size_t) 2 * n * n;
+    if (hv)
+        for (int i = tid; i < n; i += T) taug[i] = hv[i] != 0. ? 1. / hv[i] : 0.;
     DcWork W;
     {
         double *p = scratch;
@@ -764,6 +931,12 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
 
     DC_STAMP(22);
     if (ext_top) return;
+    if (hv) {
+        dc_apply_reflectors(Q, n, Qh, taug, taug + n, scratch, Bout, ldb,
+                single ? W.outpos : nullptr);
+        DC_STAMP(23);
+        return;
+    }
     // ---- B = Q_house * Q_T on the matrix cores: a wavefront keeps the Q_house fragments of
     // its row tile in registers and sweeps the column tiles ---------------------------------
     const int ntile = (n + 15) >> 4;
