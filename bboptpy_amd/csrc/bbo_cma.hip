@@ -787,6 +787,11 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
         return (int) cnt;
     }
     if (k == "profile") return timer_.report(out, cap);
+    if (k == "eig_work") {   // diagnostic: the eigensolver's global scratch of population p
+        const size_t cnt = std::min((size_t) 4 * eig_slab(c.ld), eig_work_.count);
+        if (out && (size_t) cap >= cnt) eig_work_.download(out, cnt, (size_t) p * 4 * eig_slab(c.ld));
+        return (int) cnt;
+    }
     if (k == "eig_stamps") {
         if (!stamps_.p) return 0;
         if (out && cap >= 32) {

@@ -216,10 +216,20 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
             }
             return;
         }
-        double g = sqrt(h0);
+        // sqrt and reciprocal from the hardware estimates + Newton corrections (full fp64 to a
+        // rounding error; every wavefront computes the same bits): these sit on the serial
+        // chain of the step, the IEEE sequences are twice as long
+        double g;
+        {
+            double y = __builtin_amdgcn_rsq(h0);
+            const double err = fma(-h0 * y, y, 1.);
+            y = fma(y * err, fma(err, 0.375, 0.5), y);
+            g = h0 * y;
+            g = fma(fma(-g, g, h0), 0.5 * y, g);      // one more step on the root itself
+        }
         if (f > 0) g = -g;
         const double h = h0 - f * g;
-        const double rh = 1. / h;
+        const double rh = dc_rcp(h);
         // every wavefront writes the SAME u (one store per element), so a wavefront may read
         // what it wrote without waiting for the others
         uv[lane] = lane < i ? (lane == i - 1 ? f - g : d0) : 0.;
