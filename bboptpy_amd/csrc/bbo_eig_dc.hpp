@@ -313,6 +313,16 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         double lo = left ? 0. : -0.5 * gap;
         double hi = left ? (last ? gap : 0.5 * gap) : 0.;
         double mu = 0.5 * (lo + hi);
+        if (act) {
+            // first guess: the origin pole with its TRUE weight, all other poles frozen at their
+            // midpoint value: 1 + rho (w_o / (d_o - x) + rest) = 0.  Exact in the limit of a tiny
+            // weight (root glued to its pole -- where the fitted two-pole model below starts
+            // blind and took 10-17 steps), inside the bracket by construction otherwise.
+            const double wo = W.w2[o];
+            const double rest1 = fm + (left ? 2. : -2.) * rho * wo / gap;    // 1 + rho rest
+            const double g0 = rho * wo / rest1;
+            if (g0 == g0 && g0 > lo && g0 < hi) mu = g0;
+        }
         bool done = !act;
         for (int it = 0; it < 64; it++) {
             double psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;

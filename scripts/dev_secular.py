@@ -5,7 +5,7 @@ import bboptpy_amd as b
 n, lam = 128, 4096
 alg=b.ActiveCMAES(mfev=2**31-1,tol=0.,np=lam,seed=1)
 alg.initialize(b.objectives.rosenbrock,-10*np.ones(n),10*np.ones(n),np.random.default_rng(0).uniform(-10,10,n))
-for gens in (30, 200, 600):
+for gens in [28]+[1]*12:
     alg.run(gens)
     alg.set_state("eig_stamps",[1.0]); alg.run(1)
     w = alg.get_state("eig_work")
