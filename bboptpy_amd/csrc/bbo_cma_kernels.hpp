@@ -416,7 +416,7 @@ __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int 
     if (pop_frozen(c, sc)) return;
     extern __shared__ __attribute__((aligned(16))) double sortbuf[];
     double *keys = sortbuf;
-    int *idx = reinterpret_cast<int*>(sortbuf + m);
+    int *idx = reinterpret_cast<int*>(sortbuf + max(m, 1024));   // the sort pads to >= 1024
     const double *f = d.f + (size_t) p * c.lambda_pad;
     int *order = d.order + (size_t) p * c.lambda_pad, *rank = d.rank + (size_t) p * c.lambda_pad;
     bitonic_sort_lds(f, c.lambda, m, keys, idx, order, rank);
@@ -1118,7 +1118,50 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
     const int fr = lane & 15, fk = lane >> 4;
     const int wb = blockIdx.y;            // workgroup wb of NBW: tile rows wb, wb + NBW, ...
     constexpr int NR = 8 / NBW;           // tile rows per workgroup (NBW = 4: 2, NBW = 1: 8)
-    if (mode != 2) {
+    if (mode != 2 && NBW == 1) {
+        // one workgroup per population: wavefront w owns tile ROWS w, w + 4 and sweeps all eight
+        // column tiles, so the divisions B[i][k] / D[k] (the reference's term order, kept) are
+        // made once per row and k-step, not once per wavefront
+        d4_t acc[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[h][t] = d4_t { 0., 0., 0., 0. };
+        if (wave < NT) {
+            const bool r1 = wave + 4 < NT;
+            for (int ks = 0; ks < KS; ks++) {
+                const int k = 4 * ks + fk;
+                const double dk = Dv[k];
+                const double a0 = Bs[(wave * 16 + fr) * ldp + k] / dk;
+                const double a1 = r1 ? Bs[((wave + 4) * 16 + fr) * ldp + k] / dk : 0.;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const double f = t < NT ? Bs[(t * 16 + fr) * ldp + k] : 0.;
+                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f, acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f, acc[1][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int ti = wave + 4 * h;
+                if (ti < NT) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        if (t < NT) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int i = ti * 16 + fk + 4 * r, j = t * 16 + fr;
+                                const double v = acc[h][t][r];   // 0 outside n: B is staged as 0 there
+                                isc[(size_t) i * ld + j] = v;
+                                ISp[((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15)] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (mode != 2 && NBW != 1) {
         // wavefront w: column tiles w, w + 4 of this workgroup's tile rows
         d4_t acc[NR][2];
 #pragma unroll

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void de_rank_sort(DeDev d, DeConst c, int whi
     if (de_frozen(c, sc)) return;
     extern __shared__ __attribute__((aligned(16))) double sortbuf[];
     double *keys = sortbuf;
-    int *idx = reinterpret_cast<int*>(sortbuf + m);
+    int *idx = reinterpret_cast<int*>(sortbuf + max(m, 1024));   // the sort pads to >= 1024
     const int which = which_next ? (sc->cur ^ 1) : sc->cur;
     const double *f = d.f[which] + (size_t) p * c.npinit;
     bitonic_sort_lds(f, sc->np, m, keys, idx, d.order + (size_t) p * c.npinit,

@@ -57,40 +57,123 @@ __device__ inline bool pair_less(double fa, int ia, double fb, int ib)
     return fa < fb || (fa == fb && ia < ib);
 }
 
-// keys/idx: LDS arrays of `m` (power of two >= count) entries
+// The sort proper, E = M / 1024 consecutive elements per thread in REGISTERS (M = the padded
+// size, 1024 E).  A compare-exchange stage with partner distance j runs
+//   j <  E          inside the thread,
+//   j <  64 E       between lanes of a wavefront (shuffle-xor by j / E): no barrier,
+//   j >= 64 E       through LDS (elements dumped once per merge phase, the classic in-place
+//                   stage with one barrier each, then reloaded).
+// For M = 4096 that is 14 barriers instead of 78.  Element e keeps the smaller of (itself, its
+// partner e ^ j) iff ((e & j) == 0) == ((e & k) == 0).
+template<int E>
+__device__ inline void bitonic_sort_regs(const double *f, int count, double *keys, int *idx,
+        int *order, int *rank)
+{
+    constexpr int M = 1024 * E;
+    const int tid = threadIdx.x;
+    const int e0 = tid * E;
+    double kf[E];
+    int ki[E];
+#pragma unroll
+    for (int u = 0; u < E; u++) {
+        const int e = e0 + u;
+        kf[u] = e < count ? f[e] : __builtin_huge_val();
+        ki[u] = e < count ? e : 0x7fffffff;
+    }
+    for (int k = 2; k <= M; k <<= 1) {
+        int j = k >> 1;
+        if (j >= 64 * E) {
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                keys[e0 + u] = kf[u];
+                idx[e0 + u] = ki[u];
+            }
+            __syncthreads();
+            for (; j >= 64 * E; j >>= 1) {
+#pragma unroll
+                for (int v = 0; v < (E > 1 ? E / 2 : 1); v++) {
+                    const int q = tid + 1024 * v;
+                    if (q < (M >> 1)) {
+                        const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                        const int hi = lo | j;
+                        const bool up = (lo & k) == 0;
+                        const double fa = keys[lo], fb = keys[hi];
+                        const int ia = idx[lo], ib = idx[hi];
+                        if (pair_less(fb, ib, fa, ia) == up) {
+                            keys[lo] = fb;
+                            keys[hi] = fa;
+                            idx[lo] = ib;
+                            idx[hi] = ia;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                kf[u] = keys[e0 + u];
+                ki[u] = idx[e0 + u];
+            }
+        }
+        for (; j >= E; j >>= 1) {
+            const int lx = j / E;
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const double fb = __shfl_xor(kf[u], lx, 64);
+                const int ib = __shfl_xor(ki[u], lx, 64);
+                const int e = e0 + u;
+                const bool want_min = ((e & j) == 0) == ((e & k) == 0);
+                const bool less = pair_less(fb, ib, kf[u], ki[u]);
+                const bool greater = pair_less(kf[u], ki[u], fb, ib);
+                if (want_min ? less : greater) {
+                    kf[u] = fb;
+                    ki[u] = ib;
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = E >> 1; jj > 0; jj >>= 1) {
+            if (jj < k) {
+#pragma unroll
+                for (int u = 0; u < E; u++) {
+                    if ((u & jj) == 0) {
+                        const bool up = ((e0 + u) & k) == 0;
+                        if (pair_less(kf[u | jj], ki[u | jj], kf[u], ki[u]) == up) {
+                            const double tf = kf[u];
+                            const int ti = ki[u];
+                            kf[u] = kf[u | jj];
+                            ki[u] = ki[u | jj];
+                            kf[u | jj] = tf;
+                            ki[u | jj] = ti;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // the sorted pairs also to LDS: callers read the extremes there
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; u++) {
+        const int e = e0 + u;
+        keys[e] = kf[u];
+        idx[e] = ki[u];
+        if (e < count) {
+            order[e] = ki[u];
+            rank[ki[u]] = e;
+        }
+    }
+    __syncthreads();
+}
+
+// keys/idx: LDS arrays of max(m, 1024) entries (m = power of two >= count); 1024 threads
 __device__ inline void bitonic_sort_lds(const double *f, int count, int m, double *keys,
         int *idx, int *order, int *rank)
 {
-    const int tid = threadIdx.x, T = blockDim.x;
-    for (int q = tid; q < m; q += T) {
-        keys[q] = q < count ? f[q] : __builtin_huge_val();
-        idx[q] = q < count ? q : 0x7fffffff;
-    }
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = tid; q < (m >> 1); q += T) {
-                // q-th compare-exchange of this stage: partner indices differ in bit j
-                const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-                const int hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const double fa = keys[lo], fb = keys[hi];
-                const int ia = idx[lo], ib = idx[hi];
-                if (pair_less(fb, ib, fa, ia) == up) {
-                    keys[lo] = fb;
-                    keys[hi] = fa;
-                    idx[lo] = ib;
-                    idx[hi] = ia;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int q = tid; q < count; q += T) {
-        const int cand = idx[q];
-        order[q] = cand;
-        rank[cand] = q;
-    }
+    if (m <= 1024) bitonic_sort_regs<1>(f, count, keys, idx, order, rank);
+    else if (m == 2048) bitonic_sort_regs<2>(f, count, keys, idx, order, rank);
+    else if (m == 4096) bitonic_sort_regs<4>(f, count, keys, idx, order, rank);
+    else bitonic_sort_regs<8>(f, count, keys, idx, order, rank);
 }
 
 } // namespace bbo
