@@ -467,7 +467,13 @@ void CmaEngine::launch_eigen()
         // 128 < n <= 256: the top merge's two products as whole-GPU kernels
         dim3 grid((c.n + 63) / 64, (c.n + 63) / 64, c.npop);
         hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
-        hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
+        // second product: the stashed reflectors applied in blocked form (the QL fallback of
+        // the diagnostic switch has accumulated Q_house instead)
+        if (d_.dbg & 2)
+            hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
+        else
+            hipLaunchKernelGGL(cma_eig_wy, dim3((c.n + 63) / 64, c.npop), dim3(256), 0, stream_, d_,
+                    c_);
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_POST);

@@ -335,7 +335,7 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
 // biggest steps of either phase stream from L2.
 __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, const EigMat &A,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
-        double *part, int nv, int tid, long long *stamps, const EigMat *As)
+        double *part, int nv, int tid, long long *stamps, const EigMat *As, bool accumulate = true)
 {
     const int NS = As ? 128 : 0;             // steps i < NS run out of registers
     const int T = EIG_THREADS, lane = tid & 63;
@@ -455,13 +455,31 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
         // the leading 128 x 128 block: reduce and accumulate in registers, Q block back to A
         __syncthreads();
         eig_tred_accum_reg128(A.a, lda, 128, *As, dv, ev, uv, wv, gv, hvec, td, tid, nullptr,
-                A.a, lda, false);
+                A.a, lda, false, accumulate);
         for (int k = tid; k < nr; k += T) {
             uv[k] = 0.;
             wv[k] = 0.;
         }
     }
     __syncthreads();
+    if (As && !accumulate) {
+        // the reflectors are applied later in blocked form (cma_eig_wy): leave A = V, row i = u_i
+        // in columns < i and zero from column i on; the first 128 rows come from the LDS stash
+        for (int q = tid; q < n * (nr >> 1); q += T) {
+            const int r = q / (nr >> 1), c2 = (q - r * (nr >> 1)) * 2;
+            double2 *cell = reinterpret_cast<double2*>(&A.a[(size_t) r * lda + c2]);
+            double2 v = r < 128 ? make_double2(c2 < 128 ? (*As)(r, c2) : 0.,
+                                               c2 + 1 < 128 ? (*As)(r, c2 + 1) : 0.)
+                                : *cell;
+            if (c2 >= r) v.x = 0.;
+            if (c2 + 1 >= r) v.y = 0.;
+            *cell = v;
+        }
+        __syncthreads();
+        for (int k = tid; k < n; k += T) dv[k] = td[k];
+        __syncthreads();
+        return;
+    }
     // ---- Q = H(n-1) ... H(1), in place: the block [0..i]^2 holds the product so far, the rows
     // below still hold the stashed vectors.  The strict upper triangle must read as zero ------
     for (int q = tid; q < n * (nr >> 1); q += T) {
@@ -571,8 +589,10 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     } else {
         const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
+        // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
         eig_tred_accum_global(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, part, nv, tid,
-                (d.stamps && p == 0) ? d.stamps : nullptr, hybrid ? &Ast : nullptr);
+                (d.stamps && p == 0) ? d.stamps : nullptr, hybrid ? &Ast : nullptr,
+                !(hybrid && !(d.dbg & 2)));
     }   // generic path
     {   // tql2 prologue: shift the sub-diagonal down (cmaes.cpp:384-387); T >= n
         const double t = (tid + 1 < n) ? ev[tid + 1] : 0.;
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
         eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg, pl.reg_path ? 0 : 1, pl.reg_path ? hvec : nullptr);
+                d.dbg, pl.reg_path ? 0 : 1, hvec);
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {
@@ -737,6 +757,95 @@ __global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int ld
             const int orow = blockIdx.y * 64 + wave * 16 + fk + 4 * r;
             if (orow < n && col < n) Cm[(size_t) orow * ldc + col] = acc[t][r];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// B = H(n-1) ... H(1) M for 128 < n <= 256, the reflectors applied in blocked (compact WY) form:
+// the second product of the external top merge, M = eig_work[3] = (Q_1 (+) Q_2) F, with
+// V = eig_work[1] (row i = u_i), [tau | T] behind F (written by cma_eigen / dc_build_T).
+// A wavefront owns one 16-column tile of M and keeps all of it in registers (n / 16 accumulator
+// tiles): W = V_b^T M (the accumulator layout of a row tile is the B-operand layout of the
+// contraction over its rows), W <- T_b^T W, M -= V_b W, panel after panel, then stores B.
+// The 16 x n panel is staged in LDS for the four wavefronts of the workgroup.
+// grid (ceil(n / 64), P), 256 threads
+// ---------------------------------------------------------------------------
+constexpr int WY_LDV = 256 + 4;
+__global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (!sc->eigen_done) return;
+    __shared__ __attribute__((aligned(16))) double Vp[16 * WY_LDV];
+    const int n = c.n, ld = c.ld;
+    const size_t slab = eig_slab(ld);
+    const double *base = d.eig_work + (size_t) 4 * p * slab;
+    const double *V = base + slab;
+    const double *tau = base + slab + (size_t) 2 * n * n;
+    const double *Tg = tau + n;
+    const double *M = base + 3 * slab;
+    double *Bp = d.B + (size_t) p * ld * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int npanel = (n + 15) >> 4, nrt = (n + 15) >> 4;
+    const int col = (blockIdx.x * 4 + wave) * 16 + fr;
+    const bool live = (blockIdx.x * 4 + wave) * 16 < n;
+    d4_eig q[16];
+#pragma unroll
+    for (int rt = 0; rt < 16; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * rt + fk + 4 * r;
+            q[rt][r] = (live && row < n && col < n) ? M[(size_t) row * n + col] : 0.;
+        }
+    for (int b = 0; b < npanel; b++) {
+        const int i0 = 16 * b, reach = min(n, i0 + 16);
+        __syncthreads();
+        for (int e = tid; e < 16 * 256; e += 256) {
+            const int j = e >> 8, k = e & 255;
+            Vp[j * WY_LDV + k] = (i0 + j < n && k < reach) ? V[(size_t) (i0 + j) * n + k] : 0.;
+        }
+        double tv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = 4 * ks + fk;
+            tv[ks] = kk <= fr ? Tg[(size_t) b * 256 + kk * 16 + fr] : 0.;
+        }
+        __syncthreads();
+        if (!live) continue;
+        d4_eig w = { 0., 0., 0., 0. };
+#pragma unroll
+        for (int rt = 0; rt < 16; rt++) {
+            if (16 * rt < reach) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Vp[fr * WY_LDV + 16 * rt + 4 * r + fk],
+                            q[rt][r], w, 0, 0, 0);
+            }
+        }
+        d4_eig w2 = { 0., 0., 0., 0. };
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[ks], w[ks], w2, 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 16; rt++) {
+            if (16 * rt < reach) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    q[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            -Vp[(4 * ks + fk) * WY_LDV + 16 * rt + fr], w2[ks], q[rt], 0, 0, 0);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int rt = 0; rt < 16; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * rt + fk + 4 * r;
+                if (rt < nrt && row < n && col < n) Bp[(size_t) row * ld + col] = q[rt][r];
+            }
     }
 }
 

@@ -616,52 +616,37 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     dc_wave_sync();
 }
 
-// ---- B = H(n-1) ... H(1) Q_T, the reflectors applied in blocked (compact WY) form on the matrix
-// cores.  V (global, n x n, row i = u_i, zero from column i on), tau[i] = 1 / h_i (0: no
-// reflector), Q (LDS) = Q_T on entry.  Panel b = reflectors 16b .. 16b+15:
-//     H(16b+15) ... H(16b) = I - V_b T_b^T V_b^T,   T_b upper triangular (LAPACK dlarft, forward),
-//     T(0:i, i) = -tau_i T(0:i, 0:i) (V_b^T V_b)(0:i, i),  T(i, i) = tau_i.
-// 1. Wavefront w builds T_w: Gram matrix by MFMA (all of its reflector entries requested up
-//    front: V sits in L2), written to its LDS patch; then lane l < 16 owns ROW l of T in
-//    registers and runs the 16-step recurrence on its own (it needs only its row and column i of
-//    the Gram matrix, a broadcast read): no wavefront hand-overs.  T_w goes to global (Tg).
-// 2. Panels in the order the reflectors act.  The 16 x n panel is staged in LDS once for all
-//    wavefronts (the next one is prefetched into registers meanwhile); wavefront w owns the
-//    16-column tile w of Q: W = V_b^T Q, W <- T_b^T W (the accumulator layout of one product IS
-//    the B-operand layout of the next), Q -= V_b W; rows beyond the reflectors' reach skipped.
-// k index of a contraction over rows: k(ks, fk) = 8 (ks >> 1) + 2 fk + (ks & 1), so a lane's two
-// k-steps read one 16-byte piece of a reflector.
-// scratch (LDS): 16 * 132 doubles; Tg (global): 16 * 256 doubles.
-__device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
-        double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
+// T factors of the reflector panels (see dc_apply_reflectors): T_b for panel b = reflectors
+// 16b .. 16b+15, one wavefront per panel, written to Tg[b][16][16].  V: global n x n (row i =
+// u_i, zero from column i on), tau[i] = 1 / h_i or 0.  scratch (LDS): 16 x 17 doubles per
+// wavefront.  All threads of the workgroup call it.
+__device__ inline void dc_build_T(int n, const double *V, const double *tau, double *Tg,
+        double *scratch)
 {
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const int NW = T >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int npanel = (n + 15) >> 4;
-    constexpr int LS = 17, LDV = 132;
-    // (outpos, if any, lives in the work area this stage reuses: n <= 16 then, one entry each)
-    const int ocol = (outpos && tid < n * n) ? outpos[tid % n] : -1;
-    __syncthreads();      // the merge work area is free; tau and V are visible
-    // ---- 1. T_b, one wavefront per panel ------------------------------------------------------
+    constexpr int LS = 17;
     for (int b = wave; b < npanel; b += NW) {
         double *Sb = scratch + (size_t) wave * 16 * LS;
         const int i0 = 16 * b, reach = min(n, i0 + 16);       // rows < reach can be non-zero
         const int refl = i0 + fr;
         const double *vrow = V + (size_t) min(refl, n - 1) * n;
-        double va[DC_KSTEPS];
-#pragma unroll
-        for (int q = 0; q < DC_KSTEPS / 2; q++) {
-            const int k0 = 8 * q + 2 * fk;
-            va[2 * q] = (refl < n && k0 < reach) ? vrow[k0] : 0.;
-            va[2 * q + 1] = (refl < n && k0 + 1 < reach) ? vrow[k0 + 1] : 0.;
-        }
         dc_d4 acc = { 0., 0., 0., 0. };
+        for (int r0 = 0; r0 < reach; r0 += 4 * DC_KSTEPS) {
+            double va[DC_KSTEPS];
 #pragma unroll
-        for (int q = 0; q < DC_KSTEPS / 2; q++) {
-            if (8 * q < reach) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q], va[2 * q], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q + 1], va[2 * q + 1], acc, 0, 0, 0);
+            for (int q = 0; q < DC_KSTEPS / 2; q++) {
+                const int k0 = r0 + 8 * q + 2 * fk;
+                va[2 * q] = (refl < n && k0 < reach) ? vrow[k0] : 0.;
+                va[2 * q + 1] = (refl < n && k0 + 1 < reach) ? vrow[k0 + 1] : 0.;
+            }
+#pragma unroll
+            for (int q = 0; q < DC_KSTEPS / 2; q++) {
+                if (r0 + 8 * q < reach) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q], va[2 * q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2 * q + 1], va[2 * q + 1], acc, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -682,6 +667,35 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
         }
         dc_wave_sync();
     }
+}
+
+// ---- B = H(n-1) ... H(1) Q_T, the reflectors applied in blocked (compact WY) form on the matrix
+// cores.  V (global, n x n, row i = u_i, zero from column i on), tau[i] = 1 / h_i (0: no
+// reflector), Q (LDS) = Q_T on entry.  Panel b = reflectors 16b .. 16b+15:
+//     H(16b+15) ... H(16b) = I - V_b T_b^T V_b^T,   T_b upper triangular (LAPACK dlarft, forward),
+//     T(0:i, i) = -tau_i T(0:i, 0:i) (V_b^T V_b)(0:i, i),  T(i, i) = tau_i.
+// 1. Wavefront w builds T_w: Gram matrix by MFMA (all of its reflector entries requested up
+//    front: V sits in L2), written to its LDS patch; then lane l < 16 owns ROW l of T in
+//    registers and runs the 16-step recurrence on its own (it needs only its row and column i of
+//    the Gram matrix, a broadcast read): no wavefront hand-overs.  T_w goes to global (Tg).
+// 2. Panels in the order the reflectors act.  The 16 x n panel is staged in LDS once for all
+//    wavefronts (the next one is prefetched into registers meanwhile); wavefront w owns the
+//    16-column tile w of Q: W = V_b^T Q, W <- T_b^T W (the accumulator layout of one product IS
+//    the B-operand layout of the next), Q -= V_b W; rows beyond the reflectors' reach skipped.
+// k index of a contraction over rows: k(ks, fk) = 8 (ks >> 1) + 2 fk + (ks & 1), so a lane's two
+// k-steps read one 16-byte piece of a reflector.
+// scratch (LDS): 16 * 132 doubles; Tg (global): 16 * 256 doubles.
+__device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
+        double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
+{
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int npanel = (n + 15) >> 4;
+    constexpr int LDV = 132;
+    // (outpos, if any, lives in the work area this stage reuses: n <= 16 then, one entry each)
+    const int ocol = (outpos && tid < n * n) ? outpos[tid % n] : -1;
+    __syncthreads();      // the merge work area is free; tau and V are visible
+    dc_build_T(n, V, tau, Tg, scratch);
     __threadfence();
     __syncthreads();
     // ---- 2. panels ---------------------------------------------------------------------------------
@@ -940,7 +954,15 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     __syncthreads();
 
     DC_STAMP(22);
-    if (ext_top) return;
+    if (ext_top) {
+        // (the products run as separate kernels; with stashed reflectors the second one is
+        // cma_eig_wy and needs the panels' T factors: G + 2 n^2 = [tau (n) | T (npanel x 256)])
+        if (hv) {
+            __syncthreads();
+            dc_build_T(n, Qh, taug, taug + n, scratch);
+        }
+        return;
+    }
     if (hv) {
         dc_apply_reflectors(Q, n, Qh, taug, taug + n, scratch, Bout, ldb,
                 single ? W.outpos : nullptr);

@@ -15,3 +15,4 @@ print("dc: copy/scale %.1f leaves %.1f merges L1 %.1f L2 %.1f L3 %.1f finalGEMM 
 print("top merge: sort %.1f deflate %.1f secular %.1f loewner %.1f order+F %.1f gemm %.1f" % (us(24,25),us(25,26),us(26,27),us(27,28),us(28,29),us(29,30)))
 print("top secular iterations", t[31], "k/nd/nr?")
 print("leaf batches (blk 0..3)", t[12:16])
+print("raw stamps 0..5 (us from 0):", [round((t[i]-t[0])/100.,1) for i in range(6)])
