@@ -37,6 +37,7 @@
 #include <limits>
 #include <string>
 #include <stdexcept>
+#include <functional>
 #include <vector>
 
 #include "objectives.h"
@@ -300,7 +301,13 @@ struct Cma {
     double& isc(int i, int j) { return invsqrtC[(size_t) i * n + j]; }
     double* x(int k) { return &arx[(size_t) k * n]; }
 
-    double evaluate(const double *p) { return bbo_objective_eval(obj, n, p, aux.data()); }
+    /* set by a caller that optimizes something else than a built-in objective through this
+     * object (CCPSO's local search on the swarm weights, ccpso.cpp:400-412) */
+    std::function<double(const double*)> fhook;
+    double evaluate(const double *p)
+    {
+        return fhook ? fhook(p) : bbo_objective_eval(obj, n, p, aux.data());
+    }
 
     /* base_cmaes.cpp:54-134 */
     void init_base(const double *guess)
@@ -359,7 +366,7 @@ struct Cma {
         lower.assign(lo, lo + n);
         upper.assign(up, up + n);
         aux.assign(n, 0.);
-        bbo_objective_aux(obj, n, aux.data());
+        if (!fhook) bbo_objective_aux(obj, n, aux.data());
         init_base(guess);
 
         if (variant == 2) {

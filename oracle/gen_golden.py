@@ -319,6 +319,33 @@ def gen_ccpso_runs(R):
     dump("ccpso_runs.json", runs)
 
 
+def gen_ccpso_local_runs(R):
+    """CCPSOSearch WITH its local optimizer (ccpso.cpp:116-118, 371-435; CMAES / ActiveCMAES on
+    the swarm weights every `localfreq` generations): state after generations 1, 2, 4, 10, 20.
+    One `pps` entry per case -- the reference only has defined behaviour while the number of
+    swarms does not grow (Cmaes::init resize()s _b, _c without clearing, cmaes.cpp:53-54)."""
+    runs = []
+    cases = [(24, "rosenbrock", 71, "cmaes", 3, dict(mfev=10 ** 8, stol=1e-9, np_=8, pps=[4])),
+             (20, "rastrigin", 72, "active", 2, dict(mfev=10 ** 8, stol=1e-9, np_=10, pps=[5])),
+             (30, "ellipsoid", 73, "cmaes", 1, dict(mfev=10 ** 8, stol=1e-9, np_=12, pps=[6],
+                                                    correct=False))]
+    for n, obj, seed, variant, lf, kw in cases:
+        R.seed(seed)
+        lo, up = -5. * np.ones(n), 5. * np.ones(n)
+        h = po.ccpso(R, local=po.cma(R, variant, 400, 1e-8, 8), localfreq=lf, **kw)
+        h.init(obj, lo, up, np.zeros(n))
+        rec = {"params": kw, "n": n, "objective": obj, "seed": seed, "box": 5.,
+               "local": {"variant": variant, "mfev": 400, "tol": 1e-8, "np": 8, "localfreq": lf},
+               "states": []}
+        for gen in range(1, 21):
+            h.iterate()
+            if gen in (1, 2, 4, 10, 20):
+                rec["states"].append({"gen": gen, **{k: hx(h.get(k)) for k in CCPSO_KEYS}})
+        runs.append(rec)
+        h.destroy()
+    dump("ccpso_local_runs.json", runs)
+
+
 def main():
     po.build_ref()
     R = po.reference()
@@ -328,7 +355,8 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
     gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
             "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs,
-            "sansde": gen_sansde_runs, "cso": gen_cso_runs, "ccpso": gen_ccpso_runs}
+            "sansde": gen_sansde_runs, "cso": gen_cso_runs, "ccpso": gen_ccpso_runs,
+            "ccpso_local": gen_ccpso_local_runs}
     for name, fn in gens.items():
         if only is None or only == name:
             fn(R)

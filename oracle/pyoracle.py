@@ -103,6 +103,12 @@ class _Lib:
                 f("ccpso_create").restype = C.c_void_p
                 f("ccpso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int),
                                               C.c_int, C.c_int, C.c_double]
+            if hasattr(L, p + "ccpso_set_local"):
+                f("ccpso_set_local").restype = None
+                f("ccpso_set_local").argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+            if hasattr(L, p + "ccpso_local_fresh"):
+                f("ccpso_local_fresh").restype = None
+                f("ccpso_local_fresh").argtypes = [C.c_void_p, C.c_int]
             if hasattr(L, p + "cso_create"):
                 f("cso_create").restype = C.c_void_p
                 f("cso_create").argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
@@ -287,10 +293,19 @@ def cso(lib, mfev, stol, np_, pcompete=3, ring=False, correct=True, vmax=0.2):
                                                    int(correct), vmax))
 
 
-def ccpso(lib, mfev, stol, np_, pps, correct=True, pcauchy=-1.):
+def ccpso(lib, mfev, stol, np_, pps, correct=True, pcauchy=-1., local=None, localfreq=10,
+          local_seed=0, local_fresh=False):
+    """`local`: a cma Handle (ownership passes to the CCPSO object); local_fresh (oracle only):
+    every local search starts from B = C = I like the device's, not from the reference's leftovers"""
     arr = (C.c_int * len(pps))(*[int(v) for v in pps])
-    return Handle(lib, "ccpso", lib.f("ccpso_create")(mfev, stol, np_, arr, len(pps),
-                                                       int(correct), pcauchy))
+    h = Handle(lib, "ccpso", lib.f("ccpso_create")(mfev, stol, np_, arr, len(pps),
+                                                    int(correct), pcauchy))
+    if local is not None:
+        lib.f("ccpso_set_local")(h.ptr, local.ptr, int(localfreq), int(local_seed))
+        local.ptr = None
+        if local_fresh:
+            lib.f("ccpso_local_fresh")(h.ptr, 1)
+    return h
 
 
 def apso(lib, mfev, tol, np_, correct=True):

@@ -361,6 +361,11 @@ struct CsoProbe: CSOSearch {
 
 struct CcpsoProbe: CCPSOSearch {
     using CCPSOSearch::CCPSOSearch;
+    void set_local(MultivariateOptimizer *l, int freq)
+    {
+        _local = l;
+        _localfreq = freq;
+    }
     int get(const std::string &k, double *out, int cap)
     {
         auto flat = [&](const std::vector<std::vector<double>> &m) {
@@ -667,6 +672,14 @@ POP_API(cso, CsoProbe,
 POP_API(ccpso, CcpsoProbe,
         (int mfev, double stol, int np, const int *pps, int npps, int correct, double pcauchy),
         (mfev, stol, np, const_cast<int*>(pps), npps, correct != 0, pcauchy, nullptr, 10))
+
+/* CCPSO with its local optimizer: takes ownership of `base` (a ref_cma_create handle) */
+void ref_ccpso_set_local(void *p, void *base, int localfreq, unsigned long long)
+{
+    auto *hp = static_cast<RefPop<CcpsoProbe>*>(p);
+    hp->base.reset(static_cast<RefCma*>(base));
+    hp->alg->set_local(hp->base->alg.get(), localfreq);
+}
 
 POP_API(apso, ApsoProbe,
         (int mfev, double tol, int np, int correct),

@@ -223,3 +223,25 @@ def test_ccpso_generations(oracle_lib, idx):
         for k, v in st.items():
             if k != "gen":
                 np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="gen %d %s" % (gen, k))
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_ccpso_local_search_generations(oracle_lib, idx):
+    """CCPSOSearch with its local optimizer (ccpso.cpp:116-118, 371-435): the weights of the
+    swarms optimized by CMAES / ActiveCMAES every `localfreq` generations -- including the
+    reference's habit of starting a search from the previous one's B and C (cmaes.cpp:53-54) --
+    at generations 1, 2, 4, 10, 20, bit for bit (tests/golden/ccpso_local_runs.json)"""
+    rec = load("ccpso_local_runs.json")[idx]
+    n, box, lc = rec["n"], rec["box"], rec["local"]
+    oracle_lib.seed(rec["seed"])
+    base = po.cma(oracle_lib, lc["variant"], lc["mfev"], lc["tol"], lc["np"])
+    h = po.ccpso(oracle_lib, local=base, localfreq=lc["localfreq"], **rec["params"])
+    h.init(rec["objective"], -box * np.ones(n), box * np.ones(n), np.zeros(n))
+    gen = 0
+    for st in rec["states"]:
+        while gen < st["gen"]:
+            h.iterate()
+            gen += 1
+        for k, v in st.items():
+            if k != "gen":
+                np.testing.assert_array_equal(h.get(k), unhex(v), err_msg="gen %d %s" % (gen, k))

@@ -195,6 +195,34 @@ def test_ccpso_bit_exact(oracle_lib, ref_lib, capfd, n, npp, obj, pps, kw):
     capfd.readouterr()      # the reference prints _fyhat every generation (ccpso.cpp:121)
 
 
+@pytest.mark.parametrize("n,npp,obj,cps,variant,lf", [
+    (24, 8, "rosenbrock", 4, "cmaes", 3),
+    (20, 10, "rastrigin", 5, "active", 2),
+    (30, 12, "ellipsoid", 6, "cmaes", 1),
+    (16, 6, "griewank", 2, "active", 5)])
+def test_ccpso_with_local_optimizer_bit_exact(oracle_lib, ref_lib, capfd, n, npp, obj, cps,
+                                              variant, lf):
+    """CCPSO's localSearch (ccpso.cpp:371-435) with a CMA-ES variant as `local`, one swarm size
+    (the reference's Cmaes::init has undefined behaviour when the dimension grows between two
+    optimize() calls on the same object, cmaes.cpp:53-54)"""
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    hs = []
+    for L in (oracle_lib, ref_lib):
+        L.seed(17)
+        h = po.ccpso(L, 10 ** 8, 1e-9, npp, [cps], local=po.cma(L, variant, 300, 1e-8, 8),
+                     localfreq=lf)
+        h.init(obj, lo, up, np.zeros(n))
+        hs.append(h)
+    for it in range(25):
+        for h in hs:
+            h.iterate()
+        for k in ("x", "y", "yhat", "fx", "fy", "k", "ibest", "strat", "fyhat", "phat", "fev", "is",
+                  "nswarm", "cpswarm", "improved"):
+            np.testing.assert_array_equal(hs[0].get(k), hs[1].get(k),
+                                          err_msg="ccpso+local n=%d it=%d %s" % (n, it, k))
+    capfd.readouterr()
+
+
 @pytest.mark.parametrize("driver", ["bipop", "ipop"])
 @pytest.mark.parametrize("variant", ["active", "cmaes"])
 def test_restart_drivers_bit_exact(oracle_lib, ref_lib, driver, variant):
