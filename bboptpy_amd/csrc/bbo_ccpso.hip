@@ -370,9 +370,29 @@ int CcpsoEngine::set(const std::string &k, int p, const double *in, int count)
 {
     if (!inited_) throw Error(BBO_ERR_STATE, "set() before initialize()");
     BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
-    (void) count;
     if (k == "profile") {
         timer_.enable(in[0] != 0., K_COUNT);
+        return 1;
+    }
+    // what a host-side local search (ccpso.cpp:371-435; the Python class drives it) hands back:
+    // the re-weighted context vector, its value, the evaluations it spent, the `improved` flag
+    BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));
+    if (k == "yhat") {
+        BBO_REQUIRE(count == c_.n, "set yhat: wrong element count");
+        std::vector<double> v(c_.ld, 0.);
+        std::copy(in, in + c_.n, v.begin());
+        yhat_.upload(v.data(), c_.ld, (size_t) p * c_.ld);
+        return 1;
+    }
+    if (k == "fyhat" || k == "fev" || k == "improved") {
+        BBO_REQUIRE(count == 1, "set: wrong element count");
+        CcpScal s;
+        scal_.download(&s, 1, p);
+        if (k == "fyhat") s.fyhat = in[0];
+        else if (k == "fev") s.fev = (int) in[0];
+        else s.improved = in[0] != 0. ? 1 : 0;
+        scal_.upload(&s, 1, p);
         return 1;
     }
     throw Error(BBO_ERR_KEY, "unknown or read-only state key '" + k + "'");

@@ -151,6 +151,14 @@ class MultivariateSearch:
         except Exception:
             pass
 
+    def reseed(self, seed):
+        """(extension) a new generator seed for the next initialize() / optimize(); the handle
+        is re-created (the seed is part of bbo_params)"""
+        self._params.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if self._handle is not None:
+            _ffi.lib().bbo_destroy(self._handle)
+            self._handle = None
+
     def _check(self, status):
         if status < 0:
             err = self._binding.error if self._binding is not None else None
@@ -376,15 +384,21 @@ class CSO(MultivariateSearch):
 class CCPSO(MultivariateSearch):
     """CCPSO(mfev, sigmatol, np, pps, npps, correct=True, pcauchy=-1., local=None, localfreq=10)
     -- :291-295 (cooperatively coevolving PSO, Li & Yao 2012; ccpso.cpp).  `pps` lists the
-    candidate swarm sizes (each must divide n).  The optional `local` optimizer of the reference
-    is not supported on the device path."""
+    candidate swarm sizes (each must divide n).
+
+    `local` (ccpso.cpp:116-118, 371-435): another optimizer of this package (any object with
+    optimize(f, lower, upper, guess) -> solution carrying .x and .n_evals).  Every `localfreq`
+    generations one weight per swarm, scaling that swarm's coordinates of the context vector, is
+    optimized by it inside the box that keeps the scaled vector in bounds, and the result
+    replaces the context vector if it is better.  The generations run on the device; the local
+    search is driven from here (its objective evaluates on the host: the callable itself, or the
+    built-in's formula), one population only.  Each search starts `local` afresh with the seed
+    base + search index (the reference's CMA-ES objects start from the previous search's
+    matrices, cmaes.cpp:53-54 -- not reproduced)."""
     _algo = _ffi.ALGO_CCPSO
 
     def __init__(self, mfev, sigmatol, np, pps, npps=None, correct=True, pcauchy=-1., local=None,
                  localfreq=10, **ext):
-        if local is not None:
-            raise NotImplementedError("CCPSO: the local optimizer hook is not available on the "
-                                      "device path (pass local=None)")
         super().__init__(**ext)
         pps = [int(v) for v in pps]
         npps = len(pps) if npps is None else int(npps)
@@ -396,6 +410,87 @@ class CCPSO(MultivariateSearch):
         for k in range(npps):
             p.pps[k] = pps[k]
         p.correct, p.pcauchy = int(bool(correct)), float(pcauchy)
+        if local is not None:
+            if not callable(getattr(local, "optimize", None)):
+                raise TypeError("CCPSO: local must provide optimize(f, lower, upper, guess)")
+            if p.populations != 1:
+                raise ValueError("CCPSO: the local optimizer works on one population")
+        self._local, self._localfreq = local, int(localfreq)
+        self._nlocal = 0
+        self._local_seed0 = getattr(getattr(local, "_params", None), "seed", 0)
+
+    # ---- the reference's loop with the local search between generations ------------------
+    def initialize(self, f, lower, upper, guess):
+        super().initialize(f, lower, upper, guess)
+        if isinstance(f, str):
+            from . import objectives as _objectives
+            f = getattr(_objectives, f, None)
+        self._f_host = f if callable(f) else None
+        self._lower_h, self._upper_h = _as_vec(lower, "lower"), _as_vec(upper, "upper")[:self._n]
+        self._nlocal = 0
+
+    def iterate(self):
+        gen = int(self.get_state("it")[0]) if self._local is not None else 0
+        super().iterate()
+        if self._local is not None and self._localfreq > 0 and gen % self._localfreq == 0:
+            self._local_search()
+
+    def optimize(self, f, lower, upper, guess):
+        if self._local is None:
+            return super().optimize(f, lower, upper, guess)
+        self.initialize(f, lower, upper, guess)
+        mfev = self._params.mfev
+        while True:                                   # ccpso.cpp:135-148
+            self.iterate()
+            if int(self.get_state("fev")[0]) >= mfev:
+                converged = False
+                break
+            if int(self.get_state("conv")[0]):
+                converged = True
+                break
+        return MultivariateSolution(self.get_state("yhat"), int(self.get_state("fev")[0]),
+                                    converged)
+
+    def _local_search(self):
+        """CCPSOSearch::localSearch, ccpso.cpp:371-435"""
+        n = self._n
+        f = self._f_host
+        if f is None:
+            raise RuntimeError("CCPSO: the local optimizer needs a callable objective")
+        yhat = self.get_state("yhat")
+        k = self.get_state("k").astype(int)           # position -> coordinate, swarm-major
+        cps, nsw = int(self.get_state("cpswarm")[0]), int(self.get_state("nswarm")[0])
+        group = _np.empty(n, dtype=int)
+        group[k] = _np.repeat(_np.arange(nsw), cps)
+        scale = _np.where(_np.abs(yhat) < 1e-3, _np.where(yhat > 0., 1e-3, -1e-3), yhat)
+        lb, ub = self._lower_h / scale, self._upper_h / scale
+        lb, ub = _np.minimum(lb, ub), _np.maximum(lb, ub)
+        wlb = _np.full(nsw, -_np.inf)
+        wub = _np.full(nsw, _np.inf)
+        _np.maximum.at(wlb, group, lb)
+        _np.minimum.at(wub, group, ub)
+        wguess = _np.maximum(wlb, _np.minimum(1., wub))
+
+        def faux(w):
+            return float(f(yhat * _np.asarray(w, dtype=_np.float64)[group]))
+
+        if hasattr(self._local, "reseed"):
+            self._local.reseed(self._local_seed0 + self._nlocal)
+        self._nlocal += 1
+        sol = self._local.optimize(faux, wlb, wub, wguess)
+        w = _np.asarray(sol.x, dtype=_np.float64)
+        fev = int(self.get_state("fev")[0]) + int(sol.n_evals)
+        trial = yhat * w[group]
+        inside = (not self._params.correct) or bool(
+            _np.all((trial >= self._lower_h) & (trial <= self._upper_h)))
+        if inside:
+            fwy = float(f(trial))
+            fev += 1
+            if fwy < float(self.get_state("fyhat")[0]):
+                self.set_state("yhat", trial)
+                self.set_state("fyhat", [fwy])
+                self.set_state("improved", [1.])
+        self.set_state("fev", [float(fev)])
 
 
 class APSO(MultivariateSearch):

@@ -84,5 +84,61 @@ def test_invalid_swarm_size_is_rejected(hip):
     g = hip.CCPSO(mfev=1000, sigmatol=1e-5, np=10, pps=[4], seed=3)
     with pytest.raises(Exception):
         g.initialize(hip.objectives.sphere, -np.ones(6), np.ones(6), np.zeros(6))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):         # a local optimizer must offer optimize()
         hip.CCPSO(mfev=1000, sigmatol=1e-5, np=10, pps=[2], local=object())
+
+
+@pytest.mark.parametrize("n,npp,cps,obj,variant,lf", [
+    (24, 8, 4, "ellipsoid", "cmaes", 2),
+    (20, 10, 5, "sphere", "active", 3)])
+def test_local_optimizer_hook_matches_oracle(hip, oracle_lib, n, npp, cps, obj, variant, lf):
+    """CCPSO with its local optimizer (ccpso.cpp:116-118, 371-435): the device runs the
+    generations, the Python class drives localSearch with a device CMA-ES on the swarm weights
+    (objective evaluated on the host); the oracle -- pinned bit for bit to the reference for this
+    path -- does the same with its own CMA-ES drawing the same Philox normals (search q: seed
+    base + q, started from B = C = I on both sides).  Same evaluation counts, same context
+    vector after every generation."""
+    seed, lseed = 31, 77
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    # (lambda = 16 >= 2 nswarm: with mu < n - 1 the first covariance matrices of plain CMA-ES
+    # have a repeated eigenvalue, whose eigenvectors -- and with them the samples -- are decided
+    # by rounding inside the eigensolver: same distribution, different trajectory)
+    Local = hip.CMAES if variant == "cmaes" else hip.ActiveCMAES
+    loc = Local(mfev=320, tol=1e-9, np=16, seed=lseed)
+    g = hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=npp, pps=[cps], local=loc, localfreq=lf,
+                  seed=seed)
+    o = po.ccpso(oracle_lib, 10 ** 8, 1e-12, npp, [cps],
+                 local=po.cma(oracle_lib, variant, 320, 1e-9, 16), localfreq=lf, local_seed=lseed,
+                 local_fresh=True)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    # the objective as a host callable that evaluates the oracle's own formula: every f value --
+    # in the generations and inside the local searches -- is then the same double on both
+    # sides, and the two CMA-ES runs rank their candidates identically
+    g.initialize(lambda x: oracle_lib.objective(obj, x), lo, up, np.zeros(n))
+    o.init(obj, lo, up, np.zeros(n))
+    improved_by_local = 0
+    for gen in range(10):
+        f_before = float(g.get_state("fyhat")[0])
+        g.iterate()
+        o.iterate()
+        tag = "gen %d" % gen
+        assert int(g.get_state("fev")[0]) == int(o.scalar("fev")), tag + " fev"
+        assert int(g.get_state("improved")[0]) == int(o.scalar("improved")), tag + " improved"
+        _close(g.get_state("yhat"), o.get("yhat"), 1e-8, tag + " yhat")
+        _close(g.get_state("fyhat"), [o.scalar("fyhat")], 1e-8, tag + " fyhat")
+        _close(g.get_state("x"), o.get("x"), 1e-8, tag + " x")
+        if gen % lf == 0 and float(g.get_state("fyhat")[0]) < f_before:
+            improved_by_local += 1
+    assert improved_by_local >= 1
+
+
+def test_local_optimizer_whole_run(hip):
+    """optimize() with a local optimizer: the reference's loop (generation, local search every
+    localfreq generations, budget test, spread test) driven from the Python class"""
+    n = 12
+    loc = hip.CMAES(mfev=200, tol=1e-8, np=8, seed=5)
+    g = hip.CCPSO(mfev=40000, sigmatol=1e-6, np=10, pps=[3], local=loc, localfreq=5, seed=9)
+    sol = g.optimize(hip.objectives.sphere, -5. * np.ones(n), 5. * np.ones(n), np.zeros(n))
+    assert sol.n_evals > 0 and float(np.sum(sol.x ** 2)) < 1e-3
+    with pytest.raises(TypeError):
+        hip.CCPSO(mfev=100, sigmatol=1e-6, np=4, pps=[2], local=object())
