@@ -57,10 +57,59 @@ __device__ inline bool pair_less(double fa, int ia, double fb, int ib)
     return fa < fb || (fa == fb && ia < ib);
 }
 
+// lane ^ LX exchange of a (key, index) pair inside a wavefront.  LX = 1, 2, 4, 8 stay inside a
+// 16-lane row and go through DPP moves (VALU, no LDS crossbar: quad_perm for 1 and 2,
+// row_half_mirror + quad reversal for 4, row_ror:8 for 8); 16 and 32 use the LDS permute.
+template<int CTRL>
+__device__ inline int sort_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+template<int LX>
+__device__ inline int sort_xor_lane(int v)
+{
+    if (LX == 1) return sort_dpp<0xB1>(v);                       // quad_perm:[1,0,3,2]
+    if (LX == 2) return sort_dpp<0x4E>(v);                       // quad_perm:[2,3,0,1]
+    if (LX == 4) return sort_dpp<0x1B>(sort_dpp<0x141>(v));      // half mirror, then [3,2,1,0]
+    if (LX == 8) return sort_dpp<0x128>(v);                      // row_ror:8
+    return __shfl_xor(v, LX, 64);
+}
+
+template<int LX>
+__device__ inline void sort_partner(double f, int i, double &fb, int &ib)
+{
+    const int lo = sort_xor_lane<LX>(__double2loint(f));
+    const int hi = sort_xor_lane<LX>(__double2hiint(f));
+    fb = __hiloint2double(hi, lo);
+    ib = sort_xor_lane<LX>(i);
+}
+
+// one compare-exchange stage between lanes LX apart (partner distance j = E LX)
+template<int E, int LX>
+__device__ inline void sort_wave_stage(double (&kf)[E], int (&ki)[E], int e0, int j, int k)
+{
+#pragma unroll
+    for (int u = 0; u < E; u++) {
+        double fb;
+        int ib;
+        sort_partner<LX>(kf[u], ki[u], fb, ib);
+        const int e = e0 + u;
+        // keep the smaller of the two where this element is the low end of an ascending pair (or
+        // the high end of a descending one), the larger otherwise; equal pairs (padding only:
+        // real entries differ in the index) may swap freely
+        const bool want_min = ((e & j) == 0) == ((e & k) == 0);
+        if (pair_less(fb, ib, kf[u], ki[u]) == want_min) {
+            kf[u] = fb;
+            ki[u] = ib;
+        }
+    }
+}
+
 // The sort proper, E = M / 1024 consecutive elements per thread in REGISTERS (M = the padded
 // size, 1024 E).  A compare-exchange stage with partner distance j runs
 //   j <  E          inside the thread,
-//   j <  64 E       between lanes of a wavefront (shuffle-xor by j / E): no barrier,
+//   j <  64 E       between lanes of a wavefront (lane ^ (j / E), DPP inside a 16-lane row): no barrier,
 //   j >= 64 E       through LDS (elements dumped once per merge phase, the classic in-place
 //                   stage with one barrier each, then reloaded).
 // For M = 4096 that is 14 barriers instead of 78.  Element e keeps the smaller of (itself, its
@@ -116,19 +165,13 @@ __device__ inline void bitonic_sort_regs(const double *f, int count, double *key
             }
         }
         for (; j >= E; j >>= 1) {
-            const int lx = j / E;
-#pragma unroll
-            for (int u = 0; u < E; u++) {
-                const double fb = __shfl_xor(kf[u], lx, 64);
-                const int ib = __shfl_xor(ki[u], lx, 64);
-                const int e = e0 + u;
-                const bool want_min = ((e & j) == 0) == ((e & k) == 0);
-                const bool less = pair_less(fb, ib, kf[u], ki[u]);
-                const bool greater = pair_less(kf[u], ki[u], fb, ib);
-                if (want_min ? less : greater) {
-                    kf[u] = fb;
-                    ki[u] = ib;
-                }
+            switch (j / E) {
+            case 1: sort_wave_stage<E, 1>(kf, ki, e0, j, k); break;
+            case 2: sort_wave_stage<E, 2>(kf, ki, e0, j, k); break;
+            case 4: sort_wave_stage<E, 4>(kf, ki, e0, j, k); break;
+            case 8: sort_wave_stage<E, 8>(kf, ki, e0, j, k); break;
+            case 16: sort_wave_stage<E, 16>(kf, ki, e0, j, k); break;
+            default: sort_wave_stage<E, 32>(kf, ki, e0, j, k); break;
             }
         }
 #pragma unroll
