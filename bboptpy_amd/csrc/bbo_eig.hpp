@@ -72,7 +72,7 @@ inline EigPlan eig_plan(int n, int ld)
         if (pl.dc) {
             // no QL chunk buffers; a 128 x 128 LDS matrix for the register-resident tail
             pl.rc = 0;
-            pl.lds_bytes = fixed + (size_t) 128 * 128 * sizeof(double);
+            pl.lds_bytes = fixed + (size_t) 128 * 130 * sizeof(double);
         } else {
             pl.rc = 2048;
             pl.lds_bytes = fixed + (size_t) 2 * pl.rc * 16;
@@ -179,11 +179,12 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
             const int k = 32 * a + 8 * q + b;
             a_[a][b] = (j < n && k < n) ? C[(size_t) j * ld + k] : 0.;
         }
-    for (int x = tid; x < n * As.ld; x += T) As.a[x] = 0.;
     for (int k = tid; k < 128; k += T) {
         dv[k] = k < n ? C[(size_t) (n - 1) * ld + k] : 0.;
         hvec[k] = 0.;
     }
+    __syncthreads();      // (C may live in the LDS block that becomes the stash: read it first)
+    for (int x = tid; x < n * As.ld; x += T) As.a[x] = 0.;
 
     // One Householder step, specialised on how many 32-column groups the active block (rows and
     // columns < i) still covers: the matrix-vector product and the rank-2 update then shrink with
@@ -355,6 +356,17 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
         uv[k] = 0.;
         wv[k] = 0.;
     }
+    // hybrid: the leading 128 x 128 block -- part of every streaming step -- sits in the LDS
+    // matrix that later holds the register tail's stash (row stride 130: conflict-free 16-byte
+    // reads by 4 lanes per row); the steps stream only the other three quarters from L2
+    constexpr int LB = 130;
+    double *L11 = As ? As->a : nullptr;
+    if (L11)
+        for (int q = tid; q < 128 * 64; q += T) {
+            const int r = q >> 6, c2 = (q & 63) * 2;
+            *reinterpret_cast<double2*>(&L11[r * LB + c2]) =
+                    make_double2(C[(size_t) r * ld + c2], C[(size_t) r * ld + c2 + 1]);
+        }
     const int rq = tid & 3, rj0 = tid >> 2;   // 4 lanes per row, lane q owns columns 32a + 8q + b
     for (int i = n - 1; i > 0 && i >= NS; i--) {
         __syncthreads();
@@ -369,7 +381,9 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
                 ev[i] = f;
                 hvec[i] = 0.;
             }
-            for (int k = tid; k < ir; k += T) dv[k] = k < i ? A(i - 1, k) : 0.;
+            for (int k = tid; k < ir; k += T)
+                dv[k] = k < i ? ((L11 && i - 1 < 128 && k < 128) ? L11[(i - 1) * LB + k] : A(i - 1, k))
+                              : 0.;
             continue;
         }
         double g = sqrt(h0);
@@ -381,15 +395,17 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
         // g = A u over rows j < i
         for (int j = rj0; j < i; j += T / 4) {
             const double *row = A.a + (size_t) j * lda + 8 * rq;
+            const double *lrow = (L11 && j < 128) ? L11 + j * LB + 8 * rq : nullptr;
             double acc0 = 0., acc1 = 0.;
             for (int a0 = 0; a0 < GA; a0 += 4) {
-                double2 x[4][4];
+                const double *src = (lrow && a0 == 0) ? lrow : row + 32 * a0;   // columns < 128 of
+                double2 x[4][4];                                               // rows < 128: LDS
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
                     for (int b = 0; b < 4; b++)
                         x[a][b] = a0 + a < GA
-                                ? *reinterpret_cast<const double2*>(row + 32 * (a0 + a) + 2 * b)
+                                ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
                                 : make_double2(0., 0.);
 #pragma unroll
                 for (int a = 0; a < 4; a++)
@@ -417,15 +433,17 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
         // A -= u w^T + w u^T on rows j < i; row i-1 becomes the next d
         for (int j = rj0; j < i; j += T / 4) {
             double *row = A.a + (size_t) j * lda + 8 * rq;
+            double *lrow = (L11 && j < 128) ? L11 + j * LB + 8 * rq : nullptr;
             const double uj = uv[j], wj = wv[j];
             for (int a0 = 0; a0 < GA; a0 += 4) {
+                double *src = (lrow && a0 == 0) ? lrow : row + 32 * a0;
                 double2 x[4][4];
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
                     for (int b = 0; b < 4; b++)
                         x[a][b] = a0 + a < GA
-                                ? *reinterpret_cast<const double2*>(row + 32 * (a0 + a) + 2 * b)
+                                ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
                                 : make_double2(0., 0.);
 #pragma unroll
                 for (int a = 0; a < 4; a++)
@@ -438,7 +456,7 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
                             double2 v;
                             v.x = __builtin_fma(-u2.x, wj, __builtin_fma(-w2.x, uj, x[a][b].x));
                             v.y = __builtin_fma(-u2.y, wj, __builtin_fma(-w2.y, uj, x[a][b].y));
-                            *reinterpret_cast<double2*>(row + 32 * (a0 + a) + 2 * b) = v;
+                            *reinterpret_cast<double2*>(src + 32 * a + 2 * b) = v;
                             if (j == i - 1) *reinterpret_cast<double2*>(&dv[kk]) = v;
                         }
                     }
@@ -454,7 +472,7 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
     if (As) {
         // the leading 128 x 128 block: reduce and accumulate in registers, Q block back to A
         __syncthreads();
-        eig_tred_accum_reg128(A.a, lda, 128, *As, dv, ev, uv, wv, gv, hvec, td, tid, nullptr,
+        eig_tred_accum_reg128(L11, LB, 128, *As, dv, ev, uv, wv, gv, hvec, td, tid, nullptr,
                 A.a, lda, false, accumulate);
         for (int k = tid; k < nr; k += T) {
             uv[k] = 0.;

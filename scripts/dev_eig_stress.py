@@ -8,7 +8,7 @@ import bboptpy_amd as hip
 from bboptpy_amd import _ffi
 from test_cma_gpu import _spd_cases
 worst = {}
-ns = list(range(2, 150)) + [150, 160, 176, 191, 192, 193, 200, 224, 240, 255, 256]
+ns = (list(range(2, 150)) + [150, 160, 176, 191, 192, 193, 200, 224, 240, 255, 256]) if len(sys.argv) < 2 else list(range(int(sys.argv[1]), int(sys.argv[2]) + 1))
 for n in ns:
     rng = np.random.default_rng(1000 + n)
     g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=max(4, 2 * n), seed=1)
