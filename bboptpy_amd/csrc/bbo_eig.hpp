@@ -368,6 +368,19 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
                     make_double2(C[(size_t) r * ld + c2], C[(size_t) r * ld + c2 + 1]);
         }
     const int rq = tid & 3, rj0 = tid >> 2;   // 4 lanes per row, lane q owns columns 32a + 8q + b
+    // ... and the block below it (rows 128.., columns < 128) stays in REGISTERS: thread (row
+    // 128 + rj0, class rq) keeps its 32 entries from load to the end of the streaming steps (the
+    // rows turn into reflector stash one by one, written to global memory whole).  What still
+    // streams from L2 is the half of the matrix in columns >= 128.
+    double2 r21[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = 128 + rj0, c2 = 32 * a + 8 * rq + 2 * b;
+            r21[a][b] = (L11 && r < n) ? make_double2(C[(size_t) r * ld + c2], C[(size_t) r * ld + c2 + 1])
+                                       : make_double2(0., 0.);
+        }
     for (int i = n - 1; i > 0 && i >= NS; i--) {
         __syncthreads();
         const int ir = (i + 31) & ~31, GA = ir >> 5;
@@ -384,6 +397,17 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
             for (int k = tid; k < ir; k += T)
                 dv[k] = k < i ? ((L11 && i - 1 < 128 && k < 128) ? L11[(i - 1) * LB + k] : A(i - 1, k))
                               : 0.;
+            if (L11 && i - 1 >= 128) {
+                // (columns < 128 of that row are register-resident: its owners supply them)
+                __syncthreads();
+                if (128 + rj0 == i - 1) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            *reinterpret_cast<double2*>(&dv[32 * a + 8 * rq + 2 * b]) = r21[a][b];
+                }
+            }
             continue;
         }
         double g = sqrt(h0);
@@ -399,14 +423,22 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
             double acc0 = 0., acc1 = 0.;
             for (int a0 = 0; a0 < GA; a0 += 4) {
                 const double *src = (lrow && a0 == 0) ? lrow : row + 32 * a0;   // columns < 128 of
-                double2 x[4][4];                                               // rows < 128: LDS
+                const bool inreg = L11 && a0 == 0 && j >= 128;                 // rows < 128: LDS,
+                double2 x[4][4];                                               // rows >= 128: regs
+                if (inreg) {
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                    for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        x[a][b] = a0 + a < GA
-                                ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
-                                : make_double2(0., 0.);
+                        for (int b = 0; b < 4; b++) x[a][b] = r21[a][b];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            x[a][b] = a0 + a < GA
+                                    ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
+                                    : make_double2(0., 0.);
+                }
 #pragma unroll
                 for (int a = 0; a < 4; a++)
                     if (a0 + a < GA) {
@@ -437,14 +469,22 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
             const double uj = uv[j], wj = wv[j];
             for (int a0 = 0; a0 < GA; a0 += 4) {
                 double *src = (lrow && a0 == 0) ? lrow : row + 32 * a0;
+                const bool inreg = L11 && a0 == 0 && j >= 128;
                 double2 x[4][4];
+                if (inreg) {
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                    for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        x[a][b] = a0 + a < GA
-                                ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
-                                : make_double2(0., 0.);
+                        for (int b = 0; b < 4; b++) x[a][b] = r21[a][b];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            x[a][b] = a0 + a < GA
+                                    ? *reinterpret_cast<const double2*>(src + 32 * a + 2 * b)
+                                    : make_double2(0., 0.);
+                }
 #pragma unroll
                 for (int a = 0; a < 4; a++)
                     if (a0 + a < GA) {
@@ -456,7 +496,8 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
                             double2 v;
                             v.x = __builtin_fma(-u2.x, wj, __builtin_fma(-w2.x, uj, x[a][b].x));
                             v.y = __builtin_fma(-u2.y, wj, __builtin_fma(-w2.y, uj, x[a][b].y));
-                            *reinterpret_cast<double2*>(src + 32 * a + 2 * b) = v;
+                            if (inreg) r21[a][b] = v;
+                            else *reinterpret_cast<double2*>(src + 32 * a + 2 * b) = v;
                             if (j == i - 1) *reinterpret_cast<double2*>(&dv[kk]) = v;
                         }
                     }
