@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 
 WORKLOADS = {
     "M": dict(algo="ActiveCMAES", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
+    "C1": dict(algo="ActiveCMAES", n=10, np=20, objective="rosenbrock", box=(-10., 10.), P=4096),
     "C3": dict(algo="ActiveCMAES", n=128, np=1024, objective="rosenbrock", box=(-10., 10.), P=256),
     "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=256),
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
