@@ -368,7 +368,9 @@ void CmaEngine::launch_rank()
     timer_.begin(stream_, K_RANK);
     // few populations: the counting kernel spreads one ranking over many CUs; many
     // populations: one in-LDS sort per population is far less work in total
-    if (c.lambda <= SORT_LDS_MAX && c.npop >= 4) {
+    if (c.lambda <= 64 && c.lambda >= 2 && c.npop >= 4) {
+        hipLaunchKernelGGL(cma_rank_wave, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_);
+    } else if (c.lambda <= SORT_LDS_MAX && c.npop >= 4) {
         int m = 2;
         while (m < c.lambda) m <<= 1;
         allow_lds((const void*) cma_rank_sort, SORT_LDS_MAX * 12);
@@ -459,8 +461,12 @@ void CmaEngine::launch_eigen()
     const EigPlan pl = eig_plan(c.n, c.ld);
     allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
-    hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
-            c_, pl, 0);
+    // n <= 16: a wavefront per matrix (dbg bit 4 keeps the big kernel)
+    if (c.n <= 16 && c.n >= 2 && !(d_.dbg & 16))
+        hipLaunchKernelGGL(cma_eigen_small, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_, 0);
+    else
+        hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
+                c_, pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (pl.dc && !pl.reg_path) {

@@ -430,6 +430,41 @@ __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int 
     }
 }
 
+// the same ranking for lambda <= 64: one WAVEFRONT per population, the bitonic network entirely
+// in registers and lane exchanges (no LDS, no barrier); four populations per workgroup.
+// grid (ceil(P / 4)), 256 threads
+__global__ __launch_bounds__(256) void cma_rank_wave(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= c.npop) return;
+    CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    const double *f = d.f + (size_t) p * c.lambda_pad;
+    double kf[1] = { lane < c.lambda ? f[lane] : __builtin_huge_val() };
+    int ki[1] = { lane < c.lambda ? lane : 0x7fffffff };
+    for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            switch (j) {
+            case 1: sort_wave_stage<1, 1>(kf, ki, lane, j, k); break;
+            case 2: sort_wave_stage<1, 2>(kf, ki, lane, j, k); break;
+            case 4: sort_wave_stage<1, 4>(kf, ki, lane, j, k); break;
+            case 8: sort_wave_stage<1, 8>(kf, ki, lane, j, k); break;
+            case 16: sort_wave_stage<1, 16>(kf, ki, lane, j, k); break;
+            default: sort_wave_stage<1, 32>(kf, ki, lane, j, k); break;
+            }
+        }
+    const int L = c.lambda;
+    if (lane < L) {
+        d.order[(size_t) p * c.lambda_pad + lane] = ki[0];
+        d.rank[(size_t) p * c.lambda_pad + ki[0]] = lane;
+        if (lane == 0) { sc->ibw[0] = ki[0]; sc->ybw[0] = kf[0]; }
+        if (lane == 1) { sc->ibw[1] = ki[0]; sc->ybw[1] = kf[0]; }
+        if (lane == L - 2) { sc->ibw[2] = ki[0]; sc->ybw[2] = kf[0]; }
+        if (lane == L - 1) { sc->ibw[3] = ki[0]; sc->ybw[3] = kf[0]; }
+    }
+    if (lane == 0) sc->fev += L;   // base_cmaes.cpp:218
+}
+
 // ---------------------------------------------------------------------------
 // whiten: S[r] = || C^-1/2 (x_{(lambda-mu+r):lambda} - xold) ||^2 for the worst mu
 // grid (mu_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles + 64

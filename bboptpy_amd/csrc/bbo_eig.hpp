@@ -908,4 +908,161 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
     }
 }
 
+// ---------------------------------------------------------------------------
+// n <= 16: the whole decomposition by ONE WAVEFRONT, four matrices per workgroup.  cma_eigen
+// spends a 512-thread workgroup -- the whole register file of a CU -- on a matrix whatever its
+// size; with thousands of small populations in flight (C1: n = 10) that is what a generation
+// waits for.  Same arithmetic as the big path (unscaled reflectors, the reference's QL with its
+// sign conventions as the only "leaf", reflectors applied to the tridiagonal eigenvectors,
+// ascending order, repair, square roots), lanes (row j = lane & 15, part q = lane >> 4) sharing
+// the O(n^2) loops, wavefront-level fences only.
+// grid (ceil(P / 4)), 256 threads
+// ---------------------------------------------------------------------------
+constexpr int EIGS_LD = 17;
+constexpr int EIGS_DOUBLES = 2 * 16 * EIGS_LD + 8 * 20 + 272 + 8;
+
+__global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int force)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[4][EIGS_DOUBLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= c.npop) return;
+    CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
+        if (lane == 0) sc->eigen_done = 0;
+        return;
+    }
+    const int n = c.n, ld = c.ld;
+    double *A = lds_all[wave];                  // work matrix; row i ends as the reflector u_i
+    double *Qs = A + 16 * EIGS_LD;              // eigenvectors of T, then B
+    double *dv = Qs + 16 * EIGS_LD + 2;         // (front pads: the QL producer prefetches index -1)
+    double *ev = dv + 20, *uv = ev + 20, *wv = uv + 20, *hv = wv + 20, *td = hv + 20, *gv = td + 20;
+    int *perm = reinterpret_cast<int*>(gv + 20);
+    double *ws = gv + 40;
+    double *C = d.C + (size_t) p * ld * ld;
+    const int j = lane & 15, q = lane >> 4;
+    // symmetrise from the lower triangle (cmaes.cpp:238-242)
+    for (int x = lane; x < 16 * 16; x += 64) {
+        const int r = x >> 4, k = x & 15;
+        A[r * EIGS_LD + k] = (r < n && k < n) ? (k <= r ? C[(size_t) r * ld + k] : C[(size_t) k * ld + r])
+                                               : 0.;
+    }
+    if (lane < 20) {
+        dv[lane - 2] = 0.; ev[lane - 2] = 0.; uv[lane - 2] = 0.; wv[lane - 2] = 0.; hv[lane - 2] = 0.;
+    }
+    dc_wave_sync();
+    // ---- Householder tridiagonalisation (cmaes.cpp:285-381; reflectors left unscaled) --------
+    for (int i = n - 1; i > 0; i--) {
+        const double dk = lane < i ? A[i * EIGS_LD + lane] : 0.;
+        const double h0 = eig_wave_sum(dk * dk);
+        const double f = A[i * EIGS_LD + i - 1];
+        if (h0 == 0.) {
+            if (lane == 0) {
+                ev[i] = f;
+                hv[i] = 0.;
+            }
+            dc_wave_sync();
+            continue;
+        }
+        double g = sqrt(h0);
+        if (f > 0) g = -g;
+        const double h = h0 - f * g;
+        if (lane < 16) uv[lane] = lane < i ? (lane == i - 1 ? f - g : dk) : 0.;
+        if (lane == 0) ev[i] = g;
+        dc_wave_sync();
+        // p = A u / h over the block [0, i)^2, w = p - (u^T p / 2h) u
+        double acc = 0.;
+        if (j < i)
+            for (int k = q; k < i; k += 4) acc = fma(A[j * EIGS_LD + k], uv[k], acc);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        const double pj = acc / h;
+        const double hh = eig_wave_sum((lane < 16 && lane < i) ? pj * uv[lane] : 0.) / (h + h);
+        if (lane < 16) wv[lane] = lane < i ? pj - hh * uv[lane] : 0.;
+        dc_wave_sync();
+        if (j < i) {
+            const double uj = uv[j], wj = wv[j];
+            for (int k = q; k < i; k += 4)
+                A[j * EIGS_LD + k] -= uj * wv[k] + wj * uv[k];
+        }
+        dc_wave_sync();
+        if (lane < i) A[i * EIGS_LD + lane] = uv[lane];        // stash: row i = u_i
+        if (lane == 0) hv[i] = h;
+        dc_wave_sync();
+    }
+    if (lane < 16) td[lane] = lane < n ? A[lane * EIGS_LD + lane] : 0.;
+    dc_wave_sync();
+    // tql2's prologue: the sub-diagonal shifted down (cmaes.cpp:384-387)
+    {
+        const double t = (lane + 1 < n && lane < 16) ? ev[lane + 1] : 0.;
+        dc_wave_sync();
+        if (lane < 16) ev[lane] = t;
+    }
+    dc_wave_sync();
+    // ---- the reference's implicit QL on (td, ev) ----------------------------------------------
+    DcMat Qm { Qs, EIGS_LD };
+    dc_leaf_ql(Qm, 0, n, td, ev, dv, ws, lane, nullptr);
+    // ---- B = H(n-1) ... H(1) Q_T: column j, rows k = q (mod 4) -----------------------------------
+    for (int i = 1; i < n; i++) {
+        const double h = hv[i];
+        if (h != 0.) {
+            double acc = 0.;
+            if (j < n)
+                for (int k = q; k < i; k += 4) acc = fma(A[i * EIGS_LD + k], Qs[k * EIGS_LD + j], acc);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            const double gq = -(acc / h);
+            dc_wave_sync();
+            if (j < n)
+                for (int k = q; k < i; k += 4)
+                    Qs[k * EIGS_LD + j] = fma(gq, A[i * EIGS_LD + k], Qs[k * EIGS_LD + j]);
+            dc_wave_sync();
+        }
+    }
+    // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ----------------
+    if (lane < n) {
+        const double dj = dv[lane];
+        int r = 0;
+        for (int k = 0; k < n; k++) {
+            const double dk = dv[k];
+            r += (dk < dj) || (dk == dj && k < lane);
+        }
+        perm[lane] = r;
+        gv[r] = dj;
+    }
+    dc_wave_sync();
+    const double lo = gv[0], hi = gv[n - 1];
+    dc_wave_sync();
+    if (lo <= 0.) {
+        const double shift = fmax(hi, 0.) / 1e14;
+        if (lane < n) {
+            gv[lane] = fmax(gv[lane], 0.) + shift;
+            C[(size_t) lane * ld + lane] += shift;
+        }
+        dc_wave_sync();
+    }
+    const double lo2 = gv[0], hi2 = gv[n - 1];
+    dc_wave_sync();
+    if (hi2 > 1e14 * lo2) {
+        const double shift = hi2 / 1e14 - lo2;
+        if (lane < n) {
+            gv[lane] += shift;
+            C[(size_t) lane * ld + lane] += shift;
+        }
+        dc_wave_sync();
+    }
+    double *Dp = d.D + (size_t) p * ld;
+    double *Bp = d.B + (size_t) p * ld * ld;
+    for (int i = lane; i < ld; i += 64) Dp[i] = i < n ? sqrt(gv[i]) : 1.;
+    for (int x = lane; x < n * n; x += 64) {
+        const int k = x / n, jj = x - k * n;
+        Bp[(size_t) k * ld + perm[jj]] = Qs[k * EIGS_LD + jj];
+    }
+    if (lane == 0) {
+        sc->eigenlastev = sc->fev;
+        sc->eigen_done = 1;
+    }
+}
+
 } // namespace bbo
