@@ -280,3 +280,38 @@ def test_eigendecomposition_special_matrices(hip, n):
         isc = g.get_state("invsqrtC").reshape(n, n)
         cond = lam.max() / max(lam.min(), lam.max() / 1e14)
         assert np.linalg.norm(isc @ Cm @ isc - np.eye(n)) <= 1e-13 * cond * n + 1e-10 * n, name
+
+
+def test_c1_statistical_band_matches_reference(hip, oracle_lib):
+    """the C1 configuration (README example: ActiveCMAES(mfev=10000,
+    tol=1e-4, np=20) on 10-D Rosenbrock) over 32 starts.  Stream-level parity with the
+    reference's mt19937 is impossible, so outcomes are compared as distributions: the device
+    (32 populations of one handle, Philox) against the oracle in its reference mode (mt19937,
+    pinned bit for bit to the compiled reference) from the SAME 32 starting points --
+    success rate within binomial noise, median evaluations-to-tol of the successful runs inside
+    the reference's inter-quartile band x 1.25."""
+    n, P = 10, 32
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = np.random.default_rng(2024).uniform(-10, 10, (P, n))
+    g = hip.ActiveCMAES(mfev=10000, tol=1e-4, np=20, seed=99, populations=P)
+    g.initialize(hip.objectives.rosenbrock, lo, up, guess)
+    g.run(10000)
+    dev_ok, dev_evals = 0, []
+    for p in range(P):
+        sol = g.solution(p)
+        assert sol.n_evals <= 10000 and sol.n_evals % 20 == 0
+        if sol.converged and np.abs(sol.x - 1.).max() < 1e-2:
+            dev_ok += 1
+            dev_evals.append(sol.n_evals)
+    ref_ok, ref_evals = 0, []
+    for p in range(P):
+        oracle_lib.seed(1000 + p)
+        o = po.cma(oracle_lib, "active", 10000, 1e-4, 20)
+        x, fev, conv = o.optimize("rosenbrock", lo, up, guess[p])
+        if conv and np.abs(x - 1.).max() < 1e-2:
+            ref_ok += 1
+            ref_evals.append(fev)
+    assert ref_ok >= 8 and dev_ok >= 8                 # Rosenbrock's second minimum takes its share
+    assert abs(dev_ok - ref_ok) <= 9                   # ~3 sigma of two binomial(32, 0.7) draws
+    q1, q3 = np.percentile(ref_evals, [25, 75])
+    assert q1 / 1.25 <= np.median(dev_evals) <= q3 * 1.25, (np.median(dev_evals), q1, q3)
