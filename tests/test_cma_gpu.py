@@ -315,3 +315,21 @@ def test_c1_statistical_band_matches_reference(hip, oracle_lib):
     assert abs(dev_ok - ref_ok) <= 9                   # ~3 sigma of two binomial(32, 0.7) draws
     q1, q3 = np.percentile(ref_evals, [25, 75])
     assert q1 / 1.25 <= np.median(dev_evals) <= q3 * 1.25, (np.median(dev_evals), q1, q3)
+
+
+@pytest.mark.parametrize("n,lam", [(1, 4), (2, 4), (3, 6), (5, 8)])
+@pytest.mark.parametrize("variant", ["active", "cmaes"])
+def test_tiny_dimensions_whole_run_matches_oracle(hip, oracle_lib, n, lam, variant):
+    """the smallest problems (n = 1 runs through the general eigensolver, n >= 2 through the
+    wavefront-per-matrix one): whole runs with the same Philox normals stop at the same
+    evaluation with the same x* as the oracle's"""
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(n).uniform(-3, 3, n)
+    cls = hip.ActiveCMAES if variant == "active" else hip.CMAES
+    g = cls(mfev=4000, tol=1e-8, np=lam, seed=5)
+    sol = g.optimize(hip.objectives.sphere, lo, up, guess)
+    o = po.cma(oracle_lib, variant, 4000, 1e-8, lam)
+    o.set_rng(po.RNG_PHILOX, 5)
+    xo, fevo, convo = o.optimize("sphere", lo, up, guess)
+    assert sol.n_evals == fevo and sol.converged == convo
+    np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-11)
