@@ -25,6 +25,7 @@ def _close(a, b, rtol, what):
     (7, 31, "sphere", dict(pcompete=4, ring=True)),                 # np rounded up to 32, ring
     (12, 202, "ackley", dict(pcompete=2, ring=True, correct=False, vmax=0.1)),   # np > 100: phi > 0
     (16, 9000, "sphere", dict(pcompete=3)),                         # a large swarm
+    (301, 30, "ellipsoid", dict(pcompete=3)),                       # > 128 columns: chunked row loop
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, n, npp, obj, kw):
     seed = 321

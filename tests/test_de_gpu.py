@@ -64,6 +64,8 @@ def _compare(g, o, algo, tag):
      "ackley"),
     ("jade", 8, dict(mfev=100000, np=16, tol=1e-12), "rastrigin"),
     ("jade", 21, dict(mfev=100000, np=40, tol=1e-12, pelite=0.2, archive=False), "griewank"),
+    ("shade", 150, dict(mfev=100000, npinit=24, tol=1e-12), "ellipsoid"),   # > 128 columns: the
+    ("jade", 301, dict(mfev=100000, np=20, tol=1e-12), "sphere"),           # loop's second pass
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, algo, n, kw, obj):
     g, o = _pair(hip, oracle_lib, algo, n, kw.get("npinit", kw.get("np")), obj, 99, **kw)

@@ -22,6 +22,7 @@ def _close(a, b, rtol, what):
     (33, 50, "rosenbrock", dict(repaircr=False, crref=3, pupdate=7, crupdate=5)),   # odd n, ragged np
     (12, 20, "ackley", dict(crref=1, pupdate=4, crupdate=2)),
     (64, 256, "sphere", dict(pupdate=10, crupdate=5)),
+    (201, 24, "ellipsoid", dict(pupdate=6, crupdate=3)),       # > 128 columns: second pass of the loop
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, n, npp, obj, kw):
     seed = 123
