@@ -3,8 +3,9 @@
 The reference ships no objective functions; `rosenbrock` is its README objective
 (/root/reference/README.md:111-112).  Pass one of these objects (or its name) as `f` to
 optimize()/initialize() to keep the whole generation on the GPU.  Calling one with a NumPy
-vector evaluates the same formula on the host -- a convenience for inspecting results, never
-used by the optimizers themselves.
+vector evaluates the same formula on the host -- a convenience for inspecting results; the only
+optimizer code that uses it is CCPSO's optional local search (multivariate.py), whose objective
+(the built-in composed with per-swarm weights) is a host callable by construction.
 """
 import numpy as _np
 
