@@ -460,13 +460,21 @@ void CmaEngine::launch_eigen()
     if (c.variant == 2) return;        // diagonal covariance: d = sqrt(c) is part of sep_paths
     const EigPlan pl = eig_plan(c.n, c.ld);
     allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
+    allow_lds((const void*) cma_eigen_256, 160 * 1024 - 768);
+    allow_lds((const void*) cma_eigen_128, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
     // n <= 16: a wavefront per matrix (dbg bit 4 keeps the big kernel)
     if (c.n <= 16 && c.n >= 2 && !(d_.dbg & 16))
         hipLaunchKernelGGL(cma_eigen_small, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_, 0);
+    else if (pl.threads == 128)   // four lanes per row: smaller matrices, smaller workgroups,
+        hipLaunchKernelGGL(cma_eigen_128, dim3(c.npop), dim3(128), pl.lds_bytes, stream_, d_, c_,
+                pl, 0);             // several of them per CU
+    else if (pl.threads == 256)
+        hipLaunchKernelGGL(cma_eigen_256, dim3(c.npop), dim3(256), pl.lds_bytes, stream_, d_, c_,
+                pl, 0);
     else
-        hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(EIG_THREADS), pl.lds_bytes, stream_, d_,
-                c_, pl, 0);
+        hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
+                pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (pl.dc && !pl.reg_path) {

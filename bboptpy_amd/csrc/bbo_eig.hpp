@@ -30,6 +30,7 @@ constexpr int EIG_THREADS = 512;
 constexpr int EIG_NMAX = 512;
 
 struct EigPlan {
+    int threads;      // workgroup size = 4 lanes per row: 128 (n <= 32), 256 (n <= 64), else 512
     int use_lds;      // matrix in LDS?
     int reg_path;     // n <= 128: tred2 + accumulation run out of registers
     int dc;           // tridiagonal stage by divide and conquer (bbo_eig_dc.hpp) instead of QL
@@ -49,6 +50,7 @@ __host__ __device__ inline size_t eig_slab(int ld) { return (size_t) (ld + 32) *
 inline EigPlan eig_plan(int n, int ld)
 {
     EigPlan pl {};
+    pl.threads = n <= 32 ? 128 : n <= 64 ? 256 : EIG_THREADS;
     pl.vl = (((n > 128 ? n : 128) + 31) & ~31) + 2;
     pl.reg_path = n <= 128 ? 1 : 0;
     pl.dc = n <= 256 ? 1 : 0;          // 128 < n <= 256: matrix in global memory, top merge external
@@ -63,7 +65,11 @@ inline EigPlan eig_plan(int n, int ld)
         pl.use_lds = 1;
         pl.lda = lda_lds;
         size_t rc = (budget - fixed - mat) / (2 * 16);
-        if (rc > 4096) rc = 4096;
+        // (with the D&C stage the chunk buffers are only its work area -- the merge arrays, the
+        // leaves' patches or one staged reflector panel, <= 2200 doubles counting from uv -- so a
+        // few hundred pairs are ample, and several workgroups of a small matrix then fit one CU)
+        const size_t cap = !pl.dc ? 4096 : n <= 64 ? 400 : 800;
+        if (rc > cap) rc = cap;
         pl.rc = (int) rc;
         pl.lds_bytes = fixed + mat + (size_t) 2 * pl.rc * 16;
     } else {
@@ -165,11 +171,13 @@ __device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row,
 // (C, ld): the n x n matrix to reduce (the covariance, or -- for 128 < n' <= 256 -- the leading
 // 128 x 128 block the global-memory steps have left); As: LDS matrix for the reflector stash;
 // the accumulated Q goes to (qdst, ldq), which may be As itself.
+template<int TT = EIG_THREADS>
 __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, const EigMat &As,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
         int tid, long long *stamps, double *qdst, int ldq, bool finish, bool accumulate = true)
 {
-    const int T = EIG_THREADS, lane = tid & 63;
+    // (TT = 256 / 128: rows 0..63 / 0..31 only -- n <= 64 / 32)
+    const int T = TT, lane = tid & 63;
     const int j = tid >> 2, q = tid & 3;
     double a_[4][8];
 #pragma unroll
@@ -600,7 +608,8 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
     __syncthreads();
 }
 
-__global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, EigPlan pl,
+template<int TT>
+__device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
         int force)
 {
     const int p = blockIdx.x;
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         return;
     }
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, T = EIG_THREADS, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, T = TT, lane = tid & 63, wave = tid >> 6;
     const int n = c.n, ld = c.ld, nv = pl.vl;
     double *dv = lds + 2;         // diagonal / eigenvalues        (each vector: 2-element front pad)
     double *ev = dv + nv;         // sub-diagonal
@@ -642,10 +651,10 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     if (pl.reg_path) {
         // (with the D&C stage the reflectors stay stashed in A: eig_dc_phase applies them to the
         // tridiagonal eigenvectors in blocked form on the matrix cores)
-        eig_tred_accum_reg128(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
+        eig_tred_accum_reg128<TT>(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
                 (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true,
                 !(pl.dc && !(d.dbg & 2)));
-    } else {
+    } else if (TT == EIG_THREADS) {
         const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
         // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
         double *scr = uv;
         DcMat Qm { A.a, A.ld };
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
-        eig_dc_phase(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
+        eig_dc_phase<TT>(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
                 d.dbg, pl.reg_path ? 0 : 1, hvec);
     } else
@@ -759,6 +768,21 @@ __global__ __launch_bounds__(EIG_THREADS) void cma_eigen(CmaDev d, CmaConst c, E
     }
     EIG_STAMP(5);
 #undef EIG_STAMP
+}
+
+// The kernels proper: four lanes per matrix row, so the workgroup shrinks with n and several small
+// matrices share a CU (the 512-thread form owns a CU's whole register file).
+__global__ __launch_bounds__(512) void cma_eigen(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_body<512>(d, c, pl, force);
+}
+__global__ __launch_bounds__(256, 2) void cma_eigen_256(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_body<256>(d, c, pl, force);       // n <= 64
+}
+__global__ __launch_bounds__(128, 2) void cma_eigen_128(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_body<128>(d, c, pl, force);       // n <= 32
 }
 
 // ---------------------------------------------------------------------------

@@ -620,7 +620,7 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
 // 16b .. 16b+15, one wavefront per panel, written to Tg[b][16][16].  V: global n x n (row i =
 // u_i, zero from column i on), tau[i] = 1 / h_i or 0.  scratch (LDS): 16 x 17 doubles per
 // wavefront.  All threads of the workgroup call it.
-__device__ inline void dc_build_T(int n, const double *V, const double *tau, double *Tg,
+__device__ __forceinline__ void dc_build_T(int n, const double *V, const double *tau, double *Tg,
         double *scratch)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
@@ -685,6 +685,7 @@ __device__ inline void dc_build_T(int n, const double *V, const double *tau, dou
 // k index of a contraction over rows: k(ks, fk) = 8 (ks >> 1) + 2 fk + (ks & 1), so a lane's two
 // k-steps read one 16-byte piece of a reflector.
 // scratch (LDS): 16 * 132 doubles; Tg (global): 16 * 256 doubles.
+template<int TT>
 __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
         double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
 {
@@ -701,14 +702,21 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
     // ---- 2. panels ---------------------------------------------------------------------------------
     double *Vp = scratch;
     const int ctile = wave, col = 16 * ctile + fr;
-    const int pj = tid >> 5, pc = (tid & 31) * 4;     // this thread's piece of a staged panel
-    double pre[4], tpre[4];
+    // this thread's pieces of a staged panel (16 reflectors x 32 pieces of 4 columns: one piece
+    // per thread of a 512-thread workgroup, two / four of a 256- / 128-thread one)
+    constexpr int NPIECE = 512 / TT;
+    double pre[NPIECE][4], tpre[4];
     auto prefetch = [&](int b) {
         const int i0 = 16 * b, reach = min(n, i0 + 16);
-        const int rf = i0 + pj;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            pre[u] = (rf < n && pc + u < reach) ? V[(size_t) rf * n + pc + u] : 0.;
+        for (int h = 0; h < NPIECE; h++) {
+            const int e = tid + h * TT;
+            const int pj = e >> 5, pc = (e & 31) * 4;
+            const int rf = i0 + pj;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                pre[h][u] = (rf < n && pc + u < reach) ? V[(size_t) rf * n + pc + u] : 0.;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int kk = 4 * ks + fk;
@@ -720,7 +728,12 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
         const int reach = min(n, 16 * b + 16);
         __syncthreads();                         // the previous panel has been read by everyone
 #pragma unroll
-        for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = pre[u];
+        for (int h = 0; h < NPIECE; h++) {
+            const int e = tid + h * TT;
+            const int pj = e >> 5, pc = (e & 31) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = pre[h][u];
+        }
         double tv[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) tv[ks] = tpre[ks];
@@ -784,6 +797,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 // ext_top != 0 (n > 128, Q in global memory): stop after the scalar part of the top merge; on
 // exit Q = blockdiag(Q_1, Q_2), F (= G + n*n, n x n) = the top merge's eigenvector factor with
 // columns in ascending eigenvalue order, and the caller forms B = Q_house (Q F).
+template<int TT = 512>
 __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
         const double *hv = nullptr)
@@ -964,7 +978,7 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
         return;
     }
     if (hv) {
-        dc_apply_reflectors(Q, n, Qh, taug, taug + n, scratch, Bout, ldb,
+        dc_apply_reflectors<TT>(Q, n, Qh, taug, taug + n, scratch, Bout, ldb,
                 single ? W.outpos : nullptr);
         DC_STAMP(23);
         return;
