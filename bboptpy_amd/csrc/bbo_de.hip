@@ -152,7 +152,10 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
 void DeEngine::launch_rank(int which_next, int np_bound)
 {
     const DeConst &c = c_;
-    if (np_bound <= SORT_LDS_MAX && c.npop >= 4) {
+    if (np_bound <= 64 && np_bound >= 2 && c.npop >= 4) {
+        hipLaunchKernelGGL(de_rank_wave, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_,
+                which_next);
+    } else if (np_bound <= SORT_LDS_MAX && c.npop >= 4) {
         int m = 2;
         while (m < np_bound) m <<= 1;
         allow_lds((const void*) de_rank_sort, SORT_LDS_MAX * 12);
@@ -212,9 +215,9 @@ void DeEngine::generation(bool honor_stop)
     }
     timer_.begin(stream_, K_BOOK);
     if (c.variant == 2)
-        hipLaunchKernelGGL(sansde_bookkeep, dim3(P), dim3(1024), 0, stream_, d_, c_);
+        hipLaunchKernelGGL(sansde_bookkeep, dim3(P), dim3(pop_threads()), 0, stream_, d_, c_);
     else
-        hipLaunchKernelGGL(de_bookkeep, dim3(P), dim3(1024), 0, stream_, d_, c_);
+        hipLaunchKernelGGL(de_bookkeep, dim3(P), dim3(pop_threads()), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (c.archive) {
@@ -227,7 +230,7 @@ void DeEngine::generation(bool honor_stop)
     launch_rank(1, np_host_);
     timer_.end(stream_);
     timer_.begin(stream_, K_FINISH);
-    hipLaunchKernelGGL(de_finish, dim3(P), dim3(1024), 0, stream_, d_, c_);
+    hipLaunchKernelGGL(de_finish, dim3(P), dim3(pop_threads()), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     // the same population-size schedule on the host (shade.cpp:218-225), for the grid only

@@ -78,6 +78,10 @@ public:
 private:
     void generation(bool honor_stop);
     void launch_rank(int which_next, int np_bound);
+    // threads of the one-workgroup-per-population kernels (bookkeeping, finish): one per
+    // individual up to 1024 -- sums come out bit-identical whatever the choice as long as every
+    // thread holds at most one individual, and small populations do not pay for 16 wavefronts
+    int pop_threads() const { return c_.npinit <= 64 ? 64 : c_.npinit <= 256 ? 256 : 1024; }
     void host_evaluate(int which, int rows);
     bool all_stopped();
 

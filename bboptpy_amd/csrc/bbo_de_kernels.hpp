@@ -113,6 +113,36 @@ __global__ __launch_bounds__(1024) void de_rank_sort(DeDev d, DeConst c, int whi
             d.rank + (size_t) p * c.npinit);
 }
 
+// np <= 64: one wavefront per population, the bitonic network in registers and lane exchanges
+// (no LDS, no barrier), four populations per workgroup.  grid (ceil(P / 4)), 256 threads
+__global__ __launch_bounds__(256) void de_rank_wave(DeDev d, DeConst c, int which_next)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= c.npop) return;
+    const DeScal *sc = d.scal + p;
+    if (de_frozen(c, sc)) return;
+    const int which = which_next ? (sc->cur ^ 1) : sc->cur;
+    const double *f = d.f[which] + (size_t) p * c.npinit;
+    const int np = sc->np;
+    double kf[1] = { lane < np ? f[lane] : __builtin_huge_val() };
+    int ki[1] = { lane < np ? lane : 0x7fffffff };
+    for (int k = 2; k <= 64; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            switch (j) {
+            case 1: sort_wave_stage<1, 1>(kf, ki, lane, j, k); break;
+            case 2: sort_wave_stage<1, 2>(kf, ki, lane, j, k); break;
+            case 4: sort_wave_stage<1, 4>(kf, ki, lane, j, k); break;
+            case 8: sort_wave_stage<1, 8>(kf, ki, lane, j, k); break;
+            case 16: sort_wave_stage<1, 16>(kf, ki, lane, j, k); break;
+            default: sort_wave_stage<1, 32>(kf, ki, lane, j, k); break;
+            }
+        }
+    if (lane < np) {
+        d.order[(size_t) p * c.npinit + lane] = ki[0];
+        d.rank[(size_t) p * c.npinit + ki[0]] = lane;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // the fused generation.  grid (ceil(np_launch/16), P), 256 threads; LDS 16 * ld doubles
 // ---------------------------------------------------------------------------
@@ -583,7 +613,8 @@ __device__ inline double block_sum_1024(double v, double *scratch)
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
     double s = 0.;
-    for (int w = 0; w < 16; w++) s += scratch[w];
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; w++) s += scratch[w];
     return s;
 }
 
@@ -596,6 +627,7 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
     __shared__ int carry;
     __shared__ double scratch[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = blockDim.x, NWV = (T + 63) >> 6;   // 64 / 256 / 1024 threads by np (launch)
     const int np = sc->np, gen = sc->gen, larch0 = sc->larch;
     const size_t pbase = (size_t) p * c.npinit;
     const int *flag = d.rec_flag + pbase;
@@ -603,10 +635,10 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
 
     // ---- archive slots ------------------------------------------------------------------
     if (c.archive) {
-        for (int s = tid; s < np; s += 1024) d.claim[pbase + s] = -1;
+        for (int s = tid; s < np; s += T) d.claim[pbase + s] = -1;
         if (tid == 0) carry = 0;
         __syncthreads();
-        for (int base = 0; base < np; base += 1024) {
+        for (int base = 0; base < np; base += T) {
             const int i = base + tid;
             const int rec = (i < np && (flag[i] & mask)) ? 1 : 0;
             // exclusive prefix of rec over the block
@@ -632,7 +664,7 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
             __syncthreads();
             if (tid == 0) {
                 int tot = 0;
-                for (int w = 0; w < 16; w++) tot += wave_tot[w];
+                for (int w = 0; w < NWV; w++) tot += wave_tot[w];
                 carry += tot;
             }
             __syncthreads();
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
         // weighted arithmetic mean of CR, weighted Lehmer mean of F (shade.cpp:188-205)
         double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
         int cntl = 0;
-        for (int i = tid; i < np; i += 1024)
+        for (int i = tid; i < np; i += T)
             if (flag[i] & 2) {
                 const double w = df[i];
                 a0 += w * cr[i];
@@ -671,7 +703,7 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
         // jade.cpp:180-205: mean / root-mean-square of the successful CR, Lehmer mean of F
         double s1 = 0., s2 = 0., f1 = 0., f2 = 0.;
         int cntl = 0;
-        for (int i = tid; i < np; i += 1024)
+        for (int i = tid; i < np; i += T)
             if (flag[i] & 1) {
                 s1 += cr[i];
                 s2 += cr[i] * cr[i];
@@ -687,7 +719,7 @@ __global__ __launch_bounds__(1024) void de_bookkeep(DeDev d, DeConst c)
         double dev = 0.;
         if (ns > 0.) {
             const double mean = s1 / ns;
-            for (int i = tid; i < np; i += 1024)
+            for (int i = tid; i < np; i += T)
                 if (flag[i] & 1) dev += (cr[i] - mean) * (cr[i] - mean);
         }
         dev = block_sum_1024(dev, scratch);
@@ -720,14 +752,14 @@ __global__ __launch_bounds__(1024) void sansde_bookkeep(DeDev d, DeConst c)
     DeScal *sc = d.scal + p;
     if (de_frozen(c, sc)) return;
     __shared__ double scratch[16];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     const int np = sc->np;
     const size_t pbase = (size_t) p * c.npinit;
     const int *flag = d.rec_flag + pbase, *strat = d.slot_of + pbase;
     const double *cr = d.rec_cr + pbase, *ff = d.rec_f + pbase, *df = d.rec_df + pbase;
     double ns[2] = { 0., 0. }, nf[2] = { 0., 0. }, fs[2] = { 0., 0. }, ffl[2] = { 0., 0. };
     double rec = 0., del = 0.;
-    for (int i = tid; i < np; i += 1024) {
+    for (int i = tid; i < np; i += T) {
         const int is = strat[i] & 1, fi = (strat[i] >> 1) & 1;
         if (flag[i] & 1) {
             ns[is] += 1.;
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(1024) void de_finish(DeDev d, DeConst c)
     if (de_frozen(c, sc)) return;
     __shared__ double scratch[16];
     __shared__ int sh_idx;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     const size_t pbase = (size_t) p * c.npinit;
     int np = sc->np;
     const int gen = sc->gen;
@@ -829,7 +861,7 @@ __global__ __launch_bounds__(1024) void de_finish(DeDev d, DeConst c)
                 __syncthreads();
                 const int ir = sh_idx;
                 if (ir != larch - 1)
-                    for (int j = tid; j < c.ld; j += 1024)
+                    for (int j = tid; j < c.ld; j += T)
                         d.arch[(pbase + ir) * c.ld + j] = d.arch[(pbase + larch - 1) * c.ld + j];
                 __syncthreads();
                 larch--;
@@ -841,10 +873,10 @@ __global__ __launch_bounds__(1024) void de_finish(DeDev d, DeConst c)
     const int *order = d.order + pbase;
     const double *rad = d.radius + pbase;
     double s = 0.;
-    for (int q = tid; q < np; q += 1024) s += rad[order[q]];
+    for (int q = tid; q < np; q += T) s += rad[order[q]];
     const double mean = block_sum_1024(s, scratch) / np;
     double m2 = 0.;
-    for (int q = tid; q < np; q += 1024) {
+    for (int q = tid; q < np; q += T) {
         const double dd = rad[order[q]] - mean;
         m2 += dd * dd;
     }
