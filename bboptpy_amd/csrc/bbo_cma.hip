@@ -374,7 +374,7 @@ void CmaEngine::launch_rank()
         int m = 2;
         while (m < c.lambda) m <<= 1;
         allow_lds((const void*) cma_rank_sort, SORT_LDS_MAX * 12);
-        hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(1024), (size_t) std::max(m, 1024) * 12,
+        hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(sort_threads(m)), (size_t) std::max(m, 1024) * 12,
                 stream_, d_,
                 c_, m);
     } else {

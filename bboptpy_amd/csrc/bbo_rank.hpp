@@ -114,11 +114,11 @@ __device__ inline void sort_wave_stage(double (&kf)[E], int (&ki)[E], int e0, in
 //                   stage with one barrier each, then reloaded).
 // For M = 4096 that is 14 barriers instead of 78.  Element e keeps the smaller of (itself, its
 // partner e ^ j) iff ((e & j) == 0) == ((e & k) == 0).
-template<int E>
+template<int E, int T = 1024>
 __device__ inline void bitonic_sort_regs(const double *f, int count, double *keys, int *idx,
         int *order, int *rank)
 {
-    constexpr int M = 1024 * E;
+    constexpr int M = T * E;            // T = threads of the workgroup (1024, or 256 for <= 256 keys)
     const int tid = threadIdx.x;
     const int e0 = tid * E;
     double kf[E];
@@ -141,7 +141,7 @@ __device__ inline void bitonic_sort_regs(const double *f, int count, double *key
             for (; j >= 64 * E; j >>= 1) {
 #pragma unroll
                 for (int v = 0; v < (E > 1 ? E / 2 : 1); v++) {
-                    const int q = tid + 1024 * v;
+                    const int q = tid + T * v;
                     if (q < (M >> 1)) {
                         const int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1));
                         const int hi = lo | j;
@@ -209,11 +209,15 @@ __device__ inline void bitonic_sort_regs(const double *f, int count, double *key
     __syncthreads();
 }
 
-// keys/idx: LDS arrays of max(m, 1024) entries (m = power of two >= count); 1024 threads
+// keys/idx: LDS arrays of max(m, 1024) entries (m = power of two >= count); 1024 threads, or
+// 256 threads when m <= 256 (the caller's launch decides: sort_threads(m))
+__host__ __device__ inline int sort_threads(int m) { return m <= 256 ? 256 : 1024; }
+
 __device__ inline void bitonic_sort_lds(const double *f, int count, int m, double *keys,
         int *idx, int *order, int *rank)
 {
-    if (m <= 1024) bitonic_sort_regs<1>(f, count, keys, idx, order, rank);
+    if (blockDim.x == 256) bitonic_sort_regs<1, 256>(f, count, keys, idx, order, rank);
+    else if (m <= 1024) bitonic_sort_regs<1>(f, count, keys, idx, order, rank);
     else if (m == 2048) bitonic_sort_regs<2>(f, count, keys, idx, order, rank);
     else if (m == 4096) bitonic_sort_regs<4>(f, count, keys, idx, order, rank);
     else bitonic_sort_regs<8>(f, count, keys, idx, order, rank);
