@@ -464,8 +464,10 @@ void CmaEngine::launch_eigen()
     allow_lds((const void*) cma_eigen_128, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
     // n <= 16: a wavefront per matrix (dbg bit 4 keeps the big kernel)
-    if (c.n <= 16 && c.n >= 2 && !(d_.dbg & 16))
-        hipLaunchKernelGGL(cma_eigen_small, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_, 0);
+    const bool small = c.n <= 16 && c.n >= 2 && c.ld == 16 && !(d_.dbg & 16);
+    if (small)    // (does cma_post's work too: one launch less where launches are what costs)
+        hipLaunchKernelGGL(cma_eigen_small, dim3((c.npop + 3) / 4), dim3(256), 0, stream_, d_, c_, 0,
+                1);
     else if (pl.threads == 128)   // four lanes per row: smaller matrices, smaller workgroups,
         hipLaunchKernelGGL(cma_eigen_128, dim3(c.npop), dim3(128), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);             // several of them per CU
@@ -491,7 +493,7 @@ void CmaEngine::launch_eigen()
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_POST);
-    launch_post(0);
+    if (!small) launch_post(0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }

@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
 constexpr int EIGS_LD = 17;
 constexpr int EIGS_DOUBLES = 2 * 16 * EIGS_LD + 8 * 20 + 272 + 8;
 
-__global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int force)
+__global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int force, int with_post)
 {
     __shared__ __attribute__((aligned(16))) double lds_all[4][EIGS_DOUBLES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1087,6 +1087,36 @@ __global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int
         sc->eigenlastev = sc->fev;
         sc->eigen_done = 1;
     }
+    if (!with_post) return;
+    // ---- what cma_post does after a decomposition, by the same wavefront: C^-1/2 = B D^-1 B^T
+    // term by term in the reference's order (cmaes.cpp:274-282), the packed MFMA operands of the
+    // sampler (B D) and of the whitening GEMM (C^-1/2); ld = 16 here.  B in sorted column order
+    // goes to the work matrix (the reflectors are spent), D to dv.
+    dc_wave_sync();
+    for (int x = lane; x < 16 * 16; x += 64) {
+        const int k = x >> 4, jj = x & 15;
+        if (k < n && jj < n) A[k * EIGS_LD + perm[jj]] = Qs[k * EIGS_LD + jj];
+    }
+    if (lane < 16) dv[lane] = lane < n ? sqrt(gv[lane]) : 1.;
+    dc_wave_sync();
+    double *isc = d.isc + (size_t) p * ld * ld;
+    double *ISp = d.ISp + (size_t) p * ld * ld, *BDp = d.BDp + (size_t) p * ld * ld;
+    const int KS = ld >> 2;
+    for (int x = lane; x < ld * ld; x += 64) {
+        const int i = x / ld, jc = x - i * ld;
+        double v = 0.;
+        if (i < n && jc < n)
+            for (int k = 0; k < n; k++) v += A[i * EIGS_LD + k] / dv[k] * A[jc * EIGS_LD + k];
+        isc[(size_t) i * ld + jc] = v;
+        ISp[((size_t) (i >> 4) * KS + (jc >> 2)) * 64 + ((jc & 3) << 4) + (i & 15)] = v;
+    }
+    for (int qq = lane; qq < ld * ld; qq += 64) {
+        const int t4 = qq >> 6, l = qq & 63;             // t4 = nt * KS + ks
+        const int nt = t4 / KS, ks = t4 - nt * KS;
+        const int i = nt * 16 + (l & 15), jc = 4 * ks + (l >> 4);
+        BDp[qq] = (i < n && jc < n) ? A[i * EIGS_LD + jc] * dv[jc] : 0.;
+    }
+    if (lane == 0) sc->basis_ok = 1;
 }
 
 } // namespace bbo
