@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
 // normals with them, so the packed operand is read once per 64 candidates instead of once
 // per 16.  grid (ceil(lambda_pad/64), P), 256 threads; dynamic LDS 64*(ld+2) doubles
 // ---------------------------------------------------------------------------
-template<int MAXT>
+template<int MAXT, int KSM = 32>     // KSM: k-steps held (ld <= 4 KSM); 8 keeps ld <= 32 lean in registers
 __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 {
     const int p = blockIdx.y, row0 = blockIdx.x * 64;
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 
     // (B D) fragments of this wavefront's column tiles
     const double *bdp = d.BDp + (size_t) p * ld * ld;
-    double bfr[MAXT][32];
+    double bfr[MAXT][KSM];
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         const int nt = wave + 4 * t;
 #pragma unroll
-        for (int ks = 0; ks < 32; ks++)
+        for (int ks = 0; ks < KSM; ks++)
             bfr[t][ks] = (nt < NT && ks < KS) ? bdp[((size_t) nt * KS + ks) * 64 + lane] : 0.;
     }
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 #pragma unroll
         for (int t = 0; t < MAXT; t++) acc[mt][t] = d4_t { 0., 0., 0., 0. };
 #pragma unroll
-        for (int ks = 0; ks < 32; ks++) {
+        for (int ks = 0; ks < KSM; ks++) {
             if (ks < KS) {
                 const double a = lds[(mt * 16 + ar) * ldz + 4 * ks + ak];
                 zz = __builtin_fma(a, a, zz);
