@@ -422,7 +422,14 @@ def main():
         elif wl["algo"] == "CCPSO":
             # the candidate count changes with the subset size drawn: no fixed per-launch work;
             # the evaluation kernel is bound by the objective's arithmetic, not by a roofline
-            names, costs = CCPSO_KERNELS, {k: ("hbm", None) for k in CCPSO_KERNELS}
+            # ccp_eval is bound by the objective (2 (n/s) np full-dimension evaluations per
+            # generation, no matrix instruction, hardly any HBM): the HBM figure -- X and Y read
+            # once, the two fitness tables written -- only shows how far from a stream it is
+            n_, np_ = wl["n"], wl["np"]
+            costs = {k: ("hbm", None) for k in CCPSO_KERNELS}
+            costs["ccp_eval"] = ("hbm", P * (2 * np_ * n_ * 8 + 2 * np_ * n_ * 8 // min(wl["pps"])))
+            costs["ccp_position"] = ("hbm", P * 3 * np_ * n_ * 8)
+            names = CCPSO_KERNELS
         else:
             names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
         kernels = {}
