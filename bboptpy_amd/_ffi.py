@@ -88,13 +88,17 @@ def lib():
     L.bbo_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _dp, C.c_int]
     L.bbo_cma_phase_run.argtypes = [C.c_void_p, C.c_int]
     L.bbo_cma_inject_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bbo_cma_set_params.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+    L.bbo_cma_set_seed.argtypes = [C.c_void_p, C.c_uint64]
+    L.bbo_cma_evaluate.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_double)]
     L.bbo_last_error.argtypes = [C.c_void_p]
     L.bbo_last_error.restype = C.c_char_p
     L.bbo_version.restype = C.c_char_p
     L.bbo_device_count.restype = C.c_int
     for name in ("bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init", "bbo_iterate",
                  "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
-                 "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals"):
+                 "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
+                 "bbo_cma_set_seed", "bbo_cma_evaluate"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -103,7 +107,8 @@ def lib():
 EXPORTED_SYMBOLS = (
     "bbo_params_default", "bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init",
     "bbo_iterate", "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
-    "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_last_error", "bbo_version",
+    "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
+    "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_last_error", "bbo_version",
     "bbo_device_count",
 )
 

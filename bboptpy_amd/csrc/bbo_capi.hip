@@ -280,6 +280,36 @@ int bbo_cma_inject_normals(bbo_handle h, const double *z, int count)
     });
 }
 
+int bbo_cma_set_params(bbo_handle h, int np, double sigma0, int mfev)
+{
+    return guarded(h, [&] {
+        auto *cma = dynamic_cast<bbo::CmaEngine*>(h->opt.get());
+        if (!cma) throw bbo::Error(BBO_ERR_ARG, "not a CMA-ES handle");
+        if (np < 4) throw bbo::Error(BBO_ERR_ARG, "CMA-ES needs np >= 4");
+        cma->set_params(np, sigma0, mfev);
+    });
+}
+
+int bbo_cma_set_seed(bbo_handle h, uint64_t seed)
+{
+    return guarded(h, [&] {
+        auto *cma = dynamic_cast<bbo::CmaEngine*>(h->opt.get());
+        if (!cma) throw bbo::Error(BBO_ERR_ARG, "not a CMA-ES handle");
+        cma->set_seed(seed);
+    });
+}
+
+int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out)
+{
+    return guarded(h, [&] {
+        auto *cma = dynamic_cast<bbo::CmaEngine*>(h->opt.get());
+        if (!cma) throw bbo::Error(BBO_ERR_ARG, "not a CMA-ES handle");
+        if (!x || !f_out) throw bbo::Error(BBO_ERR_ARG, "NULL argument");
+        if (cma->dimension() <= 0) throw bbo::Error(BBO_ERR_STATE, "evaluate before initialize()");
+        *f_out = cma->evaluate_point(x);
+    });
+}
+
 const char* bbo_last_error(bbo_handle h)
 {
     if (!h) return g_create_error.c_str();

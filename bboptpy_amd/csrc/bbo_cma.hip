@@ -33,6 +33,14 @@ int gram_ldy(int ld)
     return (ld % 32 == 0) ? ld + 16 : ld;
 }
 
+// dynamic LDS of cma_gram: the slab, its two coefficient columns, the mean's partial sums
+constexpr size_t GRAM_LDS_MAX = 160 * 1024 - 64;
+size_t gram_lds_bytes(int ld, int rps)
+{
+    const int rpp = 256 / (ld / 4) > 0 ? 256 / (ld / 4) : 1;
+    return ((size_t) rps * gram_ldy(ld) + 2 * (size_t) rps + (size_t) rpp * ld) * sizeof(double);
+}
+
 } // namespace
 
 CmaEngine::CmaEngine(const bbo_params &p) :
@@ -97,6 +105,8 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.seed = params_.seed;
     c.tol = params_.tol;
     c.sigma0 = params_.sigma0;
+    c.stop_off = 0;
+    c.ftarget = -std::numeric_limits<double>::infinity();
 
     // recombination weights, base_cmaes.cpp:92-105
     std::vector<double> w(c.mu);
@@ -151,8 +161,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         if (params_.adjustlr) c.ccov *= ((n + 2.) / 3.);
     }
 
-    // Gram split-K geometry
+    // Gram split-K geometry: cma_gram holds its slab (rps rows of ldy doubles) in LDS
     c.rps = 64;
+    while (c.rps > 16 && gram_lds_bytes(c.ld, c.rps) > GRAM_LDS_MAX) c.rps >>= 1;
     if (c.ld == 128) {
         // cma_gram128 streams its slab: size the slabs for ~1024 workgroups over all populations
         int want = std::max(1, std::min(32, (1024 + P - 1) / P));
@@ -351,6 +362,7 @@ void CmaEngine::launch_sample_eval()
     } else {
         dim3 grid(c.lambda_pad / 16, c.npop);
         const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
+        allow_lds((const void*) cma_sample_eval<8>, 80 * 1024);   // ld = 512: 65 792 bytes
         switch (pick_maxt(c.ld)) {
         case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;
@@ -413,6 +425,7 @@ void CmaEngine::launch_update()
         } else {
         dim3 grid(c.mu_pad / 16, c.npop);
         const size_t lds = (size_t) (16 * (c.ld + 2) + 64) * sizeof(double);
+        allow_lds((const void*) cma_whiten<8>, 80 * 1024);        // ld = 512: 66 304 bytes
         switch (pick_maxt(c.ld)) {
         case 1: hipLaunchKernelGGL(cma_whiten<1>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 2: hipLaunchKernelGGL(cma_whiten<2>, grid, dim3(256), lds, stream_, d_, c_); break;
@@ -434,9 +447,8 @@ void CmaEngine::launch_update()
         const int NT = c.ld / 16, LT = NT * (NT + 1) / 2;
         const int ldy = gram_ldy(c.ld);
         dim3 grid(c.splits, (LT + 4 * GRAM_TPW - 1) / (4 * GRAM_TPW), c.npop);
-        const int rpp = 256 / (c.ld / 4) > 0 ? 256 / (c.ld / 4) : 1;
-        const size_t lds = (size_t) (c.rps * ldy + 2 * c.rps + (size_t) rpp * c.ld) * sizeof(double);
-        allow_lds((const void*) cma_gram, 160 * 1024 - 64);
+        const size_t lds = gram_lds_bytes(c.ld, c.rps);
+        allow_lds((const void*) cma_gram, (int) GRAM_LDS_MAX);
         timer_.begin(stream_, K_GRAM);
         hipLaunchKernelGGL(cma_gram, grid, dim3(256), lds, stream_, d_, c_, ldy);
         timer_.end(stream_);
@@ -907,6 +919,11 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         return r;
     }
     if (k == "C") return mat(C_);
+    if (k == "best_hist" || k == "kth_hist") {   // cmaes_history rings (crafted stop states)
+        BBO_REQUIRE(count == c.hlen, "set: wrong element count");
+        (k == "best_hist" ? hist_best_ : hist_kth_).upload(in, c.hlen, (size_t) p * c.hlen);
+        return count;
+    }
     if (k == "invsqrtC") throw Error(BBO_ERR_KEY, "invsqrtC is derived from B and D: set those");
     if (k == "B" || k == "D") {
         int r;
@@ -932,6 +949,14 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     }
     if (k == "dbg") {
         d_.dbg = (int) in[0];
+        return 1;
+    }
+    if (k == "stop_off") {     // (extension) bit k silences the stop test with flag k
+        c_.stop_off = (int) in[0];
+        return 1;
+    }
+    if (k == "ftarget") {      // (extension) f_best <= ftarget stops with flag 10
+        c_.ftarget = in[0];
         return 1;
     }
     if (k == "eig_stamps") {
@@ -960,6 +985,8 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     else if (k == "fbest") s.fbest = in[0];
     else if (k == "fworst") s.fworst = in[0];
     else if (k == "stop") s.stop = (int) in[0];
+    else if (k == "best_len") s.hist_len = (int) in[0];
+    else if (k == "best_buffer") s.hist_head = (int) in[0];
     else throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
     scal_.upload(&s, 1, p);
     return 1;

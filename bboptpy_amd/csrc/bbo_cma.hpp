@@ -41,6 +41,10 @@ struct CmaConst {
     double mueff, cc, cs, c1, cmu, cneg, alphaold, cm, damps, chi, sigma0, tol, eigenfreq;
     double ccov;              // separable variant (sep_cmaes.cpp:53-62)
     uint64_t seed;
+    // extensions, off by default (bbo_set "stop_off" / "ftarget"): bit k of stop_off silences the
+    // reference's stop test with flag k; f_best <= ftarget raises the non-reference flag 10
+    int stop_off;
+    double ftarget;
 };
 
 struct CmaDev {
@@ -94,6 +98,7 @@ public:
     // evaluates one point with this engine's objective (restart drivers' extra call)
     double evaluate_point(const double *x);
     int lambda() const { return params_.np; }
+    int populations() const { return params_.populations; }
     uint64_t seed() const { return params_.seed; }
     void set_seed(uint64_t s) { params_.seed = s; }
 

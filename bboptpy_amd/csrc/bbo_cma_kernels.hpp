@@ -1308,13 +1308,16 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
     const double *C = d.C + (size_t) p * ld * ld, *B = d.B + (size_t) p * ld * ld;
     const double *D = d.D + (size_t) p * ld;
     int flag = 0;
+    const int off = c.stop_off;     // (extension: silenced tests; 0 = the reference's nine)
     if (it >= c.mit) {
         flag = 1;
-    } else if (it >= c.hlen && fworst - fbest < c.tol) {
+    } else if (f[order[0]] <= c.ftarget) {
+        flag = 10;                  // (extension: target value reached; ftarget = -inf by default)
+    } else if (!(off & 4) && it >= c.hlen && fworst - fbest < c.tol) {
         flag = 2;
     } else {
         // EqualFunVals
-        if (len >= n) {
+        if (!(off & 8) && len >= n) {
             int eq = 0;
             for (int i = lane; i < n; i += 64) {
                 const int idx = (c.hlen + head - i) % c.hlen;
@@ -1325,7 +1328,7 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
             if (3 * eq >= n) flag = 3;
         }
         const bool sep = c.variant == 2;   // SepCmaes: the same tests on _diagd (sep_cmaes.cpp:166-205)
-        if (!flag) {   // TolX
+        if (!flag && !(off & 16)) {   // TolX
             int bad = 0;
             for (int i = lane; i < n; i += 64) {
                 const double sd = sep ? D[i] : sqrt(C[(size_t) i * ld + i]);
@@ -1333,9 +1336,9 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
             }
             if (!__any(bad)) flag = 4;
         }
-        if (!flag && sigma / c.sigma0 > 1.0e20 * D[n - 1]) flag = 5;
-        if (!flag && D[n - 1] > 1.0e7 * D[0]) flag = 7;
-        if (!flag) {   // NoEffectAxis
+        if (!flag && !(off & 32) && sigma / c.sigma0 > 1.0e20 * D[n - 1]) flag = 5;
+        if (!flag && !(off & 128) && D[n - 1] > 1.0e7 * D[0]) flag = 7;
+        if (!flag && !(off & 256)) {   // NoEffectAxis
             const int iaxis = n - 1 - ((it - 1) % n);
             int moved = 0;
             if (sep) {
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
             }
             if (!__any(moved)) flag = 8;
         }
-        if (!flag) {   // NoEffectCoor
+        if (!flag && !(off & 512)) {   // NoEffectCoor
             int stuck = 0;
             for (int i = lane; i < n; i += 64) {
                 const double sd = sep ? D[i] : sqrt(C[(size_t) i * ld + i]);

@@ -38,6 +38,15 @@ struct Error: std::runtime_error {
         if (!(cond)) throw ::bbo::Error(BBO_ERR_ARG, msg);                         \
     } while (0)
 
+// Kernels that stage one row of ld doubles per 16-lane group (de_init, de_generation,
+// sansde_generation, pso_init, pso_update, cso_init, cso_compete): rows per workgroup so that
+// the stage stays within 64 KiB of LDS (16 rows up to ld = 512, 8 up to 1024, 4 up to 2048);
+// the kernels take their row count from blockDim.x >> 4.
+inline int rows_per_wg16(int ld)
+{
+    return ld <= 512 ? 16 : ld <= 1024 ? 8 : 4;
+}
+
 inline int round_up(int v, int m)
 {
     return (v + m - 1) / m * m;

@@ -120,8 +120,9 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     c.honor_stop = 0;
     inited_ = true;
 
-    hipLaunchKernelGGL(cso_init, dim3((c.np + 15) / 16, P), dim3(256),
-            (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
+    const int R = rows_per_wg16(c.ld);
+    hipLaunchKernelGGL(cso_init, dim3((c.np + R - 1) / R, P), dim3(16 * R),
+            (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(false);
     hipLaunchKernelGGL(cso_finish_part, dim3(c_.fparts, P), dim3(256), 0, stream_, d_, c_);
@@ -187,8 +188,9 @@ void CsoEngine::generation(bool honor_stop)
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_COMPETE);
-    hipLaunchKernelGGL(cso_compete, dim3((c.ngroup + 15) / 16, P), dim3(256),
-            (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
+    const int R = rows_per_wg16(c.ld);     // groups staged in LDS per workgroup
+    hipLaunchKernelGGL(cso_compete, dim3((c.ngroup + R - 1) / R, P), dim3(16 * R),
+            (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(true);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void cso_init(CsoDev d, CsoConst c)
     const int p = blockIdx.y;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r, ld = c.ld;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld;
     double *row = lds + r * ld;
     const size_t base = ((size_t) p * c.np + i) * ld;
     double ssq = 0.;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
     if (cso_frozen(c, sc)) return;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int gI = blockIdx.x * 16 + r, ld = c.ld, n = c.n, gen = sc->gen;
+    const int gI = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld, n = c.n, gen = sc->gen;
     const bool live = gI < c.ngroup;
     double *trial = lds + r * ld;
     const size_t pb = (size_t) p * c.np;

@@ -139,8 +139,9 @@ void DeEngine::init(int n, const double *lower, const double *upper, const doubl
     c.honor_stop = 0;
     inited_ = true;
 
-    dim3 grid((c.npinit + 15) / 16, P);
-    hipLaunchKernelGGL(de_init, grid, dim3(256), (size_t) 16 * c.ld * sizeof(double), stream_,
+    const int R = rows_per_wg16(c.ld);
+    dim3 grid((c.npinit + R - 1) / R, P);
+    hipLaunchKernelGGL(de_init, grid, dim3(16 * R), (size_t) R * c.ld * sizeof(double), stream_,
             d_, c_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(0, c.npinit);
@@ -198,12 +199,14 @@ void DeEngine::generation(bool honor_stop)
     c.np_launch = np_host_;
     const int P = c.npop;
     dim3 g16((np_host_ + 15) / 16, P);
-    const size_t lds = (size_t) 16 * c.ld * sizeof(double);
+    const int R = rows_per_wg16(c.ld);     // rows staged in LDS per workgroup
+    dim3 gR((np_host_ + R - 1) / R, P);
+    const size_t lds = (size_t) R * c.ld * sizeof(double);
     timer_.begin(stream_, K_GEN);
     if (c.variant == 2)
-        hipLaunchKernelGGL(sansde_generation, g16, dim3(256), lds, stream_, d_, c_);
+        hipLaunchKernelGGL(sansde_generation, gR, dim3(16 * R), lds, stream_, d_, c_);
     else
-        hipLaunchKernelGGL(de_generation, g16, dim3(256), lds, stream_, d_, c_);
+        hipLaunchKernelGGL(de_generation, gR, dim3(16 * R), lds, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void de_init(DeDev d, DeConst c)
     const int p = blockIdx.y;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r;
     const int ld = c.ld;
     double *row = lds + r * ld;
     double *X = d.X[0] + (size_t) p * c.npinit * ld;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     if (de_frozen(c, sc)) return;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r;
     const int ld = c.ld, n = c.n, np = sc->np, larch = sc->larch, gen = sc->gen, cur = sc->cur;
     const bool live = i < np;
     double *trial = lds + r * ld;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
     if (de_frozen(c, sc)) return;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r;
     const int ld = c.ld, n = c.n, np = sc->np, gen = sc->gen, cur = sc->cur;
     const bool live = i < np;
     double *trial = lds + r * ld;

@@ -104,8 +104,9 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     inited_ = true;
 
     dim3 g16((c.np + 15) / 16, P);
-    hipLaunchKernelGGL(pso_init, g16, dim3(256), (size_t) 16 * c.ld * sizeof(double), stream_,
-            d_, c_);
+    const int R = rows_per_wg16(c.ld);
+    hipLaunchKernelGGL(pso_init, dim3((c.np + R - 1) / R, P), dim3(16 * R),
+            (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) {
         host_evaluate_swarm();
@@ -160,7 +161,8 @@ void PsoEngine::generation(bool honor_stop)
     c.honor_stop = honor_stop ? 1 : 0;
     const int P = c.npop;
     dim3 g16((c.np + 15) / 16, P);
-    const size_t lds16 = (size_t) 16 * c.ld * sizeof(double);
+    const int R = rows_per_wg16(c.ld);     // rows staged in LDS per workgroup
+    const size_t ldsR = (size_t) R * c.ld * sizeof(double);
     timer_.begin(stream_, K_CENTER);
     hipLaunchKernelGGL(pso_center, dim3(parts_, P), dim3(256), 0, stream_, d_, c_, parts_);
     hipLaunchKernelGGL(pso_mean, dim3(P), dim3(256), 0, stream_, d_, c_, parts_);
@@ -186,7 +188,8 @@ void PsoEngine::generation(bool honor_stop)
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_UPDATE);
-    hipLaunchKernelGGL(pso_update, g16, dim3(256), lds16, stream_, d_, c_);
+    hipLaunchKernelGGL(pso_update, dim3((c.np + R - 1) / R, P), dim3(16 * R), ldsR, stream_, d_,
+            c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) {

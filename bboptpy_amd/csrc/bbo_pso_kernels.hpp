@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void pso_init(PsoDev d, PsoConst c)
     const int p = blockIdx.y;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r, ld = c.ld;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld;
     double *row = lds + r * ld;
     const size_t base = ((size_t) p * c.np + i) * ld;
     double ssq = 0.;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void pso_update(PsoDev d, PsoConst c)
     if (pso_frozen(c, sc)) return;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r, ld = c.ld, n = c.n;
+    const int i = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld, n = c.n;
     const bool live = i < c.np;
     double *row = lds + r * ld;
     const size_t base = ((size_t) p * c.np + i) * ld;

@@ -7,8 +7,8 @@
 // (base_cmaes.cpp:136-148) -- including its quirk that B and C keep their off-diagonal
 // entries across restarts (cmaes.cpp:53-59) -- and spend one extra evaluation on the point
 // each run returns (bipop_cmaes.cpp:86-87).  The driver's own draws (restart point, u, u')
-// come from the RESTART Philox stream; restart r runs the inner engine under the key
-// seed + 0x9E3779B97F4A7C15 * (r + 1).
+// come from the RESTART Philox stream at counter (run index, draw index); run r (0 = the first
+// default run) drives the inner engine under the key seed + 0x9E3779B97F4A7C15 * r.
 #include "bbo_cma.hpp"
 #include "bbo_rng.hpp"
 
@@ -23,6 +23,9 @@ public:
             params_(p), base_(base), kind_(p.algo == BBO_ALGO_IPOP_CMAES ? 0 : 1)
     {
         BBO_REQUIRE(base != nullptr, "restart driver needs a base CMA-ES optimizer");
+        // the driver hands the base ONE start point per run (guess_ / x0_, n doubles)
+        BBO_REQUIRE(base->populations() == 1,
+                "restart driver: the base optimizer must hold one population (populations=1)");
     }
 
     void init(int n, const double *lower, const double *upper, const double *guess,
@@ -34,7 +37,6 @@ public:
         upper_.assign(upper, upper + n);
         guess_.assign(guess, guess + n);
         fev_ = 0;
-        draws_ = 0;
         lambda_ = lambdadef_ = 4 + (int) (3. * std::log(1. * n));
         lambdamax_ = 10 * n * n;
         sigma_ = params_.sigma0;
@@ -160,11 +162,14 @@ public:
     int dimension() const override { return n_; }
 
 private:
-    double uniform(double a, double b)
+    // draw k of run r = it_ + 1 (run 0 is the first default run and draws nothing): k < n the
+    // restart point's coordinates, k = n / n + 1 the small regime's u / u'.  Counter-based, so
+    // the concurrent multi-GPU driver (bboptpy_amd/distributed.py) plans run r with the same
+    // numbers whatever rank executes it.
+    double uniform(int k, double a, double b)
     {
-        const u32x4 w = philox4x32_10(params_.seed, (uint32_t) draws_, 0, 0,
+        const u32x4 w = philox4x32_10(params_.seed, (uint32_t) (it_ + 1), (uint32_t) k, 0,
                 stream_word(STREAM_RESTART, 0));
-        draws_++;
         return u01(w.x, w.y) * (b - a) + a;
     }
 
@@ -199,7 +204,7 @@ private:
     // ipop_cmaes.cpp:112-162
     void iterate_ipop()
     {
-        for (int i = 0; i < n_; i++) x0_[i] = uniform(lower_[i], upper_[i]);
+        for (int i = 0; i < n_; i++) x0_[i] = uniform(i, lower_[i], upper_[i]);
         if (params_.boundlambda) {
             lambda_ <<= 1;
             if (lambda_ > lambdamax_) {
@@ -224,7 +229,7 @@ private:
     // bipop_cmaes.cpp:109-164, :204-267
     void iterate_bipop()
     {
-        for (int i = 0; i < n_; i++) x0_[i] = uniform(lower_[i], upper_[i]);
+        for (int i = 0; i < n_; i++) x0_[i] = uniform(i, lower_[i], upper_[i]);
         int regime;
         if (params_.nipop) {   // NBIPOP: favour the regime that found the incumbent
             if (bestregime_ == 1) regime = (largebudget_ <= smallbudget_ * params_.kbudget) ? 1 : 2;
@@ -245,10 +250,10 @@ private:
             largebudget_ += last_inner_fev_;
             largerestarts_++;
         } else {
-            const double u = uniform(0., 1.);
+            const double u = uniform(n_, 0., 1.);
             smalllambda_ = (int) (lambdadef_
                     * std::pow((0.5 * largelambda_) / lambdadef_, u * u));
-            smallsigma_ = params_.sigma0 * std::pow(10., -2. * uniform(0., 1.));
+            smallsigma_ = params_.sigma0 * std::pow(10., -2. * uniform(n_ + 1, 0., 1.));
             int maxfev = max_evaluations(smalllambda_);
             maxfev = std::min(maxfev, largebudget_ >> 1);
             if (inner(smalllambda_, smallsigma_, maxfev, x0_.data())) bestregime_ = 2;
@@ -294,7 +299,7 @@ private:
     int n_ = 0;
     std::vector<double> lower_, upper_, guess_, x0_, xbest_;
     std::vector<int> widths_;
-    int fev_ = 0, it_ = 0, draws_ = 0;
+    int fev_ = 0, it_ = 0;
     int lambdadef_ = 0, lambda_ = 0, lambdamax_ = 0;
     int largelambda_ = 0, smalllambda_ = 0, largebudget_ = 0, smallbudget_ = 0;
     int largerestarts_ = 0, smallrestarts_ = 0, bestregime_ = 1;

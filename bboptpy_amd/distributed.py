@@ -13,9 +13,13 @@ without a broadcast.
 
 Planning a round applies the reference's own rule (NBIPOP budget rule :117-142, large-regime
 lambda/sigma :207-214, small-regime lambda/sigma/budget cap :241-248, per-run evaluation cap
-:191-202) slot by slot, charging each planned run its evaluation CAP until the real counts
+:191-202 with the remaining budget split evenly over the slots still to plan) slot by slot,
+charging each planned run its evaluation CAP until the real counts
 arrive; with W = 1 every cap is replaced by the real count before the next decision, i.e. the
-schedule degenerates to the reference's sequential one.
+schedule degenerates to the reference's sequential one -- and to the single-GPU driver's
+(bbo_restart.hip) draw for draw: run r (= round * W + slot; run 0 is the first default run)
+takes its restart point, u and u' from the RESTART Philox stream at counter (r, k) and runs its
+inner CMA-ES under the key seed + golden * r, on both.
 """
 import math
 
@@ -82,6 +86,7 @@ class ConcurrentBiPop:
         self.variant, self.seed = variant, int(seed) & _M64
         self.device, self.group, self.runner = device, group, runner
         self._world, self._rank = world_size, rank
+        self._alg = None
 
     # -- topology ---------------------------------------------------------------------------
     def _topology(self):
@@ -96,12 +101,19 @@ class ConcurrentBiPop:
         return 1, 0, None
 
     # -- the reference's rules --------------------------------------------------------------
-    def _max_evals(self, lam, fev):   # bipop_cmaes.cpp:191-202
+    def _max_evals(self, lam, fev, slots_left=1):
+        """bipop_cmaes.cpp:191-202, with the remaining budget SPLIT EVENLY among the slots of
+        the round still to be planned (slots_left = 1, i.e. W = 1 or the last slot: the
+        reference's `mfev - fev`).  Without the split the first run's cap -- at n = 256 it is
+        1.5e7 evaluations, above any usual mfev -- would take the whole budget and leave the
+        other GPUs of the round idle."""
         maxit = int(100. + 50. * (self.n + 3) * (self.n + 3) / math.sqrt(1. * lam))
-        return min(maxit * lam, self.mfev - fev)
+        return min(maxit * lam, (self.mfev - fev) // max(1, slots_left))
 
-    def _uniform(self, rnd, slot, k, a, b):
-        w = philox4x32_10(self.seed, rnd, slot, k, (_STREAM_RESTART << 24) | 1)
+    def _uniform(self, run, k, a, b):
+        """draw k of run `run`: the sequential driver's counter layout (bbo_restart.hip
+        `uniform`), so a plan does not depend on which rank executes the run"""
+        w = philox4x32_10(self.seed, run & 0xFFFFFFFF, k, 0, _STREAM_RESTART << 24)
         return _u01(w[0], w[1]) * (b - a) + a
 
     def plan_round(self, st, world):
@@ -110,9 +122,10 @@ class ConcurrentBiPop:
         lb, sb = st.largebudget, st.smallbudget
         nl, largelambda, fev = st.largerestarts, st.largelambda, st.fev
         for s in range(world):
+            run = st.round * world + s          # global run index (0 = the first default run)
             if st.round == 0 and s == 0:
                 # the reference's first default run from the user's guess (:76-87)
-                maxfev = self._max_evals(self.lambdadef, fev)
+                maxfev = self._max_evals(self.lambdadef, fev, world - s)
                 slots.append(dict(regime=0, lam=self.lambdadef, sigma=self.sigma0,
                                   maxfev=maxfev, x0=self.guess.copy()))
                 fev += maxfev + 1
@@ -127,7 +140,7 @@ class ConcurrentBiPop:
                     regime = 2 if sb <= self.kbudget * lb else 1
             else:
                 regime = 1 if lb <= sb else 2
-            x0 = _np.array([self._uniform(st.round, s, 16 + j, self.lower[j], self.upper[j])
+            x0 = _np.array([self._uniform(run, j, self.lower[j], self.upper[j])
                             for j in range(self.n)])
             if regime == 1:
                 lam = int(self.lambdadef * math.pow(2, nl + 1))
@@ -136,17 +149,17 @@ class ConcurrentBiPop:
                                 0.01 * self.sigma0)
                 else:
                     sigma = self.sigma0
-                maxfev = self._max_evals(lam, fev)
+                maxfev = self._max_evals(lam, fev, world - s)
                 if maxfev > 0:
                     nl += 1
                     largelambda = lam
                     lb += maxfev
             else:
-                u = self._uniform(st.round, s, 0, 0., 1.)
-                u2 = self._uniform(st.round, s, 1, 0., 1.)
+                u = self._uniform(run, self.n, 0., 1.)
+                u2 = self._uniform(run, self.n + 1, 0., 1.)
                 lam = int(self.lambdadef * math.pow((0.5 * largelambda) / self.lambdadef, u * u))
                 sigma = self.sigma0 * math.pow(10., -2. * u2)
-                maxfev = min(self._max_evals(lam, fev), lb >> 1)
+                maxfev = min(self._max_evals(lam, fev, world - s), lb >> 1)
                 if maxfev > 0:
                     sb += maxfev
             if maxfev <= 0 or lam < 4:
@@ -181,12 +194,19 @@ class ConcurrentBiPop:
 
     # -- one inner run on this rank's GPU -----------------------------------------------------
     def _device_run(self, f, lam, sigma, maxfev, x0, seed):
-        cls = ActiveCMAES if self.variant == "active" else CMAES
-        alg = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
-                  device=self.device or 0)
+        """like the reference's drivers (bipop_cmaes.cpp:83-87): ONE inner optimizer per driver
+        (here: per rank), re-parameterised through setParams before every run -- so B and C
+        keep their off-diagonals from this rank's previous run (cmaes.cpp:53-59) -- and one
+        extra evaluation of the point it returns"""
+        if self._alg is None:
+            cls = ActiveCMAES if self.variant == "active" else CMAES
+            self._alg = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
+                            device=self.device or 0)
+        alg = self._alg
+        alg.set_params(lam, sigma, maxfev)
+        alg.set_seed(seed)
         sol = alg.optimize(f, self.lower, self.upper, x0)
-        fx = float(f(sol.x))
-        return sol.x, sol.n_evals, fx
+        return sol.x, sol.n_evals, alg.evaluate(sol.x)
 
     def optimize(self, f, lower, upper, guess):
         self.lower = _np.ascontiguousarray(lower, dtype=_np.float64)
@@ -205,7 +225,7 @@ class ConcurrentBiPop:
             mine = slots[rank]
             rec = _np.zeros(reclen)
             if mine is not None:
-                seed = (self.seed + _GOLDEN * (st.round * world + rank + 1)) & _M64
+                seed = (self.seed + _GOLDEN * (st.round * world + rank)) & _M64
                 if self.runner is not None:
                     x, used, fx = self.runner(mine["lam"], mine["sigma"], mine["maxfev"],
                                               mine["x0"], seed)
@@ -237,7 +257,7 @@ class ConcurrentBiPop:
         for s, plan in enumerate(slots):
             r = _np.zeros(7 + self.n)
             if plan is not None:
-                seed = (self.seed + _GOLDEN * (st.round * world + s + 1)) & _M64
+                seed = (self.seed + _GOLDEN * (st.round * world + s)) & _M64
                 run = self.runner if self.runner is not None else \
                     (lambda lam, sig, mf, x0, sd: self._device_run(f, lam, sig, mf, x0, sd))
                 x, used, fx = run(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"], seed)

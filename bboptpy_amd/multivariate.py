@@ -244,6 +244,35 @@ class BaseCMAES(MultivariateSearch):
     def phase(self, which):
         self._check(_ffi.lib().bbo_cma_phase_run(self._handle, int(which)))
 
+    def set_params(self, np, sigma0, mfev):
+        """BaseCmaes::setParams (base_cmaes.cpp:136-148; not bound to Python by the reference,
+        used by its restart drivers): new lambda, sigma0 and budget for the next initialize() /
+        optimize() of this object, which keeps B and C's off-diagonals (cmaes.cpp:53-59)"""
+        p = self._params
+        p.np, p.sigma0, p.mfev = int(np), float(sigma0), int(mfev)
+        if self._handle is not None:
+            self._check(_ffi.lib().bbo_cma_set_params(self._handle, p.np, p.sigma0, p.mfev))
+        if p.bound:
+            p.bound = 0     # the handle printed the reference's warning (or will not need to)
+
+    def set_seed(self, seed):
+        """(extension) a new Philox key WITHOUT re-creating the handle (reseed() does)"""
+        self._params.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if self._handle is not None:
+            self._check(_ffi.lib().bbo_cma_set_seed(self._handle, self._params.seed))
+
+    def evaluate(self, x):
+        """the bound objective at one point (the restart drivers' extra evaluation,
+        bipop_cmaes.cpp:86)"""
+        if self._handle is None:
+            raise RuntimeError("evaluate() called before initialize()")
+        x = _np.ascontiguousarray(_np.asarray(x, dtype=_np.float64)).ravel()
+        if x.size != self._n:
+            raise ValueError("evaluate: x must have n = %d coordinates" % self._n)
+        out = C.c_double()
+        self._check(_ffi.lib().bbo_cma_evaluate(self._handle, x, C.byref(out)))
+        return out.value
+
     def inject_normals(self, z):
         if z is None:
             self._check(_ffi.lib().bbo_cma_inject_normals(self._handle, None, 0))
@@ -291,14 +320,39 @@ class _RestartDriver(MultivariateSearch):
     def __init__(self, base, **ext):
         if not isinstance(base, BaseCMAES):
             raise TypeError("base must be a CMA-ES optimizer (CMAES / ActiveCMAES / SepCMAES)")
+        if base._params.populations != 1:
+            raise ValueError("restart drivers need a base optimizer with populations=1")
         super().__init__(**ext)
         self._base = base   # kept alive here; the reference only borrows the pointer
+        self._base_handle = None
 
     def _create(self):
         h = C.c_void_p()
         base_h = self._base._ensure_handle()
         _ffi.check(_ffi.lib().bbo_create_restart(C.byref(self._params), base_h, C.byref(h)))
+        self._base_handle = base_h
         return h
+
+    def _ensure_handle(self):
+        # the driver's handle borrows the base's engine: if the base re-created its handle
+        # (reseed()), the driver's is stale and is rebuilt over the new one
+        if self._handle is not None and self._base._handle is not self._base_handle:
+            _ffi.lib().bbo_destroy(self._handle)
+            self._handle = None
+        return super()._ensure_handle()
+
+    def _live(self):
+        if self._handle is not None and self._base._handle is not self._base_handle:
+            raise RuntimeError("the base optimizer was re-created (reseed) after this restart "
+                               "driver was initialized: call initialize() / optimize() again")
+
+    def iterate(self):
+        self._live()
+        super().iterate()
+
+    def run(self, max_generations):
+        self._live()
+        return super().run(max_generations)
 
 
 class IPopCMAES(_RestartDriver):

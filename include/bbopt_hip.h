@@ -221,6 +221,22 @@ int bbo_cma_phase_run(bbo_handle h, int phase);
  * reference's own draws.  Pass NULL to return to the device generator. */
 int bbo_cma_inject_normals(bbo_handle h, const double *z, int count);
 
+/* BaseCmaes::setParams(np, sigma, mfev) (base_cmaes.cpp:136-148): what the reference's restart
+ * drivers call on their borrowed `base` before every inner run (bipop_cmaes.cpp:83,220,251;
+ * ipop_cmaes.cpp:92,140).  Like the reference it switches `bound` off with a warning on stderr.
+ * Takes effect at the next bbo_init / bbo_optimize; B and C keep their off-diagonals across
+ * re-inits of one handle with the same n (cmaes.cpp:53-59). */
+int bbo_cma_set_params(bbo_handle h, int np, double sigma0, int mfev);
+
+/* (extension) a new Philox key for the next bbo_init / bbo_optimize of this handle; the
+ * reference has no seed API (random.hpp:150-163). */
+int bbo_cma_set_seed(bbo_handle h, uint64_t seed);
+
+/* One evaluation of the handle's objective at x (n doubles), with the objective bound by the
+ * last bbo_init / bbo_optimize: the restart drivers' re-evaluation of the point an inner run
+ * returned (`_f._f(&x[0])`, bipop_cmaes.cpp:86,223,254; ipop_cmaes.cpp:95,143). */
+int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out);
+
 const char *bbo_last_error(bbo_handle h);   /* h may be NULL: last creation error */
 const char *bbo_version(void);
 int bbo_device_count(void);

@@ -187,6 +187,63 @@ def gen_restart_runs(R):
     dump("restart_runs.json", runs)
 
 
+def _capture_stdout(fn):
+    """run fn() with the process-level stdout (fd 1: the reference prints through std::cout)
+    redirected into a temporary file; returns the text"""
+    import ctypes
+    import tempfile
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        os.dup2(tmp.fileno(), 1)
+        try:
+            fn()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tmp.seek(0)
+        return tmp.read().decode()
+
+
+def gen_restart_print(R):
+    """the `print=True` Tabular rows (tabular.hpp:65-77; bipop_cmaes.cpp:100-106,153-162;
+    ipop_cmaes.cpp:104-109,158-160): the text the reference writes, next to the values it
+    formatted"""
+    import ctypes as C
+    runs = []
+    for drv, seed, n, obj in (("bipop", 7, 5, "rastrigin"), ("ipop", 8, 5, "rosenbrock")):
+        R.f(drv + "_set_print").argtypes = [C.c_void_p, C.c_int]
+        R.f(drv + "_set_print").restype = None
+        R.seed(seed)
+        lo, up = -5. * np.ones(n), 5. * np.ones(n)
+        guess = np.random.default_rng(seed).uniform(-5, 5, n)
+        base = po.cma(R, "active", 1, 1e-6, 4)
+        h = getattr(po, drv)(R, base, 30000)
+        R.f(drv + "_set_print")(h.ptr, 1)
+        keys = ("it", "largerestarts", "smallrestarts", "largebudget", "smallbudget", "fev",
+                "fx", "fxbest") if drv == "bipop" else ("it", "fev", "lambda", "sigma", "fx",
+                                                        "fbest")
+        rows = []
+
+        def body():
+            h.init(obj, lo, up, guess)
+            rows.append({k: hx(h.get(k)) for k in keys})
+            for _ in range(8):
+                if h.scalar("fev") >= 30000:
+                    break
+                h.iterate()
+                rows.append({k: hx(h.get(k)) for k in keys})
+
+        text = _capture_stdout(body)
+        runs.append({"driver": drv, "seed": seed, "n": n, "objective": obj, "mfev": 30000,
+                     "lines": text.split("\n"), "values": rows})
+        h.destroy()
+    dump("restart_print.json", runs)
+
+
 SEP_STATE = ("xmean", "sigma", "pc", "ps", "csep", "D", "arx", "fit_val", "fit_idx", "it",
              "fev", "fbest", "fworst")
 
@@ -354,7 +411,8 @@ def main():
                  "development container")
     only = sys.argv[1] if len(sys.argv) > 1 else None   # e.g. "sep": regenerate one file
     gens = {"rng": gen_rng, "cma_constants": gen_cma_constants, "cma": gen_cma_runs,
-            "pop": gen_pop_runs, "restart": gen_restart_runs, "sep": gen_sep_runs,
+            "pop": gen_pop_runs, "restart": gen_restart_runs,
+            "restart_print": gen_restart_print, "sep": gen_sep_runs,
             "sansde": gen_sansde_runs, "cso": gen_cso_runs, "ccpso": gen_ccpso_runs,
             "ccpso_local": gen_ccpso_local_runs}
     for name, fn in gens.items():

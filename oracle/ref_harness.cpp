@@ -447,6 +447,7 @@ struct ApsoProbe: APSOSearch {
 
 struct BiPopProbe: BiPopCmaes {
     using BiPopCmaes::BiPopCmaes;
+    void set_print(bool on) { _print = on; }   /* the Tabular rows, bipop_cmaes.cpp:100-106,153-162 */
     int get(const std::string &k, double *out, int cap)
     {
         if (k == "xbest") return put(_xbest, out, cap);
@@ -471,6 +472,7 @@ struct BiPopProbe: BiPopCmaes {
 
 struct IPopProbe: IPopCmaes {
     using IPopCmaes::IPopCmaes;
+    void set_print(bool on) { _print = on; }   /* ipop_cmaes.cpp:104-109,158-160 */
     int get(const std::string &k, double *out, int cap)
     {
         if (k == "xbest") return put(_xbest, out, cap);
@@ -696,6 +698,10 @@ void* ref_bipop_create(void *base, int mfev, double sigma0, int maxlargeruns,
     return h;
 }
 void ref_bipop_destroy(void *p) { delete static_cast<RefPop<BiPopProbe>*>(p); }
+void ref_bipop_set_print(void *p, int on)
+{
+    static_cast<RefPop<BiPopProbe>*>(p)->alg->set_print(on != 0);
+}
 void ref_bipop_init(void *p, int obj, int n, const double *lower,
         const double *upper, const double *guess)
 {
@@ -739,6 +745,10 @@ void* ref_ipop_create(void *base, int mfev, double sigma0, int nipop,
     return h;
 }
 void ref_ipop_destroy(void *p) { delete static_cast<RefPop<IPopProbe>*>(p); }
+void ref_ipop_set_print(void *p, int on)
+{
+    static_cast<RefPop<IPopProbe>*>(p)->alg->set_print(on != 0);
+}
 void ref_ipop_init(void *p, int obj, int n, const double *lower,
         const double *upper, const double *guess)
 {

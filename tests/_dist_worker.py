@@ -24,10 +24,26 @@ def oracle_runner(lo, up, obj):
     return run
 
 
-def drive(world=None, rank=None, mfev=60000, n=5, seed=17):
+def shared_oracle_runner(lo, up, obj, tol=1e-8):
+    """ONE inner CMA-ES object re-parameterised before every run (setParams), as the
+    reference's drivers and ConcurrentBiPop._device_run do: B and C carry over"""
+    import pyoracle as po
+    O = po.oracle()
+    h = po.cma(O, "active", 1, tol, 4)
+
+    def run(lam, sigma, maxfev, x0, seed):
+        h.step("set_params", int(lam), float(sigma), int(maxfev))
+        h.set_rng(po.RNG_PHILOX, seed)
+        x, fev, _ = h.optimize(obj, lo, up, x0)
+        return x, fev, O.objective(obj, x)
+    return run
+
+
+def drive(world=None, rank=None, mfev=60000, n=5, seed=17, shared=False):
     from bboptpy_amd.distributed import ConcurrentBiPop
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
-    d = ConcurrentBiPop(mfev=mfev, seed=seed, runner=oracle_runner(lo, up, "rastrigin"),
+    make = shared_oracle_runner if shared else oracle_runner
+    d = ConcurrentBiPop(mfev=mfev, seed=seed, runner=make(lo, up, "rastrigin"),
                         world_size=world, rank=rank)
     sol = d.optimize(None, lo, up, np.random.default_rng(seed).uniform(-5, 5, n))
     st = d.state

@@ -36,6 +36,9 @@ def _lower(m, n):
     ("cmaes", 128, 256, "sphere"),
     ("active", 160, 48, "ellipsoid"),     # 128 < n <= 256: divide and conquer, external top merge
     ("active", 256, 32, "rosenbrock"),
+    ("active", 280, 24, "sphere"),        # 272 < ld <= 288: the Gram slab no longer fits 64 rows
+    ("active", 300, 40, "ellipsoid"),     # n > 256: Householder + QL on the L2 matrix
+    ("cmaes", 512, 24, "sphere"),         # the largest accepted n (generic kernels at ld = 512)
 ])
 def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
     from bboptpy_amd import _ffi
@@ -56,7 +59,7 @@ def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
         assert int(g.get_state(key)[0]) == int(o.scalar(key)), key
     np.testing.assert_array_equal(g.get_state("weights"), o.get("weights"))
 
-    for gen in range(6):
+    for gen in range(6 if n <= 256 else 2):
         # the eigenbasis is an OUTPUT of the previous generation's eigen phase, checked below
         # through its invariants; feeding the device's (B, D, C^-1/2) to the oracle keeps
         # nearly-degenerate eigenvectors (gen 1: C = I + small) from blurring the GEMM checks

@@ -1,0 +1,162 @@
+"""GPU parity at the HEADLINE shapes: ActiveCMAES n = 128 with lambda = 256 / 1024 (C3) / 4096 (M),
+and the many-population launch geometries the benchmark runs (cma_sample_eval128 with its
+rows-per-workgroup loop, cma_whiten128 in both its branches, cma_gram128 with split-K slabs),
+every population against the CPU oracle.
+
+The oracle follows at these sizes: one generation of n = 128, lambda = 4096 costs it ~0.15 s
+(active_cmaes.cpp:71-168 restated), so a few generations of a few populations stay in seconds.
+Randomness: the device records its normals (sub-stream p for population p), the oracle is fed
+the same ones (deterministic steps under injected randomness).
+
+Tolerances (fp64, eps = 2^-53): sums over lambda = 4096 candidates and n = 128 columns in a
+different association order than the reference's loops -> 1e-10 relative to the largest entry
+for GEMM-class outputs, 1e-9 for ycoeff (a quotient of two such sums)."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err <= rtol, "%s: rel err %.3e > %.1e" % (what, err, rtol)
+
+
+def _same_ranking(gi, oi, fo):
+    """identical, or different only where two fitness values tie to rounding"""
+    if np.array_equal(gi, oi):
+        return True
+    bad = np.nonzero(gi != oi)[0]
+    near = np.minimum(np.abs(fo[bad] - fo[np.maximum(bad - 1, 0)]),
+                      np.abs(fo[bad] - fo[np.minimum(bad + 1, fo.size - 1)]))
+    assert np.all(near <= 1e-9 * np.abs(fo[bad]) + 1e-300), "ranking differs beyond rounding ties"
+    return False
+
+
+def _run_against_oracle(hip, oracle_lib, n, lam, P, pops, gens, obj, bound, seed,
+                        lo, up, guess, sigma0=2.):
+    """device handle of P populations, oracle objects for the populations in `pops`; every
+    phase of `gens` generations compared"""
+    from bboptpy_amd import _ffi
+    g = hip.ActiveCMAES(mfev=10 ** 9, tol=1e-14, np=lam, seed=seed, populations=P,
+                        sigma0=sigma0, bound=bound)
+    g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+    g.set_state("record_normals", [1.0])
+    orc = {}
+    for p in pops:
+        o = po.cma(oracle_lib, "active", 10 ** 9, 1e-14, lam, sigma0=sigma0, bound=bound)
+        o.set_rng(po.RNG_INJECT)
+        o.init(obj, lo, up, guess[p])
+        orc[p] = o
+    clamped = 0
+    for gen in range(gens):
+        for p, o in orc.items():
+            # the basis is the previous eigen phase's output (checked below through D, C^-1/2
+            # and the invariants); hand it over so eigenvector signs do not enter the GEMM checks
+            o.set("B", g.get_state("B", p))
+            o.set("D", g.get_state("D", p))
+            o.set("invsqrtC", g.get_state("invsqrtC", p))
+        g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+        for p, o in orc.items():
+            z = g.get_state("zlast", p)
+            assert z.size == lam * n and np.isfinite(z).all()
+            o.inject_z(z)
+            o.step("sample")
+            o.step("evaluate_sort")
+            X = g.get_state("arx", p)
+            _close(X, o.get("arx"), 1e-11, "arx p%d gen %d" % (p, gen))
+            if bound:
+                Xm = X.reshape(lam, n)
+                clamped += int(np.sum((Xm == lo) | (Xm == up)))
+        g.phase(_ffi.PHASE_RANK)
+        comparable = {}
+        for p, o in orc.items():
+            fo = o.get("fit_val")
+            _close(g.get_state("fit_val", p), fo, 1e-10, "sorted fitness p%d" % p)
+            comparable[p] = _same_ranking(g.get_state("fit_idx", p).astype(int),
+                                          o.get("fit_idx").astype(int), fo)
+            assert int(g.get_state("fev", p)[0]) == int(o.scalar("fev"))
+        g.phase(_ffi.PHASE_UPDATE)
+        g.phase(_ffi.PHASE_EIGEN)
+        g.phase(_ffi.PHASE_HISTORY_STOP)
+        for p, o in orc.items():
+            if not comparable[p]:
+                pytest.skip("a fitness tie to rounding changed the ranking of population %d" % p)
+            o.step("update_distribution")
+            o.step("update_history")
+            tag = " p%d gen %d" % (p, gen)
+            _close(g.get_state("xmean", p), o.get("xmean"), 1e-11, "xmean" + tag)
+            _close(g.get_state("ps", p), o.get("ps"), 1e-10, "ps" + tag)
+            _close(g.get_state("pc", p), o.get("pc"), 1e-10, "pc" + tag)
+            _close(g.get_state("sigma", p), o.get("sigma"), 1e-10, "sigma" + tag)
+            _close(g.get_state("ycoeff", p), o.get("ycoeff"), 1e-9, "ycoeff" + tag)
+            Cg = np.tril(g.get_state("C", p).reshape(n, n))
+            Co = np.tril(o.get("C").reshape(n, n))
+            _close(Cg, Co, 1e-10, "C (lower)" + tag)
+            B = g.get_state("B", p).reshape(n, n)
+            D = g.get_state("D", p)
+            Cs = Cg + np.tril(Cg, -1).T
+            assert np.all(np.diff(D) >= 0)
+            assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cs) <= 1e-12 * np.linalg.norm(Cs)
+            assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n
+            _close(D, o.get("D"), 1e-9, "D" + tag)
+            _close(g.get_state("invsqrtC", p), o.get("invsqrtC"), 1e-8, "invsqrtC" + tag)
+            assert int(g.get_state("it", p)[0]) == int(o.scalar("it"))
+            assert int(g.get_state("flag", p)[0]) == o.converged()
+    for o in orc.values():
+        o.destroy()
+    return g, clamped
+
+
+@pytest.mark.parametrize("lam", [256, 1024, 4096])
+def test_active_n128_generation_matches_oracle(hip, oracle_lib, lam):
+    """one population, n = 128, ActiveCMAES on Rosenbrock: lambda = 1024 is C3, 4096 is M
+    (active_cmaes.cpp:71-168: mean, paths, ycoeff, rank-mu + negative update)"""
+    n = 128
+    rng = np.random.default_rng(lam)
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = rng.uniform(-10, 10, (1, n))
+    _run_against_oracle(hip, oracle_lib, n, lam, 1, [0], 5, "rosenbrock", False, 77, lo, up,
+                        guess)
+
+
+@pytest.mark.parametrize("bound", [False, True])
+def test_batched_whole_population_kernels_match_oracle(hip, oracle_lib, bound):
+    """16 populations x lambda = 4096 (P mu_pad = 32768): the whole-population kernels are the
+    ones launched -- cma_sample_eval128, cma_whiten128 (bound=False: the sigma^2 ||z||^2
+    shortcut; bound=True: clamped samples, the reference's C^-1/2 GEMM), cma_gram128 with 32
+    slabs -- and EVERY population is held against its own oracle object"""
+    n, lam, P = 128, 4096, 16
+    rng = np.random.default_rng(11)
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = rng.uniform(-4, 4, (P, n))
+    g, clamped = _run_against_oracle(hip, oracle_lib, n, lam, P, list(range(P)), 3,
+                                     "rosenbrock", bound, 4321, lo, up, guess)
+    if bound:
+        assert clamped > 1000    # the box really bites: the shortcut would be wrong here
+
+
+def test_bench_geometry_matches_oracle(hip, oracle_lib):
+    """the benchmark's own launch: 256 populations x lambda = 4096 (one cma_sample_eval128
+    workgroup per population sweeping 4096 rows, cma_gram128 with 4 slabs per population,
+    cma_whiten128 with 2048 rows per workgroup); populations 0, 131 and 255 against the oracle"""
+    n, lam, P = 128, 4096, 256
+    rng = np.random.default_rng(12)
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = rng.uniform(-10, 10, (P, n))
+    _run_against_oracle(hip, oracle_lib, n, lam, P, [0, 131, 255], 3, "rosenbrock", False,
+                        99, lo, up, guess)
+
+
+def test_c3_batched_matches_oracle(hip, oracle_lib):
+    """C3 in the batch the benchmark uses for it: 64 populations x lambda = 1024"""
+    n, lam, P = 128, 1024, 64
+    rng = np.random.default_rng(13)
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = rng.uniform(-10, 10, (P, n))
+    _run_against_oracle(hip, oracle_lib, n, lam, P, [0, 17, 63], 4, "rosenbrock", False, 5,
+                        lo, up, guess)

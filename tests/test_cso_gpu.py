@@ -26,6 +26,8 @@ def _close(a, b, rtol, what):
     (12, 202, "ackley", dict(pcompete=2, ring=True, correct=False, vmax=0.1)),   # np > 100: phi > 0
     (16, 9000, "sphere", dict(pcompete=3)),                         # a large swarm
     (301, 30, "ellipsoid", dict(pcompete=3)),                       # > 128 columns: chunked row loop
+    (513, 30, "sphere", dict(pcompete=3)),                          # > 512 columns: 8 groups per workgroup
+    (1024, 24, "rastrigin", dict(pcompete=2, ring=True)),
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, n, npp, obj, kw):
     seed = 321

@@ -66,6 +66,10 @@ def _compare(g, o, algo, tag):
     ("jade", 21, dict(mfev=100000, np=40, tol=1e-12, pelite=0.2, archive=False), "griewank"),
     ("shade", 150, dict(mfev=100000, npinit=24, tol=1e-12), "ellipsoid"),   # > 128 columns: the
     ("jade", 301, dict(mfev=100000, np=20, tol=1e-12), "sphere"),           # loop's second pass
+    # rows of more than 512 doubles: 8 / 4 individuals per workgroup (rows_per_wg16)
+    ("shade", 513, dict(mfev=100000, npinit=24, tol=1e-12), "rastrigin"),
+    ("jade", 1024, dict(mfev=100000, np=20, tol=1e-12), "rosenbrock"),
+    ("shade", 2048, dict(mfev=100000, npinit=18, tol=1e-12), "sphere"),
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, algo, n, kw, obj):
     g, o = _pair(hip, oracle_lib, algo, n, kw.get("npinit", kw.get("np")), obj, 99, **kw)
@@ -73,12 +77,24 @@ def test_generations_match_sync_oracle(hip, oracle_lib, algo, n, kw, obj):
     np.testing.assert_array_equal(np.sort(g.get_state("x"), axis=None),
                                   np.sort(o.get("x"), axis=None))
     _compare(g, o, algo, "init")
-    for gen in range(25):
+    for gen in range(25 if n <= 512 else 6):
         g.iterate()
         o.iterate()
         _compare(g, o, algo, "gen %d" % gen)
         if o.scalar("fev") >= kw["mfev"]:
             break
+
+
+def test_c2_full_size_generations_match_sync_oracle(hip, oracle_lib):
+    """C2 itself: L-SHADE n = 128, np = 4096, Rastrigin, three generations against the
+    generation-synchronous oracle (~25 ms per generation there)"""
+    n, kw = 128, dict(mfev=10 ** 8, npinit=4096, tol=1e-12)
+    g, o = _pair(hip, oracle_lib, "shade", n, 4096, "rastrigin", 2024, **kw)
+    _compare(g, o, "shade", "init")
+    for gen in range(3):
+        g.iterate()
+        o.iterate()
+        _compare(g, o, "shade", "gen %d" % gen)
 
 
 def test_shade_solves_sphere_and_stops(hip):

@@ -53,6 +53,33 @@ def test_world1_degenerates_to_the_reference_schedule():
     assert res["fev"] == sum(h["used"] + 1 for h in res["history"])
 
 
+def test_world1_equals_the_oracle_restart_driver_draw_for_draw():
+    """W = 1 with one shared inner optimizer IS the sequential driver: same restart points, same
+    (regime, lambda, sigma, evaluations, f*) per run and the same incumbent as the oracle's
+    Restart (bipop_cmaes.cpp:61-267 restated, pinned to the reference) under the same Philox key"""
+    import pyoracle as po
+    n, seed, mfev = 5, 17, 40000
+    res = drive(world=1, rank=0, mfev=mfev, n=n, seed=seed, shared=True)
+    O = po.oracle()
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    o = po.bipop(O, po.cma(O, "active", 1, 1e-8, 4), mfev)
+    o.set_mode(False, po.RNG_PHILOX, seed)
+    o.init("rastrigin", lo, up, np.random.default_rng(seed).uniform(-5, 5, n))
+    rows = [(0, int(o.scalar("last_lambda")), o.scalar("last_sigma"),
+             int(o.scalar("last_inner_fev")), o.scalar("fx"))]
+    while True:
+        o.iterate()
+        rows.append((int(o.scalar("last_regime")), int(o.scalar("last_lambda")),
+                     o.scalar("last_sigma"), int(o.scalar("last_inner_fev")), o.scalar("fx")))
+        if o.scalar("largerestarts") >= 9 or o.scalar("fev") >= mfev:
+            break
+    got = [(h["regime"], h["lam"], h["sigma"], h["used"], h["fx"]) for h in res["history"]]
+    assert got == rows
+    assert res["fev"] == int(o.scalar("fev"))
+    assert float.fromhex(res["fxbest"]) == o.scalar("fxbest")
+    np.testing.assert_array_equal([float.fromhex(v) for v in res["x"]], o.get("xbest"))
+
+
 def test_gloo_world2_matches_the_serial_reduction(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",

@@ -27,6 +27,10 @@ def _close(a, b, rtol, what):
     (33, 70, "sphere", True),         # odd n, np not a multiple of 16 or 64
     (16, 64, "ackley", False),
     (64, 130, "griewank", True),
+    # rows of more than 512 doubles: 8 / 4 particles per workgroup (rows_per_wg16)
+    (513, 40, "sphere", True),
+    (1024, 24, "rastrigin", True),
+    (2048, 20, "sphere", False),
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
@@ -40,7 +44,7 @@ def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
     _close(g.get_state("f"), o.get("f"), 1e-12, "init f")
     _close(g.get_state("fbest"), o.get("fbest"), 1e-12, "init fbest")
     states = []
-    for gen in range(40):
+    for gen in range(40 if n <= 512 else 6):
         g.iterate()
         o.iterate()
         tag = "gen %d" % gen
@@ -56,7 +60,8 @@ def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
         _close(g.get_state("f"), o.get("f"), 1e-10, tag + " f")
         _close(g.get_state("xbest"), o.get("xbest"), 1e-11, tag + " gbest")
         _close(g.get_state("fbest"), o.get("fbest"), 1e-10, tag + " fbest")
-    assert len(set(states)) >= 2   # the fuzzy state machine actually moved
+    if n <= 512:
+        assert len(set(states)) >= 2   # the fuzzy state machine actually moved
 
 
 def test_apso_solves_sphere(hip):

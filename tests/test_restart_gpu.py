@@ -109,3 +109,112 @@ def test_ipop_doubles_lambda_and_shrinks_sigma(hip):
         assert int(drv.get_state("fev")[0]) == fev
     sol = drv.solution()
     assert sol.n_evals == fev and not sol.converged
+
+
+# ---- the device drivers against the oracle's Restart (itself pinned bit for bit to the
+# reference's BiPopCmaes / IPopCmaes under mt19937, tests/test_oracle_vs_reference.py) -------
+def _schedule_row(h, get):
+    return (int(get(h, "last_regime")), int(get(h, "last_lambda")), get(h, "last_sigma"),
+            int(get(h, "last_inner_fev")), int(get(h, "fev")))
+
+
+@pytest.mark.parametrize("driver,variant,n,obj,seed", [
+    ("bipop", "active", 6, "rastrigin", 21),
+    ("bipop", "active", 10, "rosenbrock", 22),
+    ("bipop", "cmaes", 5, "ellipsoid", 23),
+    ("ipop", "active", 6, "rastrigin", 24),
+    ("ipop", "cmaes", 8, "sphere", 25),
+])
+def test_restart_schedule_matches_oracle_restart(hip, oracle_lib, driver, variant, n, obj, seed):
+    """Same Philox key on both sides: the oracle's Restart draws the driver's restart points,
+    u and u' from the RESTART stream and runs restart r's inner CMA-ES under the key
+    seed + golden * (r + 1), exactly the device's rule (bbo_restart.hip); n <= 16, so the
+    device eigensolver has the reference's sign conventions and whole inner runs coincide.
+    Compared per restart: (regime, lambda, sigma, evaluations used, budget) exactly, the
+    returned f* to 1e-7 relative (hundreds of generations of rounding), the bookkeeping exactly."""
+    import pyoracle as po
+    mfev = 40000
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(-5, 5, n)
+    cls = hip.ActiveCMAES if variant == "active" else hip.CMAES
+    base = cls(mfev=1, tol=1e-6, np=4)
+    drv = (hip.BiPopCMAES if driver == "bipop" else hip.IPopCMAES)(base, mfev=mfev, seed=seed)
+    drv.initialize(getattr(hip.objectives, obj), lo, up, guess)
+    ob = po.cma(oracle_lib, variant, 1, 1e-6, 4)
+    o = getattr(po, driver)(oracle_lib, ob, mfev)
+    o.set_mode(False, po.RNG_PHILOX, seed)
+    o.init(obj, lo, up, guess)
+    gd = lambda h, k: h.get_state(k)[0]
+    go = lambda h, k: h.scalar(k)
+    assert int(gd(drv, "fev")) == int(go(o, "fev"))
+    assert gd(drv, "fx") == pytest.approx(go(o, "fx"), rel=1e-7, abs=1e-12)
+    rows = 0
+    for _ in range(14):
+        if go(o, "fev") >= mfev or (driver == "bipop" and go(o, "largerestarts") >= 9):
+            break
+        drv.iterate()
+        o.iterate()
+        np.testing.assert_array_equal(drv.get_state("x0"), o.get("x0"))      # same restart point
+        if driver == "bipop":
+            assert _schedule_row(drv, gd) == _schedule_row(o, go)
+            for k in ("largebudget", "smallbudget", "largerestarts", "smallrestarts",
+                      "bestregime"):
+                assert int(gd(drv, k)) == int(go(o, k)), k
+        else:
+            for k in ("lambda", "last_inner_fev", "fev"):
+                assert int(gd(drv, k)) == int(go(o, k)), k
+            assert gd(drv, "sigma") == go(o, "sigma")
+        assert gd(drv, "fx") == pytest.approx(go(o, "fx"), rel=1e-7, abs=1e-12)
+        assert gd(drv, "fxbest") == pytest.approx(go(o, "fxbest"), rel=1e-7, abs=1e-12)
+        rows += 1
+    assert rows >= 4
+    np.testing.assert_allclose(drv.get_state("xbest"), o.get("xbest"), rtol=0, atol=1e-7)
+
+
+# ---- print=True: the Tabular rows (tabular.hpp:65-77) -----------------------------------------
+def _cells(line):
+    assert line.startswith(" | ") and line.endswith(" | "), repr(line)
+    return line[3:-3].split(" | ")
+
+
+@pytest.mark.parametrize("driver", ["bipop", "ipop"])
+def test_print_rows_have_the_reference_format(hip, capfd, driver):
+    """header, rule and row layout against the text the compiled reference printed
+    (tests/golden/restart_print.json); the numbers in each row against the driver's own state,
+    formatted the reference's way (toStringFull: max_digits10 significant digits, %g style)"""
+    from _golden import load
+    from _tabular import fmt_cell, WIDTHS
+    rec = [r for r in load("restart_print.json") if r["driver"] == driver][0]
+    n = rec["n"]
+    base = hip.ActiveCMAES(mfev=1, tol=1e-6, np=4)
+    cls = hip.BiPopCMAES if driver == "bipop" else hip.IPopCMAES
+    drv = cls(base, mfev=rec["mfev"], print=True, seed=3)
+    capfd.readouterr()
+    drv.initialize(getattr(hip.objectives, rec["objective"]), -5. * np.ones(n), 5. * np.ones(n),
+                   np.random.default_rng(1).uniform(-5, 5, n))
+    want = []
+
+    def expect():
+        g = lambda k: drv.get_state(k)[0]
+        if driver == "bipop":
+            reg = int(g("last_regime"))
+            vals = [int(g("it")), reg, int(g("largerestarts")), int(g("smallrestarts")),
+                    int(g("largebudget")), int(g("smallbudget")), int(g("fev")),
+                    int(g("last_lambda")), g("last_sigma"), g("fx"), g("fxbest")]
+        else:
+            vals = [int(g("it")), int(g("fev")), int(g("last_lambda")), g("last_sigma"),
+                    g("fx"), g("fxbest")]
+        want.append(" | " + " | ".join(fmt_cell(v, w) for v, w in zip(vals, WIDTHS[driver]))
+                    + " | ")
+
+    expect()
+    for _ in range(5):
+        drv.iterate()
+        expect()
+    out = capfd.readouterr().out.split("\n")
+    assert out[0] == rec["lines"][0]          # header, character for character
+    assert out[1] == rec["lines"][1]          # the rule under it
+    assert out[2:2 + len(want)] == want
+    for line in out[2:2 + len(want)]:
+        assert [len(c) for c in _cells(line)] == [max(w, len(c.strip())) for w, c in
+                                                  zip(WIDTHS[driver], _cells(line))]

@@ -23,6 +23,8 @@ def _close(a, b, rtol, what):
     (12, 20, "ackley", dict(crref=1, pupdate=4, crupdate=2)),
     (64, 256, "sphere", dict(pupdate=10, crupdate=5)),
     (201, 24, "ellipsoid", dict(pupdate=6, crupdate=3)),       # > 128 columns: second pass of the loop
+    (600, 20, "sphere", dict(pupdate=6, crupdate=3)),          # > 512 columns: 8 rows per workgroup
+    (2048, 16, "rosenbrock", dict(pupdate=3, crupdate=2)),     # the largest accepted n: 4 rows
 ])
 def test_generations_match_sync_oracle(hip, oracle_lib, n, npp, obj, kw):
     seed = 123
