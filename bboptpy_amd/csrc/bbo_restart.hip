@@ -151,6 +151,7 @@ public:
         if (k == "last_sigma") return one(last_sigma_);
         if (k == "last_inner_fev") return one(last_inner_fev_);
         if (k == "last_inner_converged") return one(last_inner_conv_);
+        if (k == "last_maxfev") return one(last_maxfev_);
         throw Error(BBO_ERR_KEY, "unknown state key '" + k + "'");
     }
 
@@ -183,6 +184,7 @@ private:
     int inner(int lam, double sig, int maxfev, const double *start)
     {
         base_->set_params(lam, sig, maxfev);
+        last_maxfev_ = maxfev;
         base_->set_seed(params_.seed + 0x9E3779B97F4A7C15ull * (uint64_t) (it_ + 1));
         std::vector<double> x(n_);
         int ifev = 0, iconv = 0;
@@ -303,7 +305,8 @@ private:
     int lambdadef_ = 0, lambda_ = 0, lambdamax_ = 0;
     int largelambda_ = 0, smalllambda_ = 0, largebudget_ = 0, smallbudget_ = 0;
     int largerestarts_ = 0, smallrestarts_ = 0, bestregime_ = 1;
-    int last_regime_ = 0, last_inner_fev_ = 0, last_inner_conv_ = 0, last_lambda_ = 0;
+    int last_regime_ = 0, last_inner_fev_ = 0, last_inner_conv_ = 0, last_lambda_ = 0,
+            last_maxfev_ = 0;
     double fx_ = 0., fxbest_ = 0., sigma_ = 0., largesigma_ = 0., smallsigma_ = 0.,
             last_sigma_ = 0.;
 };

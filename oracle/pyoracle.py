@@ -166,6 +166,8 @@ class _Lib:
                 f("pop_set_mode").restype = None
                 f("restart_set_rng").argtypes = [C.c_void_p, C.c_int, C.c_uint64]
                 f("restart_set_rng").restype = None
+                f("restart_set").argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+                f("restart_set").restype = C.c_int
 
     def f(self, name):
         return getattr(self.lib, self.p + name)
@@ -255,6 +257,11 @@ class Handle:
         else:
             kind = {"apso": 1, "sansde": 2, "cso": 3, "ccpso": 4}.get(self.alg, 0)
             self.lib.f("pop_set_mode")(self.ptr, kind, 1 if sync else 0, rng_mode, seed)
+
+    def rset(self, key, value):
+        """restart drivers (oracle only): overwrite one bookkeeping field"""
+        if self.lib.f("restart_set")(self.ptr, key.encode(), float(value)) < 0:
+            raise KeyError(key)
 
     def destroy(self):
         if self.ptr:

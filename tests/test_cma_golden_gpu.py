@@ -50,9 +50,17 @@ def test_injected_reference_normals_reproduce_reference_states(hip, idx):
         Cr = np.tril(unhex(st["C"]).reshape(n, n))      # the reference maintains the lower half
         _close(Cg, Cr, tol, "gen %d C" % gen)
         _close(g.get_state("invsqrtC"), unhex(st["invsqrtC"]), 1e-9, "gen %d invsqrtC" % gen)
-        _close(g.get_state("B"), unhex(st["B"]), 1e-8, "gen %d B" % gen)
         assert int(g.get_state("it")[0]) == int(unhex(st["it"])[0])
         assert int(g.get_state("fev")[0]) == int(unhex(st["fev"])[0])
+        # B itself is comparable only while the eigenvalues are simple: with lambda < n the first
+        # covariance matrices are I + (rank < n) and the basis of the repeated eigenvalue is
+        # decided by rounding inside the eigensolver -- the next generation's x = m + sigma B D z
+        # then differs legitimately, and the comparison ends here
+        ev = unhex(st["D"]) ** 2
+        if np.diff(ev).min() <= 1e-6 * ev.max():
+            assert gen >= 1
+            break
+        _close(g.get_state("B"), unhex(st["B"]), 1e-8, "gen %d B" % gen)
     g.inject_normals(None)
 
 

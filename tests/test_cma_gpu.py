@@ -38,7 +38,8 @@ def _lower(m, n):
     ("active", 256, 32, "rosenbrock"),
     ("active", 280, 24, "sphere"),        # 272 < ld <= 288: the Gram slab no longer fits 64 rows
     ("active", 300, 40, "ellipsoid"),     # n > 256: Householder + QL on the L2 matrix
-    ("cmaes", 512, 24, "sphere"),         # the largest accepted n (generic kernels at ld = 512)
+    ("active", 512, 24, "ellipsoid"),     # the largest accepted n (generic kernels at ld = 512)
+    ("cmaes", 512, 24, "sphere"),         # the lazy schedule there: no decomposition is due yet
 ])
 def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
     from bboptpy_amd import _ffi
@@ -98,6 +99,12 @@ def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
         _close(Cg, Co, rtol=1e-10, what="C (lower)")
 
         assert int(g.get_state("eigen_done")[0]) == int(o.scalar("eigen_done"))
+        if not int(o.scalar("eigen_done")):     # plain CMAES, decomposition not due (cmaes.cpp:233)
+            np.testing.assert_array_equal(g.get_state("D"), o.get("D"))
+            g.phase(_ffi.PHASE_HISTORY_STOP)
+            o.step("update_history")
+            assert int(g.get_state("flag")[0]) == o.converged()
+            continue
         B = g.get_state("B").reshape(n, n)
         D = g.get_state("D")
         Cs = Cg + np.tril(Cg, -1).T

@@ -1,10 +1,11 @@
 """GPU: the concurrent BIPOP driver (bboptpy_amd/distributed.py)
 with its inner runs on the device.
 
-* W = 1, small n: the driver IS the sequential one -- every run's (regime, lambda, sigma,
-  evaluations used) equals the oracle Restart's (bipop_cmaes.cpp:61-267 restated and pinned to
-  the reference) under the same Philox key, f* to 1e-7, and equals the single-GPU C++ driver
-  (bbo_restart.hip) exactly.
+* W = 1, small n: the driver IS the sequential one -- its whole history equals the single-GPU
+  C++ driver's (bbo_restart.hip) bit for bit, and its first run and first restart equal the
+  oracle Restart's (bipop_cmaes.cpp:61-267 restated and pinned to the reference) under the same
+  Philox key.  (The CPU test tests/test_distributed_cpu.py holds the whole W = 1 schedule
+  against the oracle Restart with the oracle as the inner optimizer.)
 * W = 2 at C5's n = 256 with the serial stand-in for the collective (both slots of a round run
   on this one GPU): the replicated bookkeeping equals the plan -- budgets are the sums of the
   evaluations the runs reported, every run stayed inside the cap it was planned with, regimes
@@ -20,7 +21,7 @@ import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-def test_world1_on_device_equals_oracle_restart_and_the_cxx_driver(hip, oracle_lib):
+def test_world1_on_device_equals_the_cxx_driver_and_the_oracle_plan(hip, oracle_lib):
     from bboptpy_amd.distributed import ConcurrentBiPop
     n, seed, mfev = 6, 31, 30000
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
@@ -29,30 +30,33 @@ def test_world1_on_device_equals_oracle_restart_and_the_cxx_driver(hip, oracle_l
     sol = d.optimize("rastrigin", lo, up, guess)           # a built-in by NAME
     hist = d.state.history
 
-    o = po.bipop(oracle_lib, po.cma(oracle_lib, "active", 1, 1e-8, 4), mfev)
-    o.set_mode(False, po.RNG_PHILOX, seed)
-    o.init("rastrigin", lo, up, guess)
     base = hip.ActiveCMAES(mfev=1, tol=1e-8, np=4)
     c = hip.BiPopCMAES(base, mfev=mfev, seed=seed)
     c.initialize(hip.objectives.rastrigin, lo, up, guess)
-    rows_o = [(0, int(o.scalar("last_lambda")), o.scalar("last_sigma"),
-               int(o.scalar("last_inner_fev")), o.scalar("fx"))]
-    rows_c = [(0, int(c.get_state("last_lambda")[0]), c.get_state("last_sigma")[0],
-               int(c.get_state("last_inner_fev")[0]), c.get_state("fx")[0])]
-    while not (o.scalar("largerestarts") >= 9 or o.scalar("fev") >= mfev):
-        o.iterate()
+    g = lambda k: c.get_state(k)[0]
+    rows_c = [(0, int(g("last_lambda")), g("last_sigma"), int(g("last_maxfev")),
+               int(g("last_inner_fev")), g("fx"))]
+    while not (g("largerestarts") >= 9 or g("fev") >= mfev):
         c.iterate()
-        rows_o.append((int(o.scalar("last_regime")), int(o.scalar("last_lambda")),
-                       o.scalar("last_sigma"), int(o.scalar("last_inner_fev")), o.scalar("fx")))
-        rows_c.append((int(c.get_state("last_regime")[0]), int(c.get_state("last_lambda")[0]),
-                       c.get_state("last_sigma")[0], int(c.get_state("last_inner_fev")[0]),
-                       c.get_state("fx")[0]))
-    got = [(h["regime"], h["lam"], h["sigma"], h["used"], h["fx"]) for h in hist]
-    assert got == rows_c                                   # the two device drivers: identical
-    assert [r[:4] for r in got] == [r[:4] for r in rows_o]  # the oracle: same schedule
-    np.testing.assert_allclose([r[4] for r in got], [r[4] for r in rows_o], rtol=1e-7, atol=1e-12)
-    assert sol.n_evals == int(o.scalar("fev")) == int(c.get_state("fev")[0])
-    assert not sol.converged
+        rows_c.append((int(g("last_regime")), int(g("last_lambda")), g("last_sigma"),
+                       int(g("last_maxfev")), int(g("last_inner_fev")), g("fx")))
+    got = [(h["regime"], h["lam"], h["sigma"], h["maxfev"], h["used"], h["fx"]) for h in hist]
+    # the Python rounds (set_params / set_seed / optimize / evaluate on one engine) and the C++
+    # RestartDriver are the same computation on the same device: identical, bit for bit
+    assert got == rows_c
+    assert sol.n_evals == int(g("fev")) and not sol.converged
+    np.testing.assert_array_equal(sol.x, c.get_state("xbest"))
+
+    # and the oracle's Restart plans the same first restart from the same first run (the
+    # horizon of inner-run equality is explained in tests/test_restart_gpu.py)
+    o = po.bipop(oracle_lib, po.cma(oracle_lib, "active", 1, 1e-8, 4), mfev)
+    o.set_mode(False, po.RNG_PHILOX, seed)
+    o.init("rastrigin", lo, up, guess)
+    assert (int(o.scalar("last_lambda")), o.scalar("last_sigma"), int(o.scalar("last_maxfev")),
+            int(o.scalar("last_inner_fev"))) == got[0][1:5]
+    o.iterate()
+    assert (int(o.scalar("last_regime")), int(o.scalar("last_lambda")), o.scalar("last_sigma"),
+            int(o.scalar("last_maxfev")), int(o.scalar("last_inner_fev"))) == got[1][:5]
 
 
 def test_world2_n256_bookkeeping_equals_the_plan(hip):

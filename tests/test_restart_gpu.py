@@ -118,57 +118,92 @@ def _schedule_row(h, get):
             int(get(h, "last_inner_fev")), int(get(h, "fev")))
 
 
-@pytest.mark.parametrize("driver,variant,n,obj,seed", [
-    ("bipop", "active", 6, "rastrigin", 21),
-    ("bipop", "active", 10, "rosenbrock", 22),
-    ("bipop", "cmaes", 5, "ellipsoid", 23),
-    ("ipop", "active", 6, "rastrigin", 24),
-    ("ipop", "cmaes", 8, "sphere", 25),
+@pytest.mark.parametrize("driver,nflag,n,obj,seed", [
+    ("bipop", True, 6, "rastrigin", 21),
+    ("bipop", False, 6, "ellipsoid", 22),
+    ("bipop", True, 10, "rosenbrock", 23),
+    ("ipop", True, 6, "rastrigin", 24),
+    ("ipop", False, 8, "schwefel12", 25),
 ])
-def test_restart_schedule_matches_oracle_restart(hip, oracle_lib, driver, variant, n, obj, seed):
-    """Same Philox key on both sides: the oracle's Restart draws the driver's restart points,
-    u and u' from the RESTART stream and runs restart r's inner CMA-ES under the key
-    seed + golden * (r + 1), exactly the device's rule (bbo_restart.hip); n <= 16, so the
-    device eigensolver has the reference's sign conventions and whole inner runs coincide.
-    Compared per restart: (regime, lambda, sigma, evaluations used, budget) exactly, the
-    returned f* to 1e-7 relative (hundreds of generations of rounding), the bookkeeping exactly."""
+def test_restart_decisions_match_oracle_restart(hip, oracle_lib, driver, nflag, n, obj, seed):
+    """Every DECISION of the device's restart drivers against the oracle's Restart
+    (bipop_cmaes.cpp:109-267 / ipop_cmaes.cpp:112-162 restated, pinned bit for bit to the
+    compiled reference): before each restart the oracle takes over the device driver's
+    bookkeeping (budgets, counters, incumbent value, best regime), both plan and run the restart,
+    and the plan -- restart point (same Philox counter (run, k) on both sides), regime, lambda,
+    sigma, evaluation cap -- must be IDENTICAL; so must the budget arithmetic applied to what the
+    device's own inner run reported.
+
+    The inner runs themselves are compared exactly only for the first run and the first restart
+    (evaluations used; f* to 1e-6 relative + 1e-7 absolute).  Beyond that they legitimately
+    part, and fast -- measured on this path (scripts/dev_restart_divergence.py): a restarted
+    run samples its first generation through the B the previous run left behind
+    (cmaes.cpp:53-59); CMA-ES is translation invariant, so the difference e that B carries
+    into the mean (1e-11 after one restart) persists unchanged while both sides rank their
+    candidates identically, and once sigma has shrunk to where e matters (tol = 1e-6 drives f to
+    1e-9) rankings flip: the run ends with C different at the 1e-2 level, and the NEXT run,
+    started through that B, is a different random run.  On (nearly) isotropic optima
+    (Rastrigin, sphere) the carried-over eigenvectors are not even a function of C (clustered
+    eigenvalues: C equal to 6e-8, B different by O(1)).  Whole inner runs are held against the
+    oracle where that is well defined: tests/test_cma_gpu.py::test_whole_run_same_seed_*."""
     import pyoracle as po
     mfev = 40000
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     guess = np.random.default_rng(seed).uniform(-5, 5, n)
-    cls = hip.ActiveCMAES if variant == "active" else hip.CMAES
-    base = cls(mfev=1, tol=1e-6, np=4)
-    drv = (hip.BiPopCMAES if driver == "bipop" else hip.IPopCMAES)(base, mfev=mfev, seed=seed)
+    base = hip.ActiveCMAES(mfev=1, tol=1e-6, np=4)
+    ob = po.cma(oracle_lib, "active", 1, 1e-6, 4)
+    if driver == "bipop":
+        drv = hip.BiPopCMAES(base, mfev=mfev, nbipop=nflag, seed=seed)
+        o = po.bipop(oracle_lib, ob, mfev, nbipop=nflag)
+        book = ("fev", "it", "largelambda", "largebudget", "smallbudget", "largerestarts",
+                "smallrestarts", "bestregime", "fxbest")
+    else:
+        drv = hip.IPopCMAES(base, mfev=mfev, nipop=nflag, seed=seed)
+        o = po.ipop(oracle_lib, ob, mfev, nipop=nflag)
+        book = ("fev", "it", "lambda", "sigma", "fxbest")
     drv.initialize(getattr(hip.objectives, obj), lo, up, guess)
-    ob = po.cma(oracle_lib, variant, 1, 1e-6, 4)
-    o = getattr(po, driver)(oracle_lib, ob, mfev)
     o.set_mode(False, po.RNG_PHILOX, seed)
     o.init(obj, lo, up, guess)
-    gd = lambda h, k: h.get_state(k)[0]
-    go = lambda h, k: h.scalar(k)
-    assert int(gd(drv, "fev")) == int(go(o, "fev"))
-    assert gd(drv, "fx") == pytest.approx(go(o, "fx"), rel=1e-7, abs=1e-12)
+    gd = lambda k: drv.get_state(k)[0]
+    go = lambda k: o.scalar(k)
+    same_f = lambda a, b: a == pytest.approx(b, rel=1e-6, abs=1e-7)
+    plan = ("last_regime", "last_lambda", "last_sigma", "last_maxfev")
+    # the first default run: nothing inherited, whole run comparable
+    assert [gd(k) for k in plan] == [go(k) for k in plan]
+    assert int(gd("last_inner_fev")) == int(go("last_inner_fev"))
+    assert int(gd("fev")) == int(go("fev")) and same_f(gd("fx"), go("fx"))
     rows = 0
     for _ in range(14):
-        if go(o, "fev") >= mfev or (driver == "bipop" and go(o, "largerestarts") >= 9):
+        if gd("fev") >= mfev or (driver == "bipop" and gd("largerestarts") >= 9):
             break
+        for k in book:                       # the oracle continues from the DEVICE's history
+            o.rset(k, gd(k))
+        before = {k: gd(k) for k in book}
         drv.iterate()
         o.iterate()
-        np.testing.assert_array_equal(drv.get_state("x0"), o.get("x0"))      # same restart point
+        np.testing.assert_array_equal(drv.get_state("x0"), o.get("x0"))
+        assert [gd(k) for k in plan] == [go(k) for k in plan], "restart %d plan" % (rows + 1)
+        used, fx = int(gd("last_inner_fev")), gd("fx")
+        if rows == 0:                        # first restart: the inner run itself, too
+            assert used == int(go("last_inner_fev"))
+            assert same_f(fx, go("fx"))
+        # the arithmetic on the device's own inner result (bipop_cmaes.cpp:223-236,254-267)
+        assert int(gd("fev")) == int(before["fev"]) + used + 1
+        assert int(gd("it")) == int(before["it"]) + 1
+        better = fx < before["fxbest"]
+        assert gd("fxbest") == (fx if better else before["fxbest"])
         if driver == "bipop":
-            assert _schedule_row(drv, gd) == _schedule_row(o, go)
-            for k in ("largebudget", "smallbudget", "largerestarts", "smallrestarts",
-                      "bestregime"):
-                assert int(gd(drv, k)) == int(go(o, k)), k
-        else:
-            for k in ("lambda", "last_inner_fev", "fev"):
-                assert int(gd(drv, k)) == int(go(o, k)), k
-            assert gd(drv, "sigma") == go(o, "sigma")
-        assert gd(drv, "fx") == pytest.approx(go(o, "fx"), rel=1e-7, abs=1e-12)
-        assert gd(drv, "fxbest") == pytest.approx(go(o, "fxbest"), rel=1e-7, abs=1e-12)
+            reg = int(gd("last_regime"))
+            assert int(gd("largebudget")) == int(before["largebudget"]) + (used if reg == 1 else 0)
+            assert int(gd("smallbudget")) == int(before["smallbudget"]) + (used if reg == 2 else 0)
+            assert int(gd("largerestarts")) == int(before["largerestarts"]) + (reg == 1)
+            assert int(gd("smallrestarts")) == int(before["smallrestarts"]) + (reg == 2)
+            assert int(gd("bestregime")) == (reg if better else int(before["bestregime"]))
         rows += 1
     assert rows >= 4
-    np.testing.assert_allclose(drv.get_state("xbest"), o.get("xbest"), rtol=0, atol=1e-7)
+    sol = drv.solution()
+    assert not sol.converged and sol.n_evals == int(gd("fev"))
+    assert getattr(hip.objectives, obj)(sol.x) == pytest.approx(gd("fxbest"), rel=1e-9, abs=1e-12)
 
 
 # ---- print=True: the Tabular rows (tabular.hpp:65-77) -----------------------------------------
