@@ -92,6 +92,10 @@ class ConcurrentBiPop:
     def _topology(self):
         if self._world is not None:
             return self._world, (self._rank or 0), None
+        import os
+        import sys
+        if "torch" not in sys.modules and "RANK" not in os.environ:
+            return 1, 0, None       # nobody set up a process group: do not pay for `import torch`
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():

@@ -7,7 +7,7 @@ order, keyword names and defaults of every constructor (:103-171, :265-269), the
 methods optimize / initialize / iterate / solution (:376-420) and the MultivariateSolution
 result object (:360-371).  Every constructor additionally accepts keyword-only extensions
 that have no reference counterpart: `seed` (Philox key; default = fresh entropy, like the
-reference's random_device seeding), `device`, and `populations`.
+reference's random_device seeding), `device`, `populations`, and `poll_every`.
 
 All computation happens in libbbopt_hip.so on the GPU.  A Python callable objective is
 supported through the host-callback path (X leaves HBM once per generation); the objects in
@@ -120,9 +120,11 @@ class MultivariateSearch:
 
     _algo = None
 
-    def __init__(self, *, seed=None, device=0, populations=1):
+    def __init__(self, *, seed=None, device=0, populations=1, poll_every=None):
         _ffi.lib()   # fail loudly at construction when the HIP library is missing
         self._params = _ffi.default_params(self._algo)
+        if poll_every is not None:      # generations between host polls of the stop flags in run()
+            self._params.poll_every = max(1, int(poll_every))
         if seed is None:
             seed = int.from_bytes(os.urandom(8), "little")
         self._params.seed = int(seed) & 0xFFFFFFFFFFFFFFFF

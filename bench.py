@@ -13,7 +13,9 @@ Workloads (BASELINE.json configs; `--workload`):
   SEP SepCMAES    n=1024 lambda=4096 Ellipsoid       (the HBM-bound CMA variant)
   C5  BIPOP-CMA-ES n=256 Rastrigin: world_size concurrent restart populations, one per GPU,
       one RCCL all-gather of per-restart bests per round (bboptpy_amd.distributed); a "step" is
-      one restart ROUND and --steps bounds the evaluation budget (steps * 25 000 per rank)
+      one restart ROUND and --steps bounds the evaluation budget (steps * 25 000 per rank).
+      Every default (M) line also carries a bounded C5 leg as `bipop_scaling`, so the driver's
+      N = 1, 2, 4, 8 runs report the BIPOP multi-restart scaling north_star asks for.
 `--populations P` independent populations of that exact shape are advanced in lockstep on
 each GPU (population p uses Philox sub-stream p).  P = 1 is the strict single-run reading of
 the config; the JSON line always carries BOTH the aggregate over P (`value`) and a
@@ -21,7 +23,13 @@ single-population measurement (`single_population`).
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs the same
 shape with different seeds, no data-path collective (weak scaling); the time is the MAX over
-ranks between two barriers.
+ranks between two barriers.  `python bench.py --gpus N` without a torchrun environment starts
+the N ranks itself (a child `python -m torch.distributed.run`, before this process touches the
+GPU) and passes their one JSON line through.
+
+The timed region runs with the per-kernel HIP-event timers OFF and one host poll at its end
+(poll_every = steps); the per-kernel shares and the roofline come from a second pass of the
+same length with the timers on.
 """
 import argparse
 import json
@@ -158,63 +166,66 @@ def sep_kernel_costs(n, lam, P):
     }
 
 
-def make_optimizer(bb, wl, P, seed, device):
+def make_optimizer(bb, wl, P, seed, device, poll=None):
     huge = 2 ** 31 - 1
     a = wl["algo"]
+    ext = dict(seed=seed, device=device, populations=P, poll_every=poll)
     if a == "SepCMAES":
-        return bb.SepCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
-                           populations=P)
+        return bb.SepCMAES(mfev=huge, tol=0., np=wl["np"], **ext)
     if a == "ActiveCMAES":
         # tol = 0: TolHistFun / TolX can never fire inside the timed region
-        return bb.ActiveCMAES(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device,
-                              populations=P)
+        return bb.ActiveCMAES(mfev=huge, tol=0., np=wl["np"], **ext)
     if a == "SHADE":
         # npmin = npinit: population-size reduction off, steady-state throughput
-        return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], seed=seed,
-                        device=device, populations=P)
+        return bb.SHADE(mfev=huge, npinit=wl["np"], tol=0., npmin=wl["np"], **ext)
     if a == "CCPSO":
-        return bb.CCPSO(mfev=huge, sigmatol=0., np=wl["np"], pps=wl["pps"], seed=seed,
-                        device=device, populations=P)
+        return bb.CCPSO(mfev=huge, sigmatol=0., np=wl["np"], pps=wl["pps"], **ext)
     if a == "CSO":
-        return bb.CSO(mfev=huge, stol=0., np=wl["np"], seed=seed, device=device, populations=P)
+        return bb.CSO(mfev=huge, stol=0., np=wl["np"], **ext)
     if a == "SANSDE":
-        return bb.SANSDE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
+        return bb.SANSDE(mfev=huge, np=wl["np"], tol=0., **ext)
     if a == "JADE":
-        return bb.JADE(mfev=huge, np=wl["np"], tol=0., seed=seed, device=device, populations=P)
+        return bb.JADE(mfev=huge, np=wl["np"], tol=0., **ext)
     if a == "APSO":
-        return bb.APSO(mfev=huge, tol=0., np=wl["np"], seed=seed, device=device, populations=P)
+        return bb.APSO(mfev=huge, tol=0., np=wl["np"], **ext)
     raise ValueError(a)
 
 
 def measure(bb, wl, P, steps, warmup, seed, device, profile, barrier=None):
+    """W untimed generations, then exactly `steps` timed ones (HIP-event timers off, one host
+    poll at the end); with profile=True a second pass of `steps` generations with the per-kernel
+    timers on follows and its report is returned"""
     n = wl["n"]
     lo = wl["box"][0] * np.ones(n)
     up = wl["box"][1] * np.ones(n)
     guess = np.random.default_rng(seed).uniform(wl["box"][0], wl["box"][1], (P, n))
-    alg = make_optimizer(bb, wl, P, seed, device)
+    alg = make_optimizer(bb, wl, P, seed, device, poll=max(steps, 1))
     alg.initialize(getattr(bb.objectives, wl["objective"]), lo, up, guess)
     if warmup > 0:
         assert alg.run(warmup) == warmup
-    if profile:
-        alg.set_state("profile", [1.0])
     count_all = wl["algo"] == "CCPSO"    # every population draws its own swarm size there
     pops = range(P) if count_all else (0,)
     fev0 = sum(alg.get_state("fev", p)[0] for p in pops)
     if barrier:
         barrier()
     t0 = time.perf_counter()
-    done = alg.run(steps)
+    done = alg.run(steps)            # returns after the stream has drained (hipStreamSynchronize)
     dt = time.perf_counter() - t0
     if barrier:
         barrier()
     assert done == steps, "a population stopped inside the timed region (%d of %d)" % (done,
                                                                                        steps)
-    prof = alg.get_state("profile") if profile else None
     # objective evaluations of ONE population inside the timed region (np per generation for
     # CMA / DE; CSO evaluates its losers only, APSO adds its elitist-learning probes)
     fev = sum(alg.get_state("fev", p)[0] for p in pops) - fev0
     if count_all:
         fev /= P            # (the caller multiplies by P again)
+    prof = None
+    if profile:
+        alg.set_state("profile", [1.0])
+        assert alg.run(steps) == steps
+        prof = alg.get_state("profile")
+        alg.set_state("profile", [0.0])
     return dt, prof, fev, alg
 
 
@@ -242,6 +253,32 @@ def generations_to_tol(bb, wl, device, pops=8, cap=20000):
     flags = [int(alg.get_state("flag", p)[0]) for p in range(pops)]
     fbest = [float(alg.get_state("fit_val", p)[0]) for p in range(pops)]
     return {"tol": 1e-4, "populations": pops, "generations": its, "stop_flag": flags,
+            "best_f_at_stop": fbest, "generations_median": float(np.median(its)),
+            "all_stopped": bool(launched < cap), "wall_s": dt}
+
+
+def generations_to_ftarget(bb, wl, device, ftarget=1e-4, pops=8, cap=30000):
+    """NON-REFERENCE metric (BASELINE.md section 2 asks for it next to the reference's own stop):
+    generations until the best f of a generation is <= 1e-4, with the TolUpSigma test
+    (cmaes.cpp:193) -- which ends the reference's lambda = 4096 run at f = 84 -- switched off
+    (bbo_set "stop_off") and tol = 0 so TolHistFun / TolX stay quiet; all other tests as in the
+    reference."""
+    n = wl["n"]
+    lo, up = wl["box"][0] * np.ones(n), wl["box"][1] * np.ones(n)
+    guess = np.random.default_rng(11).uniform(wl["box"][0], wl["box"][1], (pops, n))
+    alg = bb.ActiveCMAES(mfev=2 ** 31 - 1, tol=0., np=wl["np"], seed=11, device=device,
+                         populations=pops, poll_every=64)
+    alg.initialize(getattr(bb.objectives, wl["objective"]), lo, up, guess)
+    alg.set_state("stop_off", [float(1 << 5)])
+    alg.set_state("ftarget", [ftarget])
+    t0 = time.perf_counter()
+    launched = alg.run(cap)
+    dt = time.perf_counter() - t0
+    its = [int(alg.get_state("it", p)[0]) for p in range(pops)]
+    flags = [int(alg.get_state("flag", p)[0]) for p in range(pops)]
+    fbest = [float(alg.get_state("fit_val", p)[0]) for p in range(pops)]
+    return {"label": "non-reference: TolUpSigma disabled, stop at best f <= ftarget (flag 10)",
+            "ftarget": ftarget, "populations": pops, "generations": its, "stop_flag": flags,
             "best_f_at_stop": fbest, "generations_median": float(np.median(its)),
             "all_stopped": bool(launched < cap), "wall_s": dt}
 
@@ -312,33 +349,75 @@ def cpu_baseline(wl, budget_s=12.0):
                 gens, a, n, lam, wl["objective"], dt, note)}
 
 
-def bench_bipop(args, world, rank, local_rank, use_dist):
-    """C5: concurrent BIPOP over the ranks.  value = objective evaluations of ALL restarts of
-    ALL ranks per second of wall time (max over ranks); no single-kernel roofline applies (a
-    restart is a whole CMA-ES run, dominated by the n = 256 eigensolver at small lambda)."""
-    import bboptpy_amd as bb
+def bipop_leg(bb, world, rank, local_rank, use_dist, budget_per_rank, barrier=None):
+    """concurrent BIPOP-CMA-ES n = 256 Rastrigin over `world` ranks (C5): rounds of one restart
+    per GPU, one RCCL all-gather of (n + 7) doubles per round.  Returns on every rank
+    (evaluations of all ranks, seconds = max over ranks, driver state)."""
     from bboptpy_amd.distributed import ConcurrentBiPop
     n = 256
     lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
     guess = np.random.default_rng(7).uniform(-5.12, 5.12, n)
-    budget = max(1, args.steps) * 25000 * world
+    budget = budget_per_rank * world
     drv = ConcurrentBiPop(mfev=budget, tol=1e-8, sigma0=2., seed=2024, device=local_rank,
                           variant="active")
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    drv.optimize(bb.objectives.rastrigin, lo, up, guess)
+    dt = time.perf_counter() - t0
+    if barrier:
+        barrier()
     if use_dist:
         import torch
         import torch.distributed as dist
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sol = drv.optimize(bb.objectives.rastrigin, lo, up, guess)
-    dt = time.perf_counter() - t0
-    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return drv.state, dt, budget
+
+
+def c5_inner_profile(bb, device, lam=20, gens=150):
+    """per-kernel device time of the C5 building block (ActiveCMAES n = 256, lambda = lambda_def)"""
+    n = 256
+    wl = dict(algo="ActiveCMAES", n=n, np=lam, objective="rastrigin", box=(-5.12, 5.12))
+    _, prof, _, _ = measure(bb, wl, 1, gens, 10, 5, device, profile=True)
+    return wl, prof
+
+
+def c5_cpu_baseline(budget_evals=3000):
+    """the reference's BiPopCmaes (or the oracle's restatement of it) on one host core: its
+    first default-lambda run at n = 256 Rastrigin, bounded to `budget_evals` evaluations"""
+    import pyoracle as po
+    lib = po.reference()
+    kind = "reference" if lib is not None else "port"
+    if lib is None:
+        lib = po.oracle()
+    n = 256
+    lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
+    guess = np.random.default_rng(7).uniform(-5.12, 5.12, n)
+    lib.seed(1)
+    h = po.bipop(lib, po.cma(lib, "active", 1, 1e-8, 4), budget_evals)
+    t0 = time.perf_counter()
+    h.init("rastrigin", lo, up, guess)
+    dt = time.perf_counter() - t0
+    fev = h.scalar("fev")
+    return {"value": fev / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
+            "sample": "BiPopCmaes(ActiveCmaes) n=256 rastrigin, first run (lambda=20) capped at "
+                      "%d evaluations, 1 thread, %.1f s" % (budget_evals, dt)}
+
+
+def bench_bipop(args, world, rank, local_rank, use_dist, barrier):
+    """C5: concurrent BIPOP over the ranks.  value = objective evaluations of ALL restarts of
+    ALL ranks per second of wall time (max over ranks).  roofline: the dominant kernel of the
+    inner runs (the n = 256 eigensolver at small lambda: serial latency, far from any roof)."""
+    import bboptpy_amd as bb
+    st, dt, budget = bipop_leg(bb, world, rank, local_rank, use_dist,
+                               max(1, args.steps) * 25000, barrier)
     if rank != 0:
         return
-    st = drv.state
+    wl, prof = c5_inner_profile(bb, local_rank)
+    kernels, roofline = kernel_report(CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], 1), prof,
+                                      "C5", 1)
     out = {
         "metric": "candidate-evals/sec", "value": st.fev / dt, "unit": "candidate-evals/s",
         "n_gpus": world, "steps": st.round, "warmup": 0,
@@ -347,12 +426,66 @@ def bench_bipop(args, world, rank, local_rank, use_dist):
         "config": {"workload": "BIPOP-CMA-ES (ActiveCMAES inner) n=256 rastrigin, %d concurrent "
                                "restart populations (one per GPU), budget %d evaluations"
                                % (world, budget),
-                   "n": n, "objective": "rastrigin", "box": [-5.12, 5.12],
+                   "n": 256, "objective": "rastrigin", "box": [-5.12, 5.12],
                    "rounds": st.round, "large_restarts": st.largerestarts,
                    "small_restarts": st.smallrestarts, "best_f": st.fxbest},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "kernels": kernels,
+        "cpu_baseline": None if args.no_cpu_baseline else c5_cpu_baseline(),
     }
     print(json.dumps(out))
+
+
+def kernel_report(names, costs, prof, workload, P):
+    """per-kernel averages of the profiled pass priced with the algorithmic work per launch ->
+    (kernels{}, roofline of the kernel with the largest time share)"""
+    kernels = {}
+    if prof is not None and names:
+        for i, name in enumerate(names):
+            ms, calls = prof[2 * i], prof[2 * i + 1]
+            if calls <= 0 or name not in costs:
+                continue
+            bound, work = costs[name]
+            avg_s = ms * 1e-3 / calls
+            if work is None:
+                kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
+                                 "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": None}
+                continue
+            if bound == "mfma":
+                ach, peak, unit = work / avg_s / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
+            else:
+                ach, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
+                             "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak}
+        tot = sum(k["share"] for k in kernels.values())
+        for k in kernels.values():
+            k["share"] = k["share"] / tot
+    roofline = None
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["share"])
+        kd = kernels[dom]
+        roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"],
+                    "peak": kd["peak"], "unit": kd["unit"], "frac": kd["frac"],
+                    "traffic": measured_traffic(workload, P, dom),
+                    "avg_us": kd["avg_us"], "time_share": kd["share"]}
+    return kernels, roofline
+
+
+def spawn_ranks(n_gpus):
+    """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree before
+    this process has touched the GPU (never exec after HIP init), pass their output through"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -365,11 +498,15 @@ def main():
                     help="independent populations per GPU (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true",
-                    help="skip the generations-to-tol leg")
+                    help="skip the generations-to-tol legs")
     ap.add_argument("--no-single", action="store_true",
-                    help="skip the single-population leg (profiling runs: keeps rocprofv3's "
+                    help="skip the single-population legs (profiling runs: keeps rocprofv3's "
                          "per-kernel averages to the P-population launches)")
+    ap.add_argument("--no-bipop", action="store_true", help="skip the bipop_scaling leg")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -389,7 +526,7 @@ def main():
     import bboptpy_amd as bb
 
     if args.workload == "C5":
-        bench_bipop(args, world, rank, local_rank, use_dist)
+        bench_bipop(args, world, rank, local_rank, use_dist, barrier)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -397,7 +534,7 @@ def main():
     wl = WORKLOADS[args.workload]
     P = args.populations if args.populations else wl["P"]
     dt, prof, fev_pop, _ = measure(bb, wl, P, args.steps, args.warmup, 1000 + rank, local_rank,
-                                   profile=True, barrier=barrier)
+                                   profile=(rank == 0), barrier=barrier)
     if use_dist:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -406,7 +543,16 @@ def main():
     total_evals = world * P * fev_pop
     value = total_evals / dt
 
-    out = None
+    # BIPOP multi-restart scaling (north_star): a bounded C5 leg at this world size, all ranks
+    bipop = None
+    if args.workload == "M" and not args.no_bipop:
+        st, bdt, budget = bipop_leg(bb, world, rank, local_rank, use_dist, 20000, barrier)
+        bipop = {"workload": "BIPOP-CMA-ES (ActiveCMAES inner) n=256 rastrigin, one concurrent "
+                             "restart population per GPU, %d evaluations per GPU" % 20000,
+                 "n_gpus": world, "value": st.fev / bdt, "unit": "candidate-evals/s",
+                 "wall_s": bdt, "rounds": st.round, "restarts": len(st.history),
+                 "evaluations": st.fev, "best_f": st.fxbest, "scaling": "weak"}
+
     if rank == 0:
         # per-kernel device time (HIP events on the engine's stream) -> roofline
         if wl["algo"] == "ActiveCMAES":
@@ -421,7 +567,6 @@ def main():
             names, costs = CSO_KERNELS, cso_kernel_costs(wl["n"], wl["np"], P)
         elif wl["algo"] == "CCPSO":
             # the candidate count changes with the subset size drawn: no fixed per-launch work;
-            # the evaluation kernel is bound by the objective's arithmetic, not by a roofline
             # ccp_eval is bound by the objective (2 (n/s) np full-dimension evaluations per
             # generation, no matrix instruction, hardly any HBM): the HBM figure -- X and Y read
             # once, the two fitness tables written -- only shows how far from a stream it is
@@ -432,50 +577,30 @@ def main():
             names = CCPSO_KERNELS
         else:
             names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
-        kernels = {}
-        if prof is not None and names:
-            for i, name in enumerate(names):
-                ms, calls = prof[2 * i], prof[2 * i + 1]
-                if calls <= 0:
-                    continue
-                if name not in costs:
-                    continue
-                bound, work = costs[name]
-                avg_s = ms * 1e-3 / calls
-                if work is None:
-                    kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
-                                     "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": None}
-                    continue
-                if bound == "mfma":
-                    ach, peak, unit = work / avg_s / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
-                else:
-                    ach, peak, unit = work / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
-                kernels[name] = {"avg_us": avg_s * 1e6, "share": ms, "bound": bound,
-                                 "achieved": ach, "peak": peak, "unit": unit,
-                                 "frac": ach / peak}
-            tot = sum(k["share"] for k in kernels.values())
-            for k in kernels.values():
-                k["share"] = k["share"] / tot
-        roofline = None
-        if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["share"])
-            kd = kernels[dom]
-            roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"],
-                        "peak": kd["peak"], "unit": kd["unit"], "frac": kd["frac"],
-                        "traffic": measured_traffic(args.workload, P, dom),
-                        "avg_us": kd["avg_us"], "time_share": kd["share"]}
+        kernels, roofline = kernel_report(names, costs, prof, args.workload, P)
         single = None
-        if P != 1 and world == 1 and not args.no_single:
-            s1 = max(10, args.steps // 2)
-            dt1, _, fev1, _ = measure(bb, wl, 1, s1, 5, 77, local_rank, profile=False)
-            single = {"value": fev1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
-                      "unit": "candidate-evals/s"}
-        conv = None
+        singles = None
+        if world == 1 and not args.no_single:
+            if P != 1:
+                s1 = max(10, args.steps // 2)
+                dt1, _, fev1, _ = measure(bb, wl, 1, s1, 5, 77, local_rank, profile=False)
+                single = {"value": fev1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
+                          "unit": "candidate-evals/s"}
+            if args.workload == "M":
+                # one optimisation run at a time (P = 1), the strict reading of each config
+                singles = {"M": single}
+                for key in ("C1", "C3"):
+                    w1 = WORKLOADS[key]
+                    sk = 400 if key == "C1" else max(10, args.steps // 2)
+                    d1, _, f1, _ = measure(bb, w1, 1, sk, 10, 78, local_rank, profile=False)
+                    singles[key] = {"value": f1 / d1, "ms_per_step": 1e3 * d1 / sk,
+                                    "unit": "candidate-evals/s"}
+        conv = ftar = None
         if (world == 1 and wl["algo"] == "ActiveCMAES" and not args.no_convergence
                 and not args.no_single):
             conv = generations_to_tol(bb, wl, local_rank)
             conv["reference"] = REFERENCE_GENERATIONS_TO_TOL.get(args.workload)
+            ftar = generations_to_ftarget(bb, wl, local_rank)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(wl)
@@ -490,7 +615,10 @@ def main():
                        "populations_per_gpu": P, "n": wl["n"], "np": wl["np"],
                        "objective": wl["objective"], "box": list(wl["box"])},
             "single_population": single,
+            "single_population_configs": singles,
             "generations_to_tol": conv,
+            "generations_to_ftarget": ftar,
+            "bipop_scaling": bipop,
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,
