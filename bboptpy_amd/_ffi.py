@@ -91,6 +91,11 @@ def lib():
     L.bbo_cma_set_params.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
     L.bbo_cma_set_seed.argtypes = [C.c_void_p, C.c_uint64]
     L.bbo_cma_evaluate.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_double)]
+    L.bbo_ccpso_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.bbo_ccpso_phase.argtypes = [C.c_void_p, C.c_int]
+    L.bbo_ccpso_table_record.argtypes = [C.c_void_p]
+    L.bbo_ccpso_export_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bbo_ccpso_merge_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.bbo_last_error.argtypes = [C.c_void_p]
     L.bbo_last_error.restype = C.c_char_p
     L.bbo_version.restype = C.c_char_p
@@ -98,7 +103,8 @@ def lib():
     for name in ("bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init", "bbo_iterate",
                  "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
                  "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
-                 "bbo_cma_set_seed", "bbo_cma_evaluate"):
+                 "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_phase",
+                 "bbo_ccpso_table_record", "bbo_ccpso_export_tables", "bbo_ccpso_merge_tables"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -108,7 +114,9 @@ EXPORTED_SYMBOLS = (
     "bbo_params_default", "bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init",
     "bbo_iterate", "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
     "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
-    "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_last_error", "bbo_version",
+    "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_phase",
+    "bbo_ccpso_table_record", "bbo_ccpso_export_tables", "bbo_ccpso_merge_tables",
+    "bbo_last_error", "bbo_version",
     "bbo_device_count",
 )
 

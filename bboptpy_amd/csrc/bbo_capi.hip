@@ -2,6 +2,7 @@
 // Each entry point catches bbo::Error / std::exception and turns it into a status code
 // plus a message retrievable with bbo_last_error(), so no C++ exception crosses the ABI.
 #include "bbo_cma.hpp"
+#include "bbo_ccpso.hpp"
 
 #include <memory>
 #include <mutex>
@@ -307,6 +308,52 @@ int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out)
         if (!x || !f_out) throw bbo::Error(BBO_ERR_ARG, "NULL argument");
         if (cma->dimension() <= 0) throw bbo::Error(BBO_ERR_STATE, "evaluate before initialize()");
         *f_out = cma->evaluate_point(x);
+    });
+}
+
+namespace {
+bbo::CcpsoEngine* as_ccpso(bbo_handle h)
+{
+    auto *e = dynamic_cast<bbo::CcpsoEngine*>(h->opt.get());
+    if (!e) throw bbo::Error(BBO_ERR_ARG, "not a CCPSO handle");
+    return e;
+}
+}
+
+int bbo_ccpso_set_shard(bbo_handle h, int rank, int world)
+{
+    return guarded(h, [&] { as_ccpso(h)->set_shard(rank, world); });
+}
+
+int bbo_ccpso_phase(bbo_handle h, int phase)
+{
+    return guarded(h, [&] { as_ccpso(h)->phase(phase); });
+}
+
+int bbo_ccpso_table_record(bbo_handle h)
+{
+    if (!h || !h->opt) return BBO_ERR_ARG;
+    try {
+        return as_ccpso(h)->table_record();
+    } catch (const bbo::Error &e) {
+        h->error = e.what();
+        return e.status;
+    }
+}
+
+int bbo_ccpso_export_tables(bbo_handle h, double *dst, int device_memory)
+{
+    return guarded(h, [&] {
+        if (!dst) throw bbo::Error(BBO_ERR_ARG, "NULL destination");
+        as_ccpso(h)->export_tables(dst, device_memory != 0);
+    });
+}
+
+int bbo_ccpso_merge_tables(bbo_handle h, const double *gathered, int world, int device_memory)
+{
+    return guarded(h, [&] {
+        if (!gathered) throw bbo::Error(BBO_ERR_ARG, "NULL source");
+        as_ccpso(h)->merge_tables(gathered, world, device_memory != 0);
     });
 }
 

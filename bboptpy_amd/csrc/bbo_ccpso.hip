@@ -47,6 +47,8 @@ void CcpsoEngine::init(int n, const double *lower, const double *upper, const do
     const int P = params_.populations;
     CcpConst &c = c_;
     c = CcpConst {};
+    c.shard_rank = shard_rank_;
+    c.shard_world = shard_world_;
     c.n = n;
     c.ld = round_up(n, 2);
     c.np = params_.np;
@@ -146,7 +148,9 @@ void CcpsoEngine::host_eval_candidates()
         yhat_.download(yh.data(), c.ld, (size_t) p * c.ld);
         range_.download(rg.data(), c.n, (size_t) p * c.n);
         std::vector<double> fx((size_t) nswarm * c.np), fy(fx.size());
-        for (int j = 0; j < nswarm; j++)
+        const int j0 = (int) ((long) nswarm * c.shard_rank / c.shard_world);
+        const int j1 = (int) ((long) nswarm * (c.shard_rank + 1) / c.shard_world);
+        for (int j = j0; j < j1; j++)      // (all swarms unless the groups are sharded over ranks)
             for (int i = 0; i < c.np; i++)
                 for (int which = 0; which < 2; which++) {
                     work = yh;
@@ -182,10 +186,9 @@ void CcpsoEngine::host_eval_yhat()
     if (touched) scal_.upload(sc.data(), c.npop);
 }
 
-void CcpsoEngine::generation(bool honor_stop)
+void CcpsoEngine::launch_regroup_eval()
 {
     CcpConst &c = c_;
-    c.honor_stop = honor_stop ? 1 : 0;
     const int P = c.npop;
     timer_.begin(stream_, K_REGROUP);
     hipLaunchKernelGGL(ccp_regroup, dim3(P), dim3(256), 0, stream_, d_, c_);
@@ -208,6 +211,14 @@ void CcpsoEngine::generation(bool honor_stop)
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
+}
+
+void CcpsoEngine::launch_rest()
+{
+    CcpConst &c = c_;
+    const int P = c.npop;
+    int cpmin = c.pps[0];
+    for (int k = 1; k < c.npps; k++) cpmin = std::min(cpmin, c.pps[k]);
     timer_.begin(stream_, K_UPDATE);
     hipLaunchKernelGGL(ccp_update, dim3(c.n / cpmin, P), dim3(256), 0, stream_, d_, c_);
     if (!obj_.on_device()) host_eval_yhat();
@@ -225,6 +236,72 @@ void CcpsoEngine::generation(bool honor_stop)
     hipLaunchKernelGGL(ccp_finish, dim3(P), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
+}
+
+void CcpsoEngine::generation(bool honor_stop)
+{
+    c_.honor_stop = honor_stop ? 1 : 0;
+    launch_regroup_eval();
+    launch_rest();
+}
+
+// ---- swarm groups sharded over ranks ---------------------------------------------------
+void CcpsoEngine::set_shard(int rank, int world)
+{
+    BBO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "shard: need 0 <= rank < world");
+    BBO_REQUIRE(params_.populations == 1 || world == 1,
+            "sharded swarm groups work on one population");
+    c_.shard_rank = rank;
+    c_.shard_world = world;
+    shard_rank_ = rank;
+    shard_world_ = world;
+}
+
+void CcpsoEngine::phase(int which)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "phase before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    c_.honor_stop = 0;
+    if (which == 0) launch_regroup_eval();
+    else if (which == 1) launch_rest();
+    else throw Error(BBO_ERR_ARG, "unknown CCPSO phase");
+    BBO_HIP(hipStreamSynchronize(stream_));
+    timer_.collect();
+}
+
+int CcpsoEngine::table_record() const
+{
+    return 2 * c_.n * c_.np;      // fX | fY at full capacity (n swarms of one coordinate)
+}
+
+void CcpsoEngine::export_tables(double *dst, bool device_memory)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "export_tables before initialize()");
+    BBO_HIP(hipSetDevice(params_.device));
+    const size_t cap = (size_t) c_.n * c_.np;
+    const hipMemcpyKind kind = device_memory ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    BBO_HIP(hipMemcpyAsync(dst, fX_.p, cap * sizeof(double), kind, stream_));
+    BBO_HIP(hipMemcpyAsync(dst + cap, fY_.p, cap * sizeof(double), kind, stream_));
+    BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+void CcpsoEngine::merge_tables(const double *gathered, int world, bool device_memory)
+{
+    if (!inited_) throw Error(BBO_ERR_STATE, "merge_tables before initialize()");
+    BBO_REQUIRE(world == c_.shard_world, "merge_tables: world differs from the shard setting");
+    BBO_HIP(hipSetDevice(params_.device));
+    const int cap = c_.n * c_.np;
+    const double *src = gathered;
+    if (!device_memory) {
+        const size_t cnt = (size_t) world * 2 * cap;
+        if (gather_.count != cnt) gather_.alloc(cnt);
+        gather_.upload(gathered, cnt);
+        src = gather_.p;
+    }
+    hipLaunchKernelGGL(ccp_merge, dim3((cap + 255) / 256), dim3(256), 0, stream_, d_, c_, src,
+            world, cap);
+    BBO_HIP(hipGetLastError());
+    BBO_HIP(hipStreamSynchronize(stream_));
 }
 
 void CcpsoEngine::iterate()

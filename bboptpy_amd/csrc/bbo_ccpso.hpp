@@ -24,6 +24,9 @@ struct CcpConst {
     int pps[16];
     double stol, phat0;
     uint64_t seed;
+    // swarm groups sharded over ranks: this handle evaluates the swarms
+    // [nswarm * shard_rank / shard_world, nswarm * (shard_rank + 1) / shard_world)
+    int shard_rank, shard_world;
 };
 
 struct CcpDev {
@@ -52,7 +55,16 @@ public:
     int set(const std::string &key, int population, const double *in, int count) override;
     int dimension() const override { return c_.n; }
 
+    // ---- swarm groups sharded over GPUs (one population; bbo_ccpso_* of the C ABI) ----------
+    void set_shard(int rank, int world);
+    void phase(int which);                 // 0: regroup + evaluate this rank's swarms, 1: the rest
+    int table_record() const;              // doubles in one rank's record: fX | fY, full capacity
+    void export_tables(double *dst, bool device_memory);
+    void merge_tables(const double *gathered, int world, bool device_memory);
+
 private:
+    void launch_regroup_eval();
+    void launch_rest();
     void generation(bool honor_stop);
     void host_eval_candidates();
     void host_eval_yhat();
@@ -64,8 +76,9 @@ private:
     CcpDev d_ {};
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
+    int shard_rank_ = 0, shard_world_ = 1;     // survive init() (c_ is rebuilt there)
     std::vector<double> aux_h_;
-    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, lower_, upper_, aux_;
+    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, lower_, upper_, aux_, gather_;
     DevBuf<int> ibest_, strat_, range_, grp_of_;
     DevBuf<CcpScal> scal_;
     KernelTimer timer_;

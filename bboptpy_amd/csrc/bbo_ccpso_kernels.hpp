@@ -152,7 +152,12 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
     const int cand = blockIdx.x * R + r, ld = c.ld, np = c.np;
     const int nswarm = sc->nswarm, cp = sc->cpswarm;
     if (blockIdx.x * R >= 2 * nswarm * np) return;   // the grid is sized for the smallest subset size
-    const bool live = cand < 2 * nswarm * np;
+    // swarm groups sharded over ranks: candidates are swarm-major, so this rank's swarms
+    // [nswarm r / W, nswarm (r + 1) / W) are one contiguous candidate range
+    const int clo = 2 * np * (int) ((long) nswarm * c.shard_rank / c.shard_world);
+    const int chi = 2 * np * (int) ((long) nswarm * (c.shard_rank + 1) / c.shard_world);
+    if ((int) (blockIdx.x * R + R) <= clo || (int) (blockIdx.x * R) >= chi) return;
+    const bool live = cand >= clo && cand < chi;
     double *row = lds + (size_t) r * ld;
     const int which = cand & 1, t = cand >> 1;
     const int i = live ? t % np : 0, j = live ? t / np : 0;
@@ -173,6 +178,25 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
         if (f != f) f = CCP_INF;
         if (live && g == 0) (which ? d.fY : d.fX)[(size_t) p * c.n * np + (size_t) j * np + i] = f;
     }
+}
+
+// sharded swarm groups: record r of `gathered` (fX | fY of rank r, `cap` doubles each) holds the
+// fitness of the swarms rank r evaluated; take every swarm's rows from its owner.
+// grid (ceil(n * np / 256)), 256 threads; population 0 only
+__global__ __launch_bounds__(256) void ccp_merge(CcpDev d, CcpConst c, const double *gathered,
+        int world, int cap)
+{
+    const CcpScal *sc = d.scal;
+    const int q = blockIdx.x * 256 + threadIdx.x, np = c.np, nswarm = sc->nswarm;
+    if (q >= nswarm * np) return;
+    const int j = q / np;
+    int owner = 0;
+    for (int r = 0; r < world; r++)
+        if (j >= (int) ((long) nswarm * r / world) && j < (int) ((long) nswarm * (r + 1) / world))
+            owner = r;
+    const double *rec = gathered + (size_t) owner * 2 * cap;
+    d.fX[q] = rec[q];
+    d.fY[q] = rec[cap + q];
 }
 
 // one workgroup per swarm j: personal bests, the swarm's contribution to yhat, ring local bests.

@@ -1,4 +1,8 @@
-"""Concurrent BIPOP-CMA-ES across the GPUs of one node (one process per GPU).
+"""The two multi-GPU paths of the hot path (one process per GPU): concurrent BIPOP-CMA-ES
+restarts (ConcurrentBiPop) and CCPSO with its swarm groups sharded over the ranks (ShardedCCPSO,
+at the end of this file).
+
+Concurrent BIPOP-CMA-ES across the GPUs of one node.
 
 The reference's BiPopCmaes (src/multivariate/cma/bipop_cmaes.cpp:109-267) is strictly
 sequential: each regime decision depends on the budgets every earlier restart used.  This
@@ -269,3 +273,120 @@ class ConcurrentBiPop:
                 r[7:] = x
             records.append(r)
         return records
+
+
+class ShardedCCPSO:
+    """CCPSO2 (CCPSOSearch, src/multivariate/pso/ccpso.cpp) with the swarm groups of ONE swarm
+    population sharded over the ranks -- the "multi-swarm variant" of SURVEY.md section 8e/8f-4.
+
+    What is sharded: the 2 (n/s) np context-vector evaluations of a generation
+    (updateSwarm, ccpso.cpp:241-260, each a full n-dimensional objective call through
+    evaluate :152-171) -- they are independent while yhat is frozen, and they are where a
+    generation's time goes.  Rank r evaluates the swarms [nswarm r / W, nswarm (r + 1) / W).
+    What is exchanged: ONE all-gather per generation of the fitness records (fX | fY: 2 n np
+    doubles per rank; RCCL over xGMI with backend "nccl", gloo in the CPU tests).  Everything
+    else -- regrouping, personal / swarm / local bests, the move of yhat and its re-evaluation,
+    the Cauchy rate, the position update, the stop test -- is replicated: every rank holds the
+    whole state, draws the same Philox numbers (same seed everywhere) and applies the same
+    update to the same merged tables, so no broadcast is needed and the result is bit-identical
+    to the unsharded optimizer's for every world size.
+
+    Constructor arguments are CCPSO's (py/multivariate_py.cpp:291-295; no `local` optimizer).
+    `engine_factory()` replaces the device engine in the CPU tests (any object with
+    set_shard / initialize / phase / table_record / export_tables / merge_tables / get_state).
+    Without a process group, `world_size` > 1 runs all ranks in this process one after the other
+    (the serial stand-in for the collective: same plan, same merge)."""
+
+    def __init__(self, mfev, sigmatol, np, pps, npps=None, correct=True, pcauchy=-1., seed=0,
+                 device=None, group=None, engine_factory=None, world_size=None, rank=None):
+        self.mfev = int(mfev)
+        self._ctor = dict(mfev=mfev, sigmatol=sigmatol, np=np, pps=pps, npps=npps,
+                          correct=correct, pcauchy=pcauchy)
+        self.seed, self.device, self.group = int(seed) & _M64, device, group
+        self._factory = engine_factory
+        self._world, self._rank = world_size, rank
+        self._engines = None
+
+    def _make_engine(self):
+        if self._factory is not None:
+            return self._factory()
+        from .multivariate import CCPSO
+        return CCPSO(seed=self.seed, device=self.device or 0, **self._ctor)
+
+    def _topology(self):
+        import os
+        import sys
+        if self._world is not None:
+            return self._world, (self._rank or 0), None
+        if "torch" not in sys.modules and "RANK" not in os.environ:
+            return 1, 0, None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_world_size(self.group), dist.get_rank(self.group), dist
+        except ImportError:
+            pass
+        return 1, 0, None
+
+    def initialize(self, f, lower, upper, guess=None):
+        self.world, self.rank, self._dist = self._topology()
+        lower = _np.ascontiguousarray(lower, dtype=_np.float64)
+        upper = _np.ascontiguousarray(upper, dtype=_np.float64)
+        guess = _np.zeros(lower.size) if guess is None else guess    # (the reference ignores it)
+        serial = self._dist is None and self.world > 1
+        ranks = range(self.world) if serial else (self.rank,)
+        self._engines = []
+        for r in ranks:
+            e = self._make_engine()
+            e.set_shard(r, self.world)
+            e.initialize(f, lower, upper, guess)
+            self._engines.append(e)
+        self._buf = None
+
+    def iterate(self):
+        W = self.world
+        for e in self._engines:
+            e.phase(0)
+        if W == 1:
+            pass                                  # one rank evaluated every swarm: nothing to merge
+        elif self._dist is None:                  # serial stand-in: all ranks live in this process
+            gathered = _np.stack([e.export_tables() for e in self._engines])
+            for e in self._engines:
+                e.merge_tables(gathered, W)
+        else:
+            import torch
+            dist, e = self._dist, self._engines[0]
+            reclen = e.table_record()
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            if self._buf is None:
+                dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu"
+                self._buf = (torch.zeros(reclen, dtype=torch.float64, device=dev),
+                             torch.zeros(W * reclen, dtype=torch.float64, device=dev))
+            mine, allrec = self._buf
+            if on_gpu:                            # device to device: the record never visits the host
+                e.export_tables(device_ptr=mine.data_ptr())
+                dist.all_gather_into_tensor(allrec, mine, group=self.group)
+                torch.cuda.current_stream().synchronize()
+                e.merge_tables(world=W, device_ptr=allrec.data_ptr())
+            else:
+                e.export_tables(out=mine.numpy())
+                dist.all_gather(list(allrec.view(W, reclen).unbind(0)), mine, group=self.group)
+                e.merge_tables(allrec.numpy(), W)
+        for e in self._engines:
+            e.phase(1)
+
+    def get_state(self, key):
+        return self._engines[0].get_state(key)
+
+    def optimize(self, f, lower, upper, guess=None):
+        self.initialize(f, lower, upper, guess)
+        while True:                               # ccpso.cpp:135-148
+            self.iterate()
+            if int(self.get_state("fev")[0]) >= self.mfev:
+                converged = False
+                break
+            if int(self.get_state("conv")[0]):
+                converged = True
+                break
+        return MultivariateSolution(self.get_state("yhat"), int(self.get_state("fev")[0]),
+                                    converged)

@@ -475,6 +475,39 @@ class CCPSO(MultivariateSearch):
         self._nlocal = 0
         self._local_seed0 = getattr(getattr(local, "_params", None), "seed", 0)
 
+    # ---- swarm groups sharded over GPUs (bboptpy_amd.distributed.ShardedCCPSO) ---------------
+    def set_shard(self, rank, world):
+        """this object evaluates the swarms [nswarm rank / world, nswarm (rank + 1) / world)"""
+        self._check(_ffi.lib().bbo_ccpso_set_shard(self._ensure_handle(), int(rank), int(world)))
+
+    def phase(self, which):
+        """0: regroup + evaluate this rank's swarms; 1: the rest of the generation"""
+        self._check(_ffi.lib().bbo_ccpso_phase(self._handle, int(which)))
+
+    def table_record(self):
+        return self._check(_ffi.lib().bbo_ccpso_table_record(self._handle))
+
+    def export_tables(self, out=None, device_ptr=None):
+        """this rank's fitness record (fX | fY) into a host array, or to a device pointer"""
+        if device_ptr is not None:
+            self._check(_ffi.lib().bbo_ccpso_export_tables(self._handle, C.c_void_p(device_ptr), 1))
+            return None
+        if out is None:
+            out = _np.zeros(self.table_record())
+        self._check(_ffi.lib().bbo_ccpso_export_tables(self._handle,
+                                                       out.ctypes.data_as(C.c_void_p), 0))
+        return out
+
+    def merge_tables(self, gathered=None, world=1, device_ptr=None):
+        """every swarm's rows from the record of the rank that evaluated it"""
+        if device_ptr is not None:
+            self._check(_ffi.lib().bbo_ccpso_merge_tables(self._handle, C.c_void_p(device_ptr),
+                                                          int(world), 1))
+            return
+        g = _np.ascontiguousarray(gathered, dtype=_np.float64)
+        self._check(_ffi.lib().bbo_ccpso_merge_tables(self._handle, g.ctypes.data_as(C.c_void_p),
+                                                      int(world), 0))
+
     # ---- the reference's loop with the local search between generations ------------------
     def initialize(self, f, lower, upper, guess):
         super().initialize(f, lower, upper, guess)

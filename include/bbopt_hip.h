@@ -237,6 +237,22 @@ int bbo_cma_set_seed(bbo_handle h, uint64_t seed);
  * returned (`_f._f(&x[0])`, bipop_cmaes.cpp:86,223,254; ipop_cmaes.cpp:95,143). */
 int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out);
 
+/* ---- CCPSO swarm groups sharded over GPUs (extension) --------------
+ * The 2 (n/s) np context-vector evaluations of a CCPSO generation (CCPSOSearch::updateSwarm,
+ * ccpso.cpp:241-260, each through evaluate :152-171) are independent while yhat is frozen.
+ * With bbo_ccpso_set_shard(rank, world) a handle evaluates only its block of swarms,
+ *   [nswarm * rank / world, nswarm * (rank + 1) / world),
+ * and a generation becomes: phase 0 (regroup + evaluate this block) on every rank, ONE
+ * all-gather of the fitness records, bbo_ccpso_merge_tables, phase 1 (the rest of updateSwarm,
+ * updatePosition, the stop test: replicated, identical on every rank).  A record is
+ * bbo_ccpso_table_record(h) doubles (fX | fY at full capacity); `device_memory` != 0 says the
+ * caller's pointer is device memory (e.g. an RCCL buffer), else host memory.  One population. */
+int bbo_ccpso_set_shard(bbo_handle h, int rank, int world);
+int bbo_ccpso_phase(bbo_handle h, int phase);
+int bbo_ccpso_table_record(bbo_handle h);
+int bbo_ccpso_export_tables(bbo_handle h, double *dst, int device_memory);
+int bbo_ccpso_merge_tables(bbo_handle h, const double *gathered, int world, int device_memory);
+
 const char *bbo_last_error(bbo_handle h);   /* h may be NULL: last creation error */
 const char *bbo_version(void);
 int bbo_device_count(void);

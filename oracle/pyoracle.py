@@ -106,6 +106,17 @@ class _Lib:
             if hasattr(L, p + "ccpso_set_local"):
                 f("ccpso_set_local").restype = None
                 f("ccpso_set_local").argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+            if hasattr(L, p + "ccpso_phase"):
+                f("ccpso_set_shard").restype = None
+                f("ccpso_set_shard").argtypes = [C.c_void_p, C.c_int, C.c_int]
+                f("ccpso_phase").restype = None
+                f("ccpso_phase").argtypes = [C.c_void_p, C.c_int]
+                f("ccpso_table_record").restype = C.c_int
+                f("ccpso_table_record").argtypes = [C.c_void_p]
+                f("ccpso_export_tables").restype = None
+                f("ccpso_export_tables").argtypes = [C.c_void_p, _dp]
+                f("ccpso_merge_tables").restype = None
+                f("ccpso_merge_tables").argtypes = [C.c_void_p, _dp, C.c_int]
             if hasattr(L, p + "ccpso_local_fresh"):
                 f("ccpso_local_fresh").restype = None
                 f("ccpso_local_fresh").argtypes = [C.c_void_p, C.c_int]

@@ -92,3 +92,26 @@ def test_gloo_world2_matches_the_serial_reduction(tmp_path):
     serial = drive(world=2, rank=0)      # same plan, slots run one after the other
     assert json.loads(json.dumps(serial)) == r0
     assert r0["rounds"] >= 2 and len(r0["history"]) > r0["rounds"]   # two runs per round
+
+
+# ---- CCPSO swarm groups sharded over ranks (bboptpy_amd.distributed.ShardedCCPSO) ---------------
+def test_sharded_ccpso_serial_collective_equals_unsharded():
+    """W = 1, 2, 3 ranks in one process (the serial stand-in for the all-gather), the oracle as
+    the engine: state after every generation bit-identical to the unsharded optimizer's"""
+    from _ccpso_worker import drive as cdrive, unsharded
+    want = unsharded()
+    for world in (1, 2, 3):
+        assert cdrive(world=world, rank=0) == want, world
+
+
+def test_sharded_ccpso_gloo_world2_equals_unsharded(tmp_path):
+    from _ccpso_worker import unsharded
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "_ccpso_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=os.path.dirname(HERE))
+    r0 = json.load(open(tmp_path / "ccpso_rank0.json"))
+    r1 = json.load(open(tmp_path / "ccpso_rank1.json"))
+    assert r0 == r1                      # replicated state: every rank holds the same swarm
+    assert r0 == unsharded()             # and it is the unsharded optimizer's, bit for bit

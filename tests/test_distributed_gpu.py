@@ -94,3 +94,66 @@ def test_world2_n256_bookkeeping_equals_the_plan(hip):
     assert st.fxbest == min(h["fx"] for h in st.history)
     assert hip.objectives.sphere(sol.x) == pytest.approx(st.fxbest, rel=1e-9)
     assert len(st.history) >= 4 and st.largerestarts == 2
+
+
+# ---- CCPSO swarm groups sharded over ranks ------------------------------------------------------
+@pytest.mark.parametrize("n,npp,pps,obj", [(24, 12, [2, 4, 6], "rosenbrock"),
+                                           (1000, 30, [2, 5, 10, 50, 100, 250], "rosenbrock"),
+                                           (300, 20, [3, 10, 50], "rastrigin")])
+def test_sharded_ccpso_on_device_equals_unsharded(hip, n, npp, pps, obj):
+    """W = 2 and W = 3 ranks as W engines on this one GPU (the serial stand-in for the
+    all-gather: export_tables / merge_tables through host memory), every rank evaluating only
+    its block of swarms (ccp_eval's candidate range): after every generation the state is
+    bit-identical to the unsharded CCPSO's -- who evaluates a candidate does not change its f"""
+    from bboptpy_amd.distributed import ShardedCCPSO
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    gens = 8
+    ref = hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=npp, pps=pps, seed=5)
+    ref.initialize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
+    want = []
+    for _ in range(gens):
+        ref.iterate()
+        want.append((ref.get_state("fyhat")[0], int(ref.get_state("fev")[0]),
+                     int(ref.get_state("nswarm")[0]), ref.get_state("yhat").copy(),
+                     ref.get_state("x").copy(), ref.get_state("y").copy()))
+    for world in (2, 3):
+        d = ShardedCCPSO(10 ** 8, 1e-12, npp, pps, seed=5, world_size=world, rank=0)
+        d.initialize(getattr(hip.objectives, obj), lo, up)
+        for g in range(gens):
+            d.iterate()
+            for e in d._engines:                      # every rank: the same replicated state
+                assert e.get_state("fyhat")[0] == want[g][0]
+                assert int(e.get_state("fev")[0]) == want[g][1]
+                assert int(e.get_state("nswarm")[0]) == want[g][2]
+                np.testing.assert_array_equal(e.get_state("yhat"), want[g][3])
+                np.testing.assert_array_equal(e.get_state("x"), want[g][4])
+                np.testing.assert_array_equal(e.get_state("y"), want[g][5])
+
+
+def test_sharded_ccpso_host_objective_splits_the_calls(hip):
+    """a Python objective: each of the W ranks calls it only for its own swarms' candidates
+    (plus the replicated yhat re-evaluation), and the optimum found is the unsharded one's"""
+    n, npp, pps = 12, 8, [2, 3]
+    lo, up = -3. * np.ones(n), 3. * np.ones(n)
+    calls = []
+
+    def f(x):
+        calls.append(1)
+        return float(np.sum((x - 0.25) ** 2))
+
+    from bboptpy_amd.distributed import ShardedCCPSO
+    ref = hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=npp, pps=pps, seed=9)
+    ref.initialize(f, lo, up, np.zeros(n))
+    for _ in range(5):
+        ref.iterate()
+    single_calls = len(calls)
+    calls.clear()
+    d = ShardedCCPSO(10 ** 8, 1e-12, npp, pps, seed=9, world_size=2, rank=0)
+    d.initialize(f, lo, up)
+    for _ in range(5):
+        d.iterate()
+    np.testing.assert_array_equal(d.get_state("yhat"), ref.get_state("yhat"))
+    assert int(d.get_state("fev")[0]) == int(ref.get_state("fev")[0])
+    # both ranks together: the candidate evaluations ONCE (split over the ranks); only the
+    # initial swarm (np calls) and the yhat re-evaluations (at most one per generation) twice
+    assert single_calls < len(calls) <= single_calls + npp + 5
