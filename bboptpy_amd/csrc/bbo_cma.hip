@@ -540,8 +540,39 @@ void CmaEngine::host_evaluate()
     f_.upload(fh.data(), rows);
 }
 
+// n <= 16, lambda <= 64, on-device objective: whole generations in one launch
+// (cma_small_generations).  The per-kernel timers and the diagnostic bit 64 keep the nine-kernel
+// path, which computes the same bits.
+bool CmaEngine::small_fused_ok() const
+{
+    const CmaConst &c = c_;
+    return c.variant != 2 && c.ld == 16 && c.n >= 2 && c.lambda_pad <= 64 && obj_.on_device()
+            && c.npop <= SMALL_FUSED_MAXP && !timer_.on() && !(d_.dbg & (16 | 64));
+}
+
+void CmaEngine::launch_small(int gens, bool honor_stop)
+{
+    c_.honor_stop = honor_stop ? 1 : 0;
+    c_.use_zn = c_.bound ? 0 : 1;          // cma_sample_eval64 always hands down ||z||^2
+    const int ldy = gram_ldy(c_.ld);
+    size_t lds = gram_lds_bytes(c_.ld, c_.rps);
+    lds = std::max(lds, (size_t) 64 * (c_.ld + 2) * sizeof(double));
+    lds = std::max(lds, (size_t) (16 * (c_.ld + 2) + 64) * sizeof(double));
+    const int scratch = (int) ((lds + 15) / 16 * 2);                 // doubles, 16-byte aligned
+    const size_t total = ((size_t) scratch + small_state_doubles(c_)) * sizeof(double);
+    allow_lds((const void*) cma_small_generations, 120 * 1024);
+    BBO_REQUIRE(total <= 120 * 1024, "small fused path: state does not fit LDS");
+    hipLaunchKernelGGL(cma_small_generations, dim3(c_.npop), dim3(256), total, stream_, d_, c_,
+            gens, ldy, scratch);
+    BBO_HIP(hipGetLastError());
+}
+
 void CmaEngine::generation(bool honor_stop)
 {
+    if (small_fused_ok()) {
+        launch_small(1, honor_stop);
+        return;
+    }
     c_.honor_stop = honor_stop ? 1 : 0;
     launch_sample_eval();
     if (!obj_.on_device()) host_evaluate();
@@ -631,7 +662,9 @@ int CmaEngine::run(int max_generations)
     while (done < max_generations) {
         if (all_stopped()) break;
         const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
-        for (int g = 0; g < chunk; g++) generation(true);
+        if (small_fused_ok()) launch_small(chunk, true);
+        else
+            for (int g = 0; g < chunk; g++) generation(true);
         BBO_HIP(hipStreamSynchronize(stream_));
         timer_.collect();
         done += chunk;

@@ -104,6 +104,8 @@ public:
 
 private:
     void generation(bool honor_stop);
+    bool small_fused_ok() const;
+    void launch_small(int gens, bool honor_stop);
     void launch_sample_eval();
     void launch_post(int mode);
     void launch_rank();

@@ -36,6 +36,15 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
+// hand-over point between the lanes of ONE wavefront (single-wavefront bodies: the hardware
+// keeps a wavefront's memory operations in order, the fence stops the compiler from moving
+// loads across the point)
+__device__ inline void cma_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ inline bool pop_frozen(const CmaConst &c, const CmaScal *sc)
 {
     return c.honor_stop && sc->stop != 0;
@@ -165,12 +174,12 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
 // per 16.  grid (ceil(lambda_pad/64), P), 256 threads; dynamic LDS 64*(ld+2) doubles
 // ---------------------------------------------------------------------------
 template<int MAXT, int KSM = 32>     // KSM: k-steps held (ld <= 4 KSM); 8 keeps ld <= 32 lean in registers
-__global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
+__device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaConst &c, int p, int bx,
+        double *lds, int psub)      // psub: the population's Philox sub-stream (= p unless d is a local view)
 {
-    const int p = blockIdx.y, row0 = blockIdx.x * 64;
+    const int row0 = bx * 64;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c.ld, ldz = ld + 2;
     const int gen = sc->it;
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
     normal_table_fill(ntab, tid, 256);
     __syncthreads();
     const int nquads = ld >> 2;
-    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) psub);
     for (int qi = tid; qi < 64 * nquads; qi += 256) {
         const int r = qi / nquads, q = qi - r * nquads;
         double z[4];
@@ -267,6 +276,13 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
             }
         }
     }
+}
+
+template<int MAXT, int KSM = 32>
+__global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sample_eval64_body<MAXT, KSM>(d, c, blockIdx.y, blockIdx.x, lds, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -433,10 +449,8 @@ __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int 
 // the same ranking for lambda <= 64: one WAVEFRONT per population, the bitonic network entirely
 // in registers and lane exchanges (no LDS, no barrier); four populations per workgroup.
 // grid (ceil(P / 4)), 256 threads
-__global__ __launch_bounds__(256) void cma_rank_wave(CmaDev d, CmaConst c)
+__device__ __forceinline__ void rank_wave_body(const CmaDev &d, const CmaConst &c, int p, int lane)
 {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (p >= c.npop) return;
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     const double *f = d.f + (size_t) p * c.lambda_pad;
@@ -465,17 +479,23 @@ __global__ __launch_bounds__(256) void cma_rank_wave(CmaDev d, CmaConst c)
     if (lane == 0) sc->fev += L;   // base_cmaes.cpp:218
 }
 
+__global__ __launch_bounds__(256) void cma_rank_wave(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= c.npop) return;
+    rank_wave_body(d, c, p, lane);
+}
+
 // ---------------------------------------------------------------------------
 // whiten: S[r] = || C^-1/2 (x_{(lambda-mu+r):lambda} - xold) ||^2 for the worst mu
 // grid (mu_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles + 64
 // ---------------------------------------------------------------------------
 template<int MAXT>
-__global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
+__device__ __forceinline__ void whiten_body(const CmaDev &d, const CmaConst &c, int p, int mt,
+        double *lds)
 {
-    const int p = blockIdx.y, mt = blockIdx.x;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c.ld, ldz = ld + 2;
     if (c.use_zn && sc->basis_ok) {
@@ -549,6 +569,13 @@ __global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
             d.S[(size_t) p * c.mu_pad + wr] = part[tid] + part[16 + tid] + part[32 + tid]
                     + part[48 + tid];
     }
+}
+
+template<int MAXT>
+__global__ __launch_bounds__(256) void cma_whiten(CmaDev d, CmaConst c)
+{
+    extern __shared__ double lds[];
+    whiten_body<MAXT>(d, c, blockIdx.y, blockIdx.x, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -671,12 +698,11 @@ __device__ inline void tri_tile(int q, int &ti, int &tj)
 
 constexpr int GRAM_TPW = 9;   // lower 16x16 tiles per wavefront (36 per workgroup)
 
-__global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
+__device__ __forceinline__ void gram_body(const CmaDev &d, const CmaConst &c, int p, int s, int tg,
+        int ldy, double *lds)
 {
-    const int p = blockIdx.z, s = blockIdx.x, tg = blockIdx.y;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c.ld, rps = c.rps;
     double *Y = lds;                 // [rps][ldy]   y = (x - xold) / sigma
@@ -774,6 +800,12 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    gram_body(d, c, blockIdx.z, blockIdx.x, blockIdx.y, ldy, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -957,9 +989,8 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
 // ---------------------------------------------------------------------------
 // paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
+__device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, int p)
 {
-    const int p = blockIdx.x;
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     __shared__ double dm[512];
@@ -1032,18 +1063,22 @@ __global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
     }
 }
 
+__global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
+{
+    paths_body(d, c, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------
 // cov: C <- decay * C + c1 (pc pc^T + c2 C) + sum of the Gram slabs   (lower half,
 // mirrored).  grid (ceil(n*(n+1)/2 / 256), P), 256 threads.
 // NB launched BEFORE cma_paths commits the new sigma? No: the slabs already hold
 // y = (x - xold)/sigma_old, and this kernel reads only pc and hsig.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cma_cov(CmaDev d, CmaConst c)
+__device__ __forceinline__ void cov_body(const CmaDev &d, const CmaConst &c, int p, int bx)
 {
-    const int p = blockIdx.y;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int q = bx * 256 + threadIdx.x;
     const int total = c.n * (c.n + 1) / 2;
     if (q >= total) return;
     int i, j;
@@ -1062,6 +1097,11 @@ __global__ __launch_bounds__(256) void cma_cov(CmaDev d, CmaConst c)
     sum += g;
     C[(size_t) i * ld + j] = sum;
     C[(size_t) j * ld + i] = sum;
+}
+
+__global__ __launch_bounds__(256) void cma_cov(CmaDev d, CmaConst c)
+{
+    cov_body(d, c, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1264,12 +1304,11 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
 // history + stop tests (base_cmaes.cpp:191-209, :155 it++, cmaes.cpp:151-227)
 // one workgroup of 64 threads per population
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
+__device__ __forceinline__ void history_stop_body(const CmaDev &d, const CmaConst &c, int p, int lane)
 {
-    const int p = blockIdx.x;
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
-    const int lane = threadIdx.x, ld = c.ld, n = c.n;
+    const int ld = c.ld, n = c.n;
     double *hb = d.hist_best + (size_t) p * c.hlen, *hk = d.hist_kth + (size_t) p * c.hlen;
     const double *f = d.f + (size_t) p * c.lambda_pad;
     const int *order = d.order + (size_t) p * c.lambda_pad;
@@ -1284,7 +1323,7 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
             hk[head] = f[order[c.ik]];
         }
         if (len < c.hlen) len++;
-        __syncthreads();
+        cma_wave_sync();
         if (len == c.hlen) {
             double lo = BBO_INF, hi = -BBO_INF;
             for (int k = lane; k < c.hlen; k += 64) {
@@ -1301,7 +1340,7 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
         }
     }
     it++;
-    __syncthreads();
+    cma_wave_sync();
 
     const double sigma = sc->sigma;
     const double *pc = d.pc + (size_t) p * ld, *xm = d.xmean + (size_t) p * ld;
@@ -1368,6 +1407,236 @@ __global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
         if (flag) sc->stop = 1;
         else if (sc->fev >= c.mfev) sc->stop = 2;
     }
+}
+
+__global__ __launch_bounds__(64) void cma_history_stop(CmaDev d, CmaConst c)
+{
+    history_stop_body(d, c, blockIdx.x, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Small problems (n <= 16, lambda <= 64; the README example is n = 10, lambda = 20): `gens` whole
+// generations in ONE launch, the population's whole state resident in LDS.
+//
+// A generation of such a problem is nine launches of a few microseconds of work each, and what
+// each of them waits for is not the launch but its own dependent global-memory round trips
+// (1-2 us each; measured: running the nine bodies inside one kernel on the HBM-resident state
+// gained 7 %).  So one 256-thread workgroup per population copies the state into LDS, builds a
+// LOCAL VIEW of it -- a CmaDev whose pointers are LDS addresses, laid out like population 0 --
+// and runs the bodies of the kernels above on that view, back to back, a barrier where the
+// kernel sequence has a kernel boundary: the same code, the same arithmetic, bit for bit (the
+// bodies dereference generic pointers).  The state returns to HBM once, at the end of the launch.
+// What is left of a generation is the serial chain of the 10 x 10 eigendecomposition.
+// Used for up to SMALL_FUSED_MAXP populations (beyond, the kernel sequence fills the GPU better).
+// grid (P), 256 threads, dynamic LDS = scratch of the largest body + small_state_doubles().
+// ---------------------------------------------------------------------------
+constexpr int SMALL_FUSED_MAXP = 512;
+
+__host__ __device__ inline int small_state_doubles(const CmaConst &c)
+{
+    const int ld = c.ld, ld2 = ld * ld, lp = c.lambda_pad;
+    return lp * ld                      // X
+            + 2 * lp + lp               // f, zn2, rank + order (ints, two per double)
+            + 5 * ld                    // xmean, xold, pc, ps, D
+            + 5 * ld2                   // C, B, isc, BDp, ISp
+            + c.mu_pad                  // S
+            + c.splits * ld2 + c.splits * ld    // gram_part, mean_part
+            + 2 * ((c.hlen + 1) & ~1)   // history rings (kept 16-byte aligned)
+            + c.mu_pad                  // weights
+            + 3 * ld                    // lower, upper, aux
+            + 16;                       // CmaScal
+}
+
+__device__ inline void small_phase_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+}
+
+// The phases as real (not inlined) functions: each gets its own register allocation.  Inlined
+// into one kernel the nine bodies needed 256 VGPRs + 110 AGPRs and spilled ~500 SGPRs.
+#define SMALL_NOINLINE __device__ __attribute__((noinline))
+// (the scratch is named inside each function, not passed in: through a pointer argument the
+// compiler loses the address space and turns every ds_read into a flat load -- the serial QL chain
+// of the eigensolver ran 1.5x slower that way)
+SMALL_NOINLINE void small_sample(const CmaDev &v, const CmaConst &c, int bx, int psub)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sample_eval64_body<1, 8>(v, c, 0, bx, lds, psub);
+}
+SMALL_NOINLINE void small_rank(const CmaDev &v, const CmaConst &c, int lane) { rank_wave_body(v, c, 0, lane); }
+SMALL_NOINLINE void small_whiten(const CmaDev &v, const CmaConst &c, int mt)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    whiten_body<1>(v, c, 0, mt, lds);
+}
+SMALL_NOINLINE void small_gram(const CmaDev &v, const CmaConst &c, int s, int ldy)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    gram_body(v, c, 0, s, 0, ldy, lds);
+}
+SMALL_NOINLINE void small_paths(const CmaDev &v, const CmaConst &c) { paths_body(v, c, 0); }
+SMALL_NOINLINE void small_cov(const CmaDev &v, const CmaConst &c) { cov_body(v, c, 0, 0); }
+SMALL_NOINLINE void small_eigen(const CmaDev &v, const CmaConst &c, int lane)
+{
+    __shared__ __attribute__((aligned(16))) double eig_lds[EIGS_DOUBLES];
+    eigen_small_body(v, c, 0, lane, eig_lds, 0, 1);
+}
+SMALL_NOINLINE void small_stop(const CmaDev &v, const CmaConst &c, int lane) { history_stop_body(v, c, 0, lane); }
+#undef SMALL_NOINLINE
+
+__device__ inline void small_copy(double *dst, const double *src, int count, int tid)
+{
+    for (int i = tid; i < count; i += 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void cma_small_generations(CmaDev d, CmaConst c_arg, int gens,
+        int gram_ldy, int scratch_doubles)
+{
+    __shared__ CmaConst cs;                 // (by reference to the phase functions)
+    if (threadIdx.x == 0) cs = c_arg;
+    __syncthreads();
+    const CmaConst &c = cs;
+    const int p = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (pop_frozen(c, d.scal + p)) return;       // nothing to do: leave the state where it is
+    const int ld = c.ld, ld2 = ld * ld, lp = c.lambda_pad;
+    static_assert(sizeof(CmaScal) <= 16 * sizeof(double), "CmaScal outgrew its LDS slot");
+
+    // ---- the local view: population p's state in LDS, addressed like population 0.  The view
+    // itself lives in LDS too: thirty pointers held in scalar registers next to the kernel's own
+    // arguments made the compiler spill ~500 of them (readlane / writelane on every use)
+    __shared__ CmaDev vs;
+    if (tid == 0) {
+        CmaDev t = d;
+        double *q = lds + scratch_doubles;
+        t.X = q; q += lp * ld;
+        t.f = q; q += lp;
+        t.zn2 = q; q += lp;
+        t.rank = reinterpret_cast<int*>(q);
+        t.order = t.rank + lp; q += lp;
+        t.xmean = q; q += ld;
+        t.xold = q; q += ld;
+        t.pc = q; q += ld;
+        t.ps = q; q += ld;
+        t.D = q; q += ld;
+        t.C = q; q += ld2;
+        t.B = q; q += ld2;
+        t.isc = q; q += ld2;
+        t.BDp = q; q += ld2;
+        t.ISp = q; q += ld2;
+        t.S = q; q += c.mu_pad;
+        t.gram_part = q; q += c.splits * ld2;
+        t.mean_part = q; q += c.splits * ld;
+        t.hist_best = q; q += (c.hlen + 1) & ~1;
+        t.hist_kth = q; q += (c.hlen + 1) & ~1;
+        t.weights = q; q += c.mu_pad;
+        t.lower = q; q += ld;
+        t.upper = q; q += ld;
+        t.aux = q; q += ld;
+        t.scal = reinterpret_cast<CmaScal*>(q);
+        if (d.zinject) t.zinject = d.zinject + (size_t) p * c.lambda * c.n;
+        if (d.zrecord) t.zrecord = d.zrecord + (size_t) p * c.lambda * c.n;
+        vs = t;
+    }
+    __syncthreads();
+    const CmaDev &v = vs;
+    double *wl = const_cast<double*>(v.weights), *lo = const_cast<double*>(v.lower);
+    double *up = const_cast<double*>(v.upper), *ax = const_cast<double*>(v.aux);
+
+    small_copy(v.xmean, d.xmean + (size_t) p * ld, ld, tid);
+    small_copy(v.xold, d.xold + (size_t) p * ld, ld, tid);
+    small_copy(v.pc, d.pc + (size_t) p * ld, ld, tid);
+    small_copy(v.ps, d.ps + (size_t) p * ld, ld, tid);
+    small_copy(v.D, d.D + (size_t) p * ld, ld, tid);
+    small_copy(v.C, d.C + (size_t) p * ld2, ld2, tid);
+    small_copy(v.B, d.B + (size_t) p * ld2, ld2, tid);
+    small_copy(v.isc, d.isc + (size_t) p * ld2, ld2, tid);
+    small_copy(v.BDp, d.BDp + (size_t) p * ld2, ld2, tid);
+    small_copy(v.ISp, d.ISp + (size_t) p * ld2, ld2, tid);
+    small_copy(v.hist_best, d.hist_best + (size_t) p * c.hlen, c.hlen, tid);
+    small_copy(v.hist_kth, d.hist_kth + (size_t) p * c.hlen, c.hlen, tid);
+    for (int i = tid; i < c.mu_pad; i += 256) wl[i] = i < c.mu ? d.weights[i] : 0.;
+    small_copy(lo, d.lower, ld, tid);
+    small_copy(up, d.upper, ld, tid);
+    small_copy(ax, d.aux, ld, tid);
+    // (the outputs of a generation that a LATER call may read before it is overwritten)
+    small_copy(v.X, d.X + (size_t) p * lp * ld, lp * ld, tid);
+    small_copy(v.f, d.f + (size_t) p * lp, lp, tid);
+    small_copy(v.zn2, d.zn2 + (size_t) p * lp, lp, tid);
+    small_copy(v.S, d.S + (size_t) p * c.mu_pad, c.mu_pad, tid);
+    for (int i = tid; i < lp; i += 256) {
+        v.rank[i] = d.rank[(size_t) p * lp + i];
+        v.order[i] = d.order[(size_t) p * lp + i];
+    }
+    if (tid == 0) *v.scal = d.scal[p];
+    small_phase_sync();
+
+    const CmaScal *sc = v.scal;
+    // (diagnostic: phase clocks of the last generation, bbo_set "eig_stamps"; 100 MHz)
+#define SMALL_STAMP(slot) do { if (d.stamps && p == 0 && tid == 0) d.stamps[slot] = wall_clock64(); } while (0)
+    for (int g = 0; g < gens; g++) {
+        if (pop_frozen(c, sc)) break;       // (uniform: every thread reads the same LDS word)
+        SMALL_STAMP(16);
+        for (int bx = 0; bx * 64 < lp; bx++) {
+            small_sample(v, c, bx, p);
+            small_phase_sync();
+        }
+        SMALL_STAMP(17);
+        if (wave == 0) small_rank(v, c, lane);
+        small_phase_sync();
+        SMALL_STAMP(18);
+        if (c.variant == 1)
+            for (int mt = 0; mt * 16 < c.mu_pad; mt++) {
+                small_whiten(v, c, mt);
+                small_phase_sync();
+            }
+        SMALL_STAMP(19);
+        for (int s = 0; s < c.splits; s++) {
+            small_gram(v, c, s, gram_ldy);
+            small_phase_sync();
+        }
+        SMALL_STAMP(20);
+        small_paths(v, c);
+        small_phase_sync();
+        SMALL_STAMP(21);
+        small_cov(v, c);                    // n (n + 1) / 2 <= 136 entries: one pass
+        small_phase_sync();
+        SMALL_STAMP(22);
+        if (wave == 0) small_eigen(v, c, lane);
+        small_phase_sync();
+        SMALL_STAMP(23);
+        if (wave == 0) small_stop(v, c, lane);
+        small_phase_sync();
+        SMALL_STAMP(24);
+    }
+#undef SMALL_STAMP
+
+    // ---- back to HBM ---------------------------------------------------------------------------
+    small_copy(d.X + (size_t) p * lp * ld, v.X, lp * ld, tid);
+    small_copy(d.f + (size_t) p * lp, v.f, lp, tid);
+    small_copy(d.zn2 + (size_t) p * lp, v.zn2, lp, tid);
+    for (int i = tid; i < lp; i += 256) {
+        d.rank[(size_t) p * lp + i] = v.rank[i];
+        d.order[(size_t) p * lp + i] = v.order[i];
+    }
+    small_copy(d.xmean + (size_t) p * ld, v.xmean, ld, tid);
+    small_copy(d.xold + (size_t) p * ld, v.xold, ld, tid);
+    small_copy(d.pc + (size_t) p * ld, v.pc, ld, tid);
+    small_copy(d.ps + (size_t) p * ld, v.ps, ld, tid);
+    small_copy(d.D + (size_t) p * ld, v.D, ld, tid);
+    small_copy(d.C + (size_t) p * ld2, v.C, ld2, tid);
+    small_copy(d.B + (size_t) p * ld2, v.B, ld2, tid);
+    small_copy(d.isc + (size_t) p * ld2, v.isc, ld2, tid);
+    small_copy(d.BDp + (size_t) p * ld2, v.BDp, ld2, tid);
+    small_copy(d.ISp + (size_t) p * ld2, v.ISp, ld2, tid);
+    small_copy(d.S + (size_t) p * c.mu_pad, v.S, c.mu_pad, tid);
+    small_copy(d.gram_part + (size_t) p * c.splits * ld2, v.gram_part, c.splits * ld2, tid);
+    small_copy(d.mean_part + (size_t) p * c.splits * ld, v.mean_part, c.splits * ld, tid);
+    small_copy(d.hist_best + (size_t) p * c.hlen, v.hist_best, c.hlen, tid);
+    small_copy(d.hist_kth + (size_t) p * c.hlen, v.hist_kth, c.hlen, tid);
+    if (tid == 0) d.scal[p] = *v.scal;
 }
 
 } // namespace bbo

@@ -945,12 +945,10 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
 constexpr int EIGS_LD = 17;
 constexpr int EIGS_DOUBLES = 2 * 16 * EIGS_LD + 8 * 20 + 272 + 8;
 
-__global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int force, int with_post)
+// one wavefront, one matrix: population p, `A` = EIGS_DOUBLES doubles of LDS owned by the wavefront
+__device__ __forceinline__ void eigen_small_body(const CmaDev &d, const CmaConst &c, int p, int lane,
+        double *A, int force, int with_post)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[4][EIGS_DOUBLES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + wave;
-    if (p >= c.npop) return;
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
     if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
@@ -958,7 +956,8 @@ __global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int
         return;
     }
     const int n = c.n, ld = c.ld;
-    double *A = lds_all[wave];                  // work matrix; row i ends as the reflector u_i
+    if (d.stamps && lane == 0) d.stamps[25] = wall_clock64();      // (diagnostic)
+    // A: work matrix; row i ends as the reflector u_i
     double *Qs = A + 16 * EIGS_LD;              // eigenvectors of T, then B
     double *dv = Qs + 16 * EIGS_LD + 2;         // (front pads: the QL producer prefetches index -1)
     double *ev = dv + 20, *uv = ev + 20, *wv = uv + 20, *hv = wv + 20, *td = hv + 20, *gv = td + 20;
@@ -1026,7 +1025,9 @@ __global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int
     dc_wave_sync();
     // ---- the reference's implicit QL on (td, ev) ----------------------------------------------
     DcMat Qm { Qs, EIGS_LD };
+    if (d.stamps && lane == 0) d.stamps[26] = wall_clock64();
     dc_leaf_ql(Qm, 0, n, td, ev, dv, ws, lane, nullptr);
+    if (d.stamps && lane == 0) d.stamps[27] = wall_clock64();
     // ---- B = H(n-1) ... H(1) Q_T: column j, rows k = q (mod 4) -----------------------------------
     for (int i = 1; i < n; i++) {
         const double h = hv[i];
@@ -1117,6 +1118,16 @@ __global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int
         BDp[qq] = (i < n && jc < n) ? A[i * EIGS_LD + jc] * dv[jc] : 0.;
     }
     if (lane == 0) sc->basis_ok = 1;
+    if (d.stamps && lane == 0) d.stamps[28] = wall_clock64();
+}
+
+__global__ __launch_bounds__(256) void cma_eigen_small(CmaDev d, CmaConst c, int force, int with_post)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[4][EIGS_DOUBLES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= c.npop) return;
+    eigen_small_body(d, c, p, lane, lds_all[wave], force, with_post);
 }
 
 } // namespace bbo

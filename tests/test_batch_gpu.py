@@ -70,3 +70,59 @@ def test_batch_stops_populations_independently(hip):
     assert max(its) <= done
     for p in range(P):
         assert g.solution(p).converged
+
+
+@pytest.mark.parametrize("variant,n,lam,P,bound,obj", [
+    ("active", 10, 20, 1, False, "rosenbrock"),        # C1
+    ("active", 10, 20, 37, False, "rosenbrock"),
+    ("cmaes", 5, 8, 3, False, "sphere"),
+    ("active", 16, 64, 5, True, "rastrigin"),          # the largest fused shape, clamped samples
+    ("cmaes", 2, 6, 2, False, "ellipsoid"),
+    ("active", 13, 33, 4, False, "ackley"),            # ragged lambda (lambda_pad = 48)
+])
+def test_fused_small_generations_equal_the_kernel_sequence(hip, variant, n, lam, P, bound, obj):
+    """n <= 16, lambda <= 64: run() / iterate() execute whole generations in ONE launch
+    (cma_small_generations: the bodies of the nine kernels back to back inside one workgroup per
+    population).  Same code, same arithmetic: the state after 25 generations -- several of them
+    per launch -- is BIT-IDENTICAL to the nine-kernel sequence (diagnostic bit 64 keeps it)."""
+    cls = hip.ActiveCMAES if variant == "active" else hip.CMAES
+    lo, up = -3. * np.ones(n), 3. * np.ones(n)
+    guess = np.random.default_rng(n).uniform(-2, 2, (P, n))
+
+    def make(dbg):
+        g = cls(mfev=10 ** 7, tol=1e-12, np=lam, seed=99, populations=P, bound=bound)
+        g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [float(dbg)])
+        return g
+
+    a, b = make(0), make(64)
+    a.run(13)                  # 8 + 5 generations: two launches
+    b.run(13)
+    for _ in range(12):        # and one generation per launch
+        a.iterate()
+        b.iterate()
+    for p in (0, P // 2, P - 1):
+        for key in ("xmean", "sigma", "pc", "ps", "C", "B", "D", "invsqrtC", "arx", "fitness",
+                    "fit_idx", "it", "fev", "flag", "best_hist", "kth_hist", "fbest", "fworst"):
+            np.testing.assert_array_equal(a.get_state(key, p), b.get_state(key, p), err_msg=key)
+    assert int(a.get_state("it")[0]) == 25
+
+
+def test_fused_small_run_freezes_stopped_populations(hip):
+    """a population that stops inside a multi-generation launch stays exactly at its stopping
+    generation (the in-kernel loop honours the stop flag like the kernel sequence does)"""
+    n, lam, P = 4, 8, 6
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(1).uniform(-3, 3, (P, n))
+    runs = []
+    for dbg in (0, 64):
+        g = hip.ActiveCMAES(mfev=4000, tol=1e-8, np=lam, seed=5, populations=P)
+        g.initialize(hip.objectives.sphere, lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [64.])
+        g.run(10000)
+        runs.append([(g.solution(p).n_evals, g.solution(p).converged, g.solution(p).x.tolist(),
+                      int(g.get_state("it", p)[0])) for p in range(P)])
+    assert runs[0] == runs[1]
+    assert len({r[3] for r in runs[0]}) > 1          # they did stop at different generations

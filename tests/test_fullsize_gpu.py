@@ -1,6 +1,8 @@
-"""GPU, at BASELINE.json's full sizes: the configurations the oracle cannot step through in
-seconds (C2: L-SHADE n = 128, np = 4096; C4: APSO n = 512, np = 65536; M: ActiveCMAES n = 128,
-lambda = 4096) are checked through properties that do not depend on the size:
+"""GPU, at BASELINE.json's full sizes (C2: L-SHADE n = 128, np = 4096; C4: APSO n = 512,
+np = 65536; M: ActiveCMAES n = 128, lambda = 4096): properties that do not depend on the size.
+(The oracle itself follows M, C3 and C2 for a few generations -- ~0.15 s per generation at M --
+and does: tests/test_cma_headline_gpu.py, tests/test_de_gpu.py::test_c2_full_size_*.  Only C4's
+O(np^2 n) reference generation, about half an hour, is out of its reach.)
 
 * the stored fitness IS the objective of the stored position (recomputed on the host),
 * selection never loses ground (sorted fitness / personal bests are element-wise non-increasing),
