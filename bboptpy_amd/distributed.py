@@ -78,19 +78,28 @@ class ConcurrentBiPop:
     is described by `variant` ("active" | "cmaes") and `tol`.  `group` is a torch.distributed
     process group (None = the default group, or no collective at all when torch.distributed is
     not initialised: a single-process run).  `runner(lam, sigma, maxfev, x0, seed) -> (x,
-    evaluations_used, f(x))` replaces the device run in the CPU tests.
+    evaluations_used, f(x))` replaces the device run in the CPU tests.  `slots_per_rank` > 1 packs
+    several concurrent restart populations onto each GPU (a rank's slots of a round run at the same
+    time on separate engines / HIP streams); a round has world_size * slots_per_rank slots and
+    the plan, the seeds and the reduction depend on the global slot only, so (W ranks, S slots)
+    and (W S ranks, 1 slot) produce the same history.
     """
 
     def __init__(self, mfev, tol=1e-8, sigma0=2., maxlargeruns=9, nbipop=True, ksigmadec=1.6,
                  kbudget=2., variant="active", seed=0, device=None, group=None, runner=None,
-                 world_size=None, rank=None):
+                 world_size=None, rank=None, slots_per_rank=1):
         self.mfev, self.tol, self.sigma0 = int(mfev), float(tol), float(sigma0)
         self.maxlargeruns, self.nbipop = int(maxlargeruns), bool(nbipop)
         self.ksigmadec, self.kbudget = float(ksigmadec), float(kbudget)
         self.variant, self.seed = variant, int(seed) & _M64
         self.device, self.group, self.runner = device, group, runner
         self._world, self._rank = world_size, rank
-        self._alg = None
+        # slots_per_rank concurrent restart populations PER GPU (each on its own engine and HIP
+        # stream, driven from its own host thread): a round then has world_size * slots_per_rank
+        # slots.  An inner run at n = 256 keeps ONE compute unit busy most of the time (the
+        # eigensolver is one workgroup), so several of them share a GPU almost for free.
+        self.slots = max(1, int(slots_per_rank))
+        self._algs = {}
 
     # -- topology ---------------------------------------------------------------------------
     def _topology(self):
@@ -201,20 +210,50 @@ class ConcurrentBiPop:
         st.round += 1
 
     # -- one inner run on this rank's GPU -----------------------------------------------------
-    def _device_run(self, f, lam, sigma, maxfev, x0, seed):
+    def _device_run(self, f, lam, sigma, maxfev, x0, seed, slot=0):
         """like the reference's drivers (bipop_cmaes.cpp:83-87): ONE inner optimizer per driver
-        (here: per rank), re-parameterised through setParams before every run -- so B and C
-        keep their off-diagonals from this rank's previous run (cmaes.cpp:53-59) -- and one
+        (here: per slot), re-parameterised through setParams before every run -- so B and C
+        keep their off-diagonals from this slot's previous run (cmaes.cpp:53-59) -- and one
         extra evaluation of the point it returns"""
-        if self._alg is None:
+        if slot not in self._algs:
             cls = ActiveCMAES if self.variant == "active" else CMAES
-            self._alg = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
-                            device=self.device or 0)
-        alg = self._alg
+            self._algs[slot] = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
+                                   device=self.device or 0)
+        alg = self._algs[slot]
         alg.set_params(lam, sigma, maxfev)
         alg.set_seed(seed)
         sol = alg.optimize(f, self.lower, self.upper, x0)
         return sol.x, sol.n_evals, alg.evaluate(sol.x)
+
+    def _run_slots(self, f, slots, st, total, first):
+        """the records of the slots first .. first + len(slots) - 1 of this round.  Device runs
+        of several slots go out concurrently (one host thread each: the C calls release the
+        GIL, every engine has its own HIP stream); a `runner` is called slot after slot."""
+        reclen = 7 + self.n
+
+        def one(k):
+            plan = slots[k]
+            r = _np.zeros(reclen)
+            if plan is None:
+                return r
+            s = first + k
+            seed = (self.seed + _GOLDEN * (st.round * total + s)) & _M64
+            if self.runner is not None:
+                x, used, fx = self.runner(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"],
+                                          seed)
+            else:
+                x, used, fx = self._device_run(f, plan["lam"], plan["sigma"], plan["maxfev"],
+                                               plan["x0"], seed, slot=s)
+            r[:7] = [1., plan["regime"], plan["lam"], plan["sigma"], plan["maxfev"], used, fx]
+            r[7:] = x
+            return r
+
+        live = [k for k in range(len(slots)) if slots[k] is not None]
+        if self.runner is not None or len(live) <= 1:
+            return [one(k) for k in range(len(slots))]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(live)) as pool:
+            return list(pool.map(one, range(len(slots))))
 
     def optimize(self, f, lower, upper, guess):
         self.lower = _np.ascontiguousarray(lower, dtype=_np.float64)
@@ -223,56 +262,34 @@ class ConcurrentBiPop:
         self.n = self.lower.size
         self.lambdadef = 4 + int(3. * math.log(1. * self.n))
         world, rank, dist = self._topology()
+        S = self.slots
+        total = world * S                     # slots of a round
         st = _State()
         self.state = st
         reclen = 7 + self.n
         while True:
-            slots = self.plan_round(st, world)
+            slots = self.plan_round(st, total)
             if all(p is None for p in slots):
                 break
-            mine = slots[rank]
-            rec = _np.zeros(reclen)
-            if mine is not None:
-                seed = (self.seed + _GOLDEN * (st.round * world + rank)) & _M64
-                if self.runner is not None:
-                    x, used, fx = self.runner(mine["lam"], mine["sigma"], mine["maxfev"],
-                                              mine["x0"], seed)
-                else:
-                    x, used, fx = self._device_run(f, mine["lam"], mine["sigma"],
-                                                   mine["maxfev"], mine["x0"], seed)
-                rec[:7] = [1., mine["regime"], mine["lam"], mine["sigma"], mine["maxfev"], used,
-                           fx]
-                rec[7:] = x
             if dist is not None:
                 import torch
+                mine = _np.concatenate(self._run_slots(f, slots[rank * S:(rank + 1) * S], st, total,
+                                                       rank * S))
                 dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
-                mine_t = torch.from_numpy(rec).to(dev)
+                mine_t = torch.from_numpy(mine).to(dev)
                 out = [torch.empty_like(mine_t) for _ in range(world)]
                 dist.all_gather(out, mine_t, group=self.group)
-                records = [t.cpu().numpy() for t in out]
+                records = [r for t in out for r in t.cpu().numpy().reshape(S, reclen)]
             else:
-                records = [rec] if world == 1 else self._serial_records(f, slots, st, world, rec,
-                                                                        rank)
+                # no process group: every rank's slots run in this process, rank after rank (the
+                # serial stand-in for the collective -- same plan, same reduction)
+                records = []
+                for g in range(world):
+                    records += self._run_slots(f, slots[g * S:(g + 1) * S], st, total, g * S)
             self.apply_round(st, slots, records)
             if st.largerestarts >= self.maxlargeruns or st.fev >= self.mfev:
                 break
         return MultivariateSolution(st.xbest, st.fev, False)
-
-    def _serial_records(self, f, slots, st, world, rec, rank):
-        """world_size > 1 without torch.distributed: run every slot in this process (the
-        "fake collective" of SURVEY.md section 4) -- same plan, same reduction"""
-        records = []
-        for s, plan in enumerate(slots):
-            r = _np.zeros(7 + self.n)
-            if plan is not None:
-                seed = (self.seed + _GOLDEN * (st.round * world + s)) & _M64
-                run = self.runner if self.runner is not None else \
-                    (lambda lam, sig, mf, x0, sd: self._device_run(f, lam, sig, mf, x0, sd))
-                x, used, fx = run(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"], seed)
-                r[:7] = [1., plan["regime"], plan["lam"], plan["sigma"], plan["maxfev"], used, fx]
-                r[7:] = x
-            records.append(r)
-        return records
 
 
 class ShardedCCPSO:

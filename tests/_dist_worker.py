@@ -39,12 +39,12 @@ def shared_oracle_runner(lo, up, obj, tol=1e-8):
     return run
 
 
-def drive(world=None, rank=None, mfev=60000, n=5, seed=17, shared=False):
+def drive(world=None, rank=None, mfev=60000, n=5, seed=17, shared=False, slots=1):
     from bboptpy_amd.distributed import ConcurrentBiPop
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     make = shared_oracle_runner if shared else oracle_runner
     d = ConcurrentBiPop(mfev=mfev, seed=seed, runner=make(lo, up, "rastrigin"),
-                        world_size=world, rank=rank)
+                        world_size=world, rank=rank, slots_per_rank=slots)
     sol = d.optimize(None, lo, up, np.random.default_rng(seed).uniform(-5, 5, n))
     st = d.state
     return {"x": [float(v).hex() for v in sol.x], "fev": sol.n_evals, "fxbest": st.fxbest.hex(),

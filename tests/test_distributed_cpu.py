@@ -94,6 +94,16 @@ def test_gloo_world2_matches_the_serial_reduction(tmp_path):
     assert r0["rounds"] >= 2 and len(r0["history"]) > r0["rounds"]   # two runs per round
 
 
+def test_slots_per_rank_is_the_same_plan_as_more_ranks():
+    """(W ranks, S slots each) and (W S ranks, one slot each): the plan, the seeds and the
+    reduction depend on the global slot only, so the histories are identical"""
+    a = drive(world=4, rank=0)
+    b = drive(world=2, rank=0, slots=2)
+    c = drive(world=1, rank=0, slots=4)
+    assert json.loads(json.dumps(a)) == json.loads(json.dumps(b)) == json.loads(json.dumps(c))
+    assert max(h["slot"] for h in a["history"]) >= 2
+
+
 # ---- CCPSO swarm groups sharded over ranks (bboptpy_amd.distributed.ShardedCCPSO) ---------------
 def test_sharded_ccpso_serial_collective_equals_unsharded():
     """W = 1, 2, 3 ranks in one process (the serial stand-in for the all-gather), the oracle as

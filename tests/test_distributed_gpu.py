@@ -157,3 +157,23 @@ def test_sharded_ccpso_host_objective_splits_the_calls(hip):
     # both ranks together: the candidate evaluations ONCE (split over the ranks); only the
     # initial swarm (np calls) and the yhat re-evaluations (at most one per generation) twice
     assert single_calls < len(calls) <= single_calls + npp + 5
+
+
+def test_concurrent_slots_on_one_gpu_equal_the_serial_plan(hip):
+    """slots_per_rank = 4: four restart populations of a round run AT THE SAME TIME on this GPU
+    (four engines, four HIP streams, four host threads inside the C library) -- and produce,
+    bit for bit, the history of the same four slots run one after the other (W = 4 ranks in one
+    process).  Inner runs are deterministic functions of (plan, seed): concurrency must not show."""
+    from bboptpy_amd.distributed import ConcurrentBiPop
+    n, seed, mfev = 24, 9, 120000
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(-5, 5, n)
+    hist = []
+    for kw in (dict(world_size=4, rank=0), dict(world_size=1, rank=0, slots_per_rank=4),
+               dict(world_size=2, rank=0, slots_per_rank=2)):
+        d = ConcurrentBiPop(mfev=mfev, tol=1e-8, seed=seed, **kw)
+        sol = d.optimize(hip.objectives.rastrigin, lo, up, guess)
+        hist.append(([tuple(sorted(h.items())) for h in d.state.history], sol.n_evals,
+                     sol.x.tolist()))
+    assert hist[0] == hist[1] == hist[2]
+    assert max(dict(h)["slot"] for h in hist[0][0]) >= 2      # rounds really had four runs
