@@ -2,6 +2,10 @@
 restarts (ConcurrentBiPop) and CCPSO with its swarm groups sharded over the ranks (ShardedCCPSO,
 at the end of this file).
 
+Import order: with backend "nccl" the collectives run on torch CUDA tensors, and torch brings its
+own HIP runtime, which has to be loaded before libbbopt_hip.so's: `import torch` (or let torchrun's
+RANK variable make bboptpy_amd._ffi do it) before the first optimizer is created.
+
 Concurrent BIPOP-CMA-ES across the GPUs of one node.
 
 The reference's BiPopCmaes (src/multivariate/cma/bipop_cmaes.cpp:109-267) is strictly

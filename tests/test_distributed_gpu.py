@@ -177,3 +177,19 @@ def test_concurrent_slots_on_one_gpu_equal_the_serial_plan(hip):
                      sol.x.tolist()))
     assert hist[0] == hist[1] == hist[2]
     assert max(dict(h)["slot"] for h in hist[0][0]) >= 2      # rounds really had four runs
+
+
+def test_sharded_ccpso_device_pointer_exchange(hip):
+    """the RCCL form of the exchange: records leave and enter the engines through DEVICE pointers
+    (torch CUDA tensors standing in for the all-gather's send / receive buffers), never through
+    host memory -- same merged tables, same state as the unsharded optimizer.  Runs in a child
+    process that imports torch BEFORE the HIP library is loaded, the order every torch.distributed
+    program has (torch bundles its own HIP runtime; loaded second it finds no device)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "_ccpso_devptr_worker.py")],
+                         capture_output=True, text=True, timeout=600, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DEVPTR_OK" in out.stdout
