@@ -661,7 +661,10 @@ int CmaEngine::run(int max_generations)
     }
     while (done < max_generations) {
         if (all_stopped()) break;
-        const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
+        int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
+        // (one launch = `chunk` generations on the fused path: keep a launch to tens of
+        // milliseconds whatever poll_every says)
+        if (small_fused_ok()) chunk = std::min(chunk, 512);
         if (small_fused_ok()) launch_small(chunk, true);
         else
             for (int g = 0; g < chunk; g++) generation(true);
