@@ -344,7 +344,11 @@ void CmaEngine::launch_sample_eval()
         rw = std::max(128, std::min(4096, rw));
         allow_lds((const void*) cma_sample_eval128, 128 * 1024);
         dim3 grid((c.lambda_pad + rw - 1) / rw, c.npop);
-        hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw);
+        // the lean build of the tile loop where nothing needs guarding (M, C3)
+        const int full = (c.n == 128 && !c.bound && c.lambda == c.lambda_pad && !d_.zinject
+                && !d_.zrecord && !(d_.dbg & 256)) ? 1 : 0;
+        hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw,
+                full);
         zn_valid = true;
     } else if (c.ld <= 128) {
         // 64 candidates per workgroup, packed operand held in registers

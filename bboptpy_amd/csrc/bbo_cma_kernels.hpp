@@ -294,12 +294,18 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 // accumulators.  No LDS traffic besides the B fragments, no barrier after the fill.
 // grid (ceil(lambda_pad / rows_per_wg), P), 512 threads, dynamic LDS 128 KB
 // ---------------------------------------------------------------------------
+// FULL: the dimension is exactly 128, no box, lambda a multiple of 16, no injected / recorded
+// normals (the benchmark's M and C3): every bounds test, clamp and per-store branch of the general
+// form is gone at compile time -- ~400 of the ~3100 vector instructions a 16-row tile costs next
+// to its 256 MFMAs, all on the same pipe.  Same arithmetic, same bits.
+template<bool FULL>
 __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, int p, int rowbase,
         double sigma, const d4_t (&acc)[8], int lane)
 {
     const int fr = lane & 15, fk = lane >> 4;
+    const int n = FULL ? 128 : c.n;
     const double *xm = d.xmean + (size_t) p * 128;
-    double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    double *Xp = d.X + (size_t) p * c.lambda_pad * 128 + ((size_t) rowbase + fk) * 128 + fr;
     double x[8][4];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -308,49 +314,40 @@ __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, in
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             double v = 0.;
-            if (col < c.n) {
+            if (FULL) {
+                v = xmc + sigma * acc[t][r];
+            } else if (col < n) {
                 v = xmc + sigma * acc[t][r];
                 if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
             }
             x[t][r] = v;
-            Xp[((size_t) rowbase + fk + 4 * r) * 128 + col] = v;
+            Xp[(size_t) (4 * r) * 128 + t * 16] = v;
         }
     }
     if (c.obj >= 0) {
         double f[4];
-        eval_frag_rows<8>(c.obj, c.n, x, d.aux, lane, f);
+        eval_frag_rows<8>(c.obj, n, x, d.aux, lane, f);
         if (fr == 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int rr = rowbase + fk + 4 * r;
                 double fv = f[r];
-                if (!(rr < c.lambda) || fv != fv) fv = BBO_INF;
+                if ((!FULL && !(rr < c.lambda)) || fv != fv) fv = BBO_INF;
                 d.f[(size_t) p * c.lambda_pad + rr] = fv;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst c, int rows_per_wg)
+template<bool FULL>
+__device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaConst &c,
+        int rows_per_wg, double *bd, const double2 *ntab)
 {
     const int p = blockIdx.y, row0 = blockIdx.x * rows_per_wg;
     const CmaScal *sc = d.scal + p;
-    if (pop_frozen(c, sc)) return;
-    extern __shared__ __attribute__((aligned(16))) double bd[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        const double2 *src = reinterpret_cast<const double2*>(d.BDp + (size_t) p * 128 * 128);
-        double2 *dst = reinterpret_cast<double2*>(bd);
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
-    }
-    __shared__ double2 ntab[NORMAL_TABLE_N];
-    normal_table_fill(ntab, tid, 512);
-    __syncthreads();
-    // (fp64 MFMA and fp64 VALU do not overlap on gfx950 -- measured: draw-only + sweep-only
-    // times add up to the full kernel whatever the wave priorities -- so the draw is priced in
-    // VALU cycles next to the sweep, not hidden behind it.)
-
+    // (fp64 MFMA and vector ALU work of any kind do not overlap on gfx950 -- measured, DESIGN.md
+    // section 3 -- so the draw is priced in VALU cycles next to the sweep, not hidden behind it.)
     const int gen = sc->it;
     const double sigma = sc->sigma;
     const int tiles = min(rows_per_wg, c.lambda_pad - row0) >> 4;
@@ -372,7 +369,11 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 double z[4];
-                cma_draw_quad(d, c, p, row, 4 * (2 * kc + h) + fk, gen, sw, ntab, z);
+                if (FULL)
+                    normal_quad(c.seed, (uint32_t) row, (uint32_t) (4 * (2 * kc + h) + fk),
+                            (uint32_t) gen, sw, ntab, z[0], z[1], z[2], z[3]);
+                else
+                    cma_draw_quad(d, c, p, row, 4 * (2 * kc + h) + fk, gen, sw, ntab, z);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     a[4 * h + i] = z[i];
@@ -392,8 +393,29 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
         zz += __shfl_xor(zz, 16, 64);
         zz += __shfl_xor(zz, 32, 64);
         if (fk == 0) d.zn2[(size_t) p * c.lambda_pad + row] = zz;
-        sample128_epilogue(d, c, p, rowbase, sigma, acc, lane);
+        sample128_epilogue<FULL>(d, c, p, rowbase, sigma, acc, lane);
     }
+}
+
+__global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst c, int rows_per_wg,
+        int full)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (pop_frozen(c, sc)) return;
+    extern __shared__ __attribute__((aligned(16))) double bd[];
+    const int tid = threadIdx.x;
+    {
+        const double2 *src = reinterpret_cast<const double2*>(d.BDp + (size_t) p * 128 * 128);
+        double2 *dst = reinterpret_cast<double2*>(bd);
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
+    }
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    normal_table_fill(ntab, tid, 512);
+    __syncthreads();
+    if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab);
+    else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab);
 }
 
 // ---------------------------------------------------------------------------

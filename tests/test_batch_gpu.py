@@ -126,3 +126,25 @@ def test_fused_small_run_freezes_stopped_populations(hip):
                       int(g.get_state("it", p)[0])) for p in range(P)])
     assert runs[0] == runs[1]
     assert len({r[3] for r in runs[0]}) > 1          # they did stop at different generations
+
+
+@pytest.mark.parametrize("lam,P", [(4096, 8), (1024, 32)])
+def test_lean_sampler_build_equals_the_general_one(hip, lam, P):
+    """cma_sample_eval128 has a lean build of its tile loop for n = 128 exactly, no box, lambda a
+    multiple of 16 (M, C3): no bounds tests, clamps or per-store branches.  Same arithmetic:
+    X, f and everything downstream are BIT-IDENTICAL to the general build (diagnostic bit 256)."""
+    n = 128
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = np.random.default_rng(4).uniform(-10, 10, (P, n))
+    runs = []
+    for dbg in (0, 256):
+        g = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=77, populations=P)
+        g.initialize(hip.objectives.rosenbrock, lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [float(dbg)])
+        g.run(5)
+        runs.append([(g.get_state("arx", p), g.get_state("fitness", p), g.get_state("C", p),
+                      g.get_state("sigma", p)) for p in (0, P - 1)])
+    for a, b in zip(runs[0], runs[1]):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
