@@ -165,8 +165,10 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.rps = 64;
     while (c.rps > 16 && gram_lds_bytes(c.ld, c.rps) > GRAM_LDS_MAX) c.rps >>= 1;
     if (c.ld == 128) {
-        // cma_gram128 streams its slab: size the slabs for ~1024 workgroups over all populations
-        int want = std::max(1, std::min(32, (1024 + P - 1) / P));
+        // cma_gram128 streams its slab: size the slabs for ~512 workgroups over all populations
+        // (two resident per CU: one round; 1024 cost 1 % more in the Gram kernel and a quarter more
+        // in cma_cov, which sums the slabs)
+        int want = std::max(1, std::min(32, (512 + P - 1) / P));
         want = std::min(want, (c.lambda_pad + G128_CH - 1) / G128_CH);
         c.rps = ((c.lambda_pad + want - 1) / want + G128_CH - 1) / G128_CH * G128_CH;
     }

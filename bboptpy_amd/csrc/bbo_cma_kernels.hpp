@@ -933,13 +933,13 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
     const double2 xo01 = *reinterpret_cast<const double2*>(&xold[c4]);
     const double2 xo23 = *reinterpret_cast<const double2*>(&xold[c4 + 2]);
     const bool in0 = c4 < c.n, in1 = c4 + 1 < c.n, in2 = c4 + 2 < c.n, in3 = c4 + 3 < c.n;
-    double2 pf[4][2];
+    double2 pf[G128_CH / 8][2];
     double pv = 0., pw = 0.;
 
     auto fetch = [&](int ch) {
         const int base = row0 + ch * G128_CH;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < G128_CH / 8; i++) {
             const int row = base + r0 + 8 * i;
             const double *src = Xp + (size_t) row * 128 + c4;
             pf[i][0] = pf[i][1] = make_double2(0., 0.);
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
     auto stash = [&](int ch, int buf) {
         const int base = row0 + ch * G128_CH;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < G128_CH / 8; i++) {
             const int r = r0 + 8 * i;
             const bool in = base + r < c.lambda;
             double2 y01, y23;
