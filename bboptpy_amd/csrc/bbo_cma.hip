@@ -322,16 +322,36 @@ void CmaEngine::launch_sample_eval()
     timer_.begin(stream_, K_SAMPLE);
     if (c.variant == 2) {
         // separable: 16 lanes per candidate for short rows, one wavefront per candidate beyond
-        allow_lds((const void*) sep_sample_eval<16>, 128 * 1024);
-        allow_lds((const void*) sep_sample_eval<64>, 128 * 1024);
+        // (a workgroup stages the generator's table once and then walks chunks of candidates:
+        // ~4096 workgroups in all, 16 per CU)
+        const int per_pop = std::max(1, 4096 / c.npop);
         if (c.ld <= 256) {   // (beyond that the 16-row LDS tile would leave one workgroup per CU)
+            allow_lds((const void*) sep_sample_eval<16>, 128 * 1024);
             const size_t lds = (size_t) 16 * c.ld * sizeof(double);
-            hipLaunchKernelGGL(sep_sample_eval<16>, dim3((c.lambda_pad + 15) / 16, c.npop),
-                    dim3(256), lds, stream_, d_, c_);
+            hipLaunchKernelGGL(sep_sample_eval<16>,
+                    dim3(std::min((c.lambda_pad + 15) / 16, per_pop), c.npop), dim3(256), lds,
+                    stream_, d_, c_);
+        } else if (c.ld <= 2048) {
+            // 8 rows per workgroup of 512: rows + table leave room for two workgroups (16
+            // wavefronts) per CU up to ld = 1024
+            const size_t lds = (size_t) 8 * c.ld * sizeof(double);
+            const dim3 grid(std::min((c.lambda_pad + 7) / 8, per_pop), c.npop);
+            if (c.n == c.ld && !c.bound && c.lambda == c.lambda_pad && !d_.zinject
+                    && !d_.zrecord && !(d_.dbg & 256)) {   // nothing to guard (the benchmark's SEP)
+                allow_lds((const void*) sep_sample_eval<64, 512, true>, 140 * 1024);
+                hipLaunchKernelGGL((sep_sample_eval<64, 512, true>), grid, dim3(512), lds,
+                        stream_, d_, c_);
+            } else {
+                allow_lds((const void*) sep_sample_eval<64, 512>, 140 * 1024);
+                hipLaunchKernelGGL((sep_sample_eval<64, 512>), grid, dim3(512), lds, stream_,
+                        d_, c_);
+            }
         } else {
+            allow_lds((const void*) sep_sample_eval<64>, 140 * 1024);
             const size_t lds = (size_t) 4 * c.ld * sizeof(double);
-            hipLaunchKernelGGL(sep_sample_eval<64>, dim3((c.lambda_pad + 3) / 4, c.npop),
-                    dim3(256), lds, stream_, d_, c_);
+            hipLaunchKernelGGL(sep_sample_eval<64>,
+                    dim3(std::min((c.lambda_pad + 3) / 4, per_pop), c.npop), dim3(256), lds,
+                    stream_, d_, c_);
         }
         timer_.end(stream_);
         BBO_HIP(hipGetLastError());

@@ -80,6 +80,51 @@ __device__ inline void cma_draw_quad(const CmaDev &d, const CmaConst &c, int p, 
     }
 }
 
+// The same in two steps (normal_quad_fast / normal_quad_settle): the candidates of call q and
+// the mask of the draws still to settle -- the caller collects the masks of all the calls it
+// holds and settles them together, cma_settle_draw per set bit.
+__device__ inline uint32_t cma_draw_quad_fast(const CmaDev &d, const CmaConst &c, int p, int row,
+        int q, int gen, uint32_t sw, const double2 *tab, double (&z)[4])
+{
+    const int j0 = cma_quad_col0(q);
+    uint32_t pend = 0;
+    z[0] = z[1] = z[2] = z[3] = 0.;
+    if (row < c.lambda && j0 < c.n) {
+        if (d.zinject) {
+            const double *zi = d.zinject + ((size_t) p * c.lambda + row) * c.n;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (j0 + 4 * i < c.n) z[i] = zi[j0 + 4 * i];
+        } else {
+            pend = normal_quad_fast(c.seed, (uint32_t) row, (uint32_t) q, (uint32_t) gen, sw, tab,
+                    z[0], z[1], z[2], z[3]);
+#pragma unroll
+            for (int i = 1; i < 4; i++)
+                if (j0 + 4 * i >= c.n) {
+                    z[i] = 0.;
+                    pend &= ~(1u << i);
+                }
+        }
+        if (d.zrecord) {
+            double *zr = d.zrecord + ((size_t) p * c.lambda + row) * c.n;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (j0 + 4 * i < c.n) zr[j0 + 4 * i] = z[i];
+        }
+    }
+    return pend;
+}
+
+__device__ inline double cma_settle_draw(const CmaDev &d, const CmaConst &c, int p, int row, int q,
+        int slot, int gen, uint32_t sw)
+{
+    const double v = normal_quad_settle(c.seed, (uint32_t) row, (uint32_t) q, (uint32_t) slot,
+            (uint32_t) gen, sw);
+    if (d.zrecord)
+        d.zrecord[((size_t) p * c.lambda + row) * c.n + cma_quad_col0(q) + 4 * slot] = v;
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // sample + evaluate: X = m + sigma * Z (B diag D)^T, f = objective(X)
 // grid (lambda_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles
@@ -101,13 +146,21 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     __syncthreads();
     const int nquads = ld >> 2;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
-    for (int qi = tid; qi < 16 * nquads; qi += 256) {
+    uint64_t pend = 0;                       // 4 bits per call this thread draws (<= 16 calls)
+    for (int qi = tid, it = 0; qi < 16 * nquads; qi += 256, it++) {
         const int r = qi / nquads, q = qi - r * nquads;
         double z[4];
-        cma_draw_quad(d, c, p, mt * 16 + r, q, gen, sw, ntab, z);
+        pend |= (uint64_t) cma_draw_quad_fast(d, c, p, mt * 16 + r, q, gen, sw, ntab, z) << (4 * it);
         const int j0 = cma_quad_col0(q);
 #pragma unroll
         for (int i = 0; i < 4; i++) lds[r * ldz + j0 + 4 * i] = z[i];
+    }
+    while (pend) {
+        const int b = __ffsll((unsigned long long) pend) - 1;
+        pend &= pend - 1;
+        const int qi = tid + 256 * (b >> 2), r = qi / nquads, q = qi - r * nquads;
+        lds[r * ldz + cma_quad_col0(q) + 4 * (b & 3)] =
+                cma_settle_draw(d, c, p, mt * 16 + r, q, b & 3, gen, sw);
     }
     __syncthreads();
 
@@ -175,7 +228,8 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
 // ---------------------------------------------------------------------------
 template<int MAXT, int KSM = 32>     // KSM: k-steps held (ld <= 4 KSM); 8 keeps ld <= 32 lean in registers
 __device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaConst &c, int p, int bx,
-        double *lds, int psub)      // psub: the population's Philox sub-stream (= p unless d is a local view)
+        double *lds, int psub,      // psub: the population's Philox sub-stream (= p unless d is a local view)
+        bool stage_table = true)    // false: an earlier call of this workgroup staged the generator's table
 {
     const int row0 = bx * 64;
     const CmaScal *sc = d.scal + p;
@@ -198,17 +252,27 @@ __device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaCon
 
     // standard normals of the 64 candidates (four per Philox call)
     __shared__ double2 ntab[NORMAL_TABLE_N];
-    normal_table_fill(ntab, tid, 256);
-    __syncthreads();
+    if (stage_table) {
+        normal_table_fill(ntab, tid, 256);
+        __syncthreads();
+    }
     const int nquads = ld >> 2;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) psub);
-    for (int qi = tid; qi < 64 * nquads; qi += 256) {
+    uint32_t pend = 0;                       // 4 bits per call this thread draws (<= 8 calls)
+    for (int qi = tid, it = 0; qi < 64 * nquads; qi += 256, it++) {
         const int r = qi / nquads, q = qi - r * nquads;
         double z[4];
-        cma_draw_quad(d, c, p, row0 + r, q, gen, sw, ntab, z);
+        pend |= cma_draw_quad_fast(d, c, p, row0 + r, q, gen, sw, ntab, z) << (4 * it);
         const int j0 = cma_quad_col0(q);
 #pragma unroll
         for (int i = 0; i < 4; i++) lds[r * ldz + j0 + 4 * i] = z[i];
+    }
+    while (pend) {
+        const int b = __ffs(pend) - 1;
+        pend &= pend - 1;
+        const int qi = tid + 256 * (b >> 2), r = qi / nquads, q = qi - r * nquads;
+        lds[r * ldz + cma_quad_col0(q) + 4 * (b & 3)] =
+                cma_settle_draw(d, c, p, row0 + r, q, b & 3, gen, sw);
     }
     __syncthreads();
 
@@ -361,32 +425,61 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
         double zz = 0.;
-        // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk] (two Philox calls),
-        // then sweep them
-#pragma unroll 1
-        for (int kc = 0; kc < 4; kc++) {
-            double a[8];
+        if (FULL) {
+            // the 32 normals this lane feeds: z[4 q + i] = Z[row][16 q + fk + 4 i], i.e. the A
+            // elements of k-steps 4 q .. 4 q + 3; candidates first, the unsettled draws of all
+            // eight calls together afterwards (normal_quad_fast)
+            double z[32];
+            uint32_t pend = 0;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                double z[4];
-                if (FULL)
-                    normal_quad(c.seed, (uint32_t) row, (uint32_t) (4 * (2 * kc + h) + fk),
-                            (uint32_t) gen, sw, ntab, z[0], z[1], z[2], z[3]);
-                else
-                    cma_draw_quad(d, c, p, row, 4 * (2 * kc + h) + fk, gen, sw, ntab, z);
+            for (int q = 0; q < 8; q++)
+                pend |= normal_quad_fast(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk),
+                        (uint32_t) gen, sw, ntab, z[4 * q], z[4 * q + 1], z[4 * q + 2],
+                        z[4 * q + 3]) << (4 * q);
+            while (pend) {
+                const int b = __ffs(pend) - 1;
+                pend &= pend - 1;
+                const double v = normal_quad_settle(c.seed, (uint32_t) row,
+                        (uint32_t) (4 * (b >> 2) + fk), (uint32_t) (b & 3), (uint32_t) gen, sw);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    a[4 * h + i] = z[i];
-                    zz = __builtin_fma(z[i], z[i], zz);
-                }
+                for (int i = 0; i < 32; i++) z[i] = (i == b) ? v : z[i];
             }
-            const double *bk = bd + kc * 8 * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 32; i++) zz = __builtin_fma(z[i], z[i], zz);
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const double *bk = bd + (i >> 3) * 8 * 64 + lane;
 #pragma unroll
                 for (int t = 0; t < 8; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bk[(t * 32 + i) * 64],
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[i], bk[(t * 32 + (i & 7)) * 64],
                             acc[t], 0, 0, 0);
+                // (keeps the scheduler from hoisting the operand loads of all 32 k-steps at once)
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk] (two Philox calls),
+            // then sweep them
+#pragma unroll 1
+            for (int kc = 0; kc < 4; kc++) {
+                double a[8];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double z[4];
+                    cma_draw_quad(d, c, p, row, 4 * (2 * kc + h) + fk, gen, sw, ntab, z);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        a[4 * h + i] = z[i];
+                        zz = __builtin_fma(z[i], z[i], zz);
+                    }
+                }
+                const double *bk = bd + kc * 8 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bk[(t * 32 + i) * 64],
+                                acc[t], 0, 0, 0);
+                }
             }
         }
         // ||z||^2 of the row: the four k-groups of a row sit 16 lanes apart
@@ -1481,10 +1574,10 @@ __device__ inline void small_phase_sync()
 // (the scratch is named inside each function, not passed in: through a pointer argument the
 // compiler loses the address space and turns every ds_read into a flat load -- the serial QL chain
 // of the eigensolver ran 1.5x slower that way)
-SMALL_NOINLINE void small_sample(const CmaDev &v, const CmaConst &c, int bx, int psub)
+SMALL_NOINLINE void small_sample(const CmaDev &v, const CmaConst &c, int bx, int psub, bool first)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    sample_eval64_body<1, 8>(v, c, 0, bx, lds, psub);
+    sample_eval64_body<1, 8>(v, c, 0, bx, lds, psub, first);
 }
 SMALL_NOINLINE void small_rank(const CmaDev &v, const CmaConst &c, int lane) { rank_wave_body(v, c, 0, lane); }
 SMALL_NOINLINE void small_whiten(const CmaDev &v, const CmaConst &c, int mt)
@@ -1602,7 +1695,7 @@ __global__ __launch_bounds__(256) void cma_small_generations(CmaDev d, CmaConst 
         if (pop_frozen(c, sc)) break;       // (uniform: every thread reads the same LDS word)
         SMALL_STAMP(16);
         for (int bx = 0; bx * 64 < lp; bx++) {
-            small_sample(v, c, bx, p);
+            small_sample(v, c, bx, p, g == 0 && bx == 0);   // (the table stays for the launch)
             small_phase_sync();
         }
         SMALL_STAMP(17);

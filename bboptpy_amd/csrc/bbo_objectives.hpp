@@ -88,10 +88,19 @@ __device__ inline double group_prod(double v)
 // x: the candidate (LDS or global), n coordinates; aux: per-coordinate constants
 // (see bbo_objective_aux in oracle/objectives.h -- the host fills the same table);
 // g: this lane's index inside its group.  Every lane of the group returns f.
-template<int G>
-__device__ inline double eval_row_group(int obj, int n, const double *x, const double *aux,
+// SWZ: the row is stored at row_swizzle(j) instead of j (an LDS row written four columns apart
+// per lane, see sep_sample_eval).
+__host__ __device__ inline int row_swizzle(int j) { return j ^ (((j >> 4) & 3) << 2); }
+
+template<int G, bool SWZ = false>
+__device__ inline double eval_row_group(int obj, int n, const double *xrow, const double *aux,
         int g)
 {
+    struct Row {
+        const double *p;
+        __device__ double operator[](int j) const { return p[SWZ ? row_swizzle(j) : j]; }
+    };
+    const Row x { xrow };
     double a = 0., b = 0.;
     switch (obj) {
     case OBJ_SPHERE:

@@ -154,92 +154,146 @@ __device__ inline void normal_pair(uint64_t seed, uint32_t c0, uint32_t c1, uint
 }
 
 // ---------------------------------------------------------------------------
-// normal_quad: the samplers' generator -- ONE Philox call -> FOUR standard normals (two
-// Box-Muller pairs from 32 + 32 bits each), about half the instructions of two normal_pair
-// calls.  Per pair:
-//   radius  r = sqrt(-2 ln u), u = (a + 1) 2^-32 in (0, 1]      (|z| <= 6.66)
-//           -2 ln u from a 91-entry table in LDS (bbo_normal_table.inc; bin width 1/128 on
-//           m in [0.70703125, 1.4140625), centre 1 exactly in bin 37) and a degree-8
-//           polynomial in r = m inv_i - 1, |r| < 2^-7.5: no division
-//   angle   x = (k + 1/2) (pi/4) 2^-29 in (0, pi/4) from 29 bits, fdlibm kernels, and three
-//           more bits pick one of the 8 symmetries of the square (swap, -sin, -cos): a
-//           uniform direction without the octant bookkeeping
-// Only +, *, fma, frexp/ldexp, sqrt: oracle/philox.h (bbo_normal_quad) gets the same bits.
+// normal_quad: the CMA samplers' generator -- ONE Philox call -> FOUR standard normals by the
+// Marsaglia-Tsang ZIGGURAT (1024 strips of exp(-x^2 / 2); tables: scripts/gen_ziggurat_table.py).
+// On gfx950 the fp64 matrix instruction shares the one vector pipe with everything else (no
+// overlap), so a sampler is paid per vector instruction: a Box-Muller pair
+// costs ~70 of them beyond Philox (logarithm, root, sine and cosine), a ziggurat normal 8.
+// A 32-bit word w is one draw: strip i = w & 1023, t = (w >> 10) | 1 (an odd 22-bit integer: the
+// position inside the strip, never 0), sign = bit 10:
+//     z = +/- t W[i];   t < K[i]: the point lies under the curve for sure -- 99.57 % of the draws
+// The rest (zig_slow) takes fresh Philox words at counters no first draw uses (c1 = q | (slot + 1)
+// << 12 | attempt << 16): in the base strip the tail beyond r = 4.04 by Marsaglia's -ln(u)/r
+// method, in the others the wedge test f(x_i) + U (f(x_{i+1}) - f(x_i)) < exp(-x^2 / 2) and, on
+// rejection, a fresh draw.  Exact normal, unbounded tails (the Box-Muller pair of round 1 stopped
+// at 6.66 sigma), 32 bits of entropy per normal as before.  Only integer operations, +, *, fma,
+// ldexp and conversions: oracle/philox.h (bbo_normal_quad) states the same arithmetic on the CPU
+// and gets the same bits, slow paths included.
 // ---------------------------------------------------------------------------
-static __device__ const double NORMAL_TABLE[91][2] = {
-#include "bbo_normal_table.inc"
-};
-constexpr int NORMAL_TABLE_N = 91;
+#include "bbo_zig_table.inc"
+struct alignas(16) ZigStrip { double w, kbits; };   // W[i]; K[i] in the low word of kbits
+static __device__ const ZigStrip ZIG_WK[BBO_ZIG_N] = BBO_ZIG_TABLE_WK;
+static __device__ const double ZIG_F[BBO_ZIG_N + 1] = BBO_ZIG_TABLE_F;
+constexpr int NORMAL_TABLE_N = BBO_ZIG_N;           // LDS copy of ZIG_WK (16 KB)
 
-// cooperative copy of the table into LDS (caller synchronises)
+// cooperative copy of the fast-path table into LDS (caller synchronises)
 __device__ inline void normal_table_fill(double2 *tab, int tid, int nthreads)
 {
-    for (int i = tid; i < NORMAL_TABLE_N; i += nthreads)
-        tab[i] = make_double2(NORMAL_TABLE[i][0], NORMAL_TABLE[i][1]);
+    const double2 *src = reinterpret_cast<const double2*>(ZIG_WK);
+    for (int i = tid; i < NORMAL_TABLE_N; i += nthreads) tab[i] = src[i];
 }
+__device__ inline double zig_w(uint32_t i) { return ZIG_WK[i].w; }
+__device__ inline uint32_t zig_k(uint32_t i) { return (uint32_t) __double_as_longlong(ZIG_WK[i].kbits); }
 
-// -2 ln((a + 1) 2^-32)
-__device__ inline double neg2log32(uint32_t a, const double2 *tab)
+// exp(-s) for s in [0, 700]: s = k ln 2 + r, |r| <= 0.35, Taylor to the 13th power (oracle twin:
+// bbo_exp_neg)
+__device__ inline double exp_neg(double s)
 {
-    const double d = (double) a + 1.;                       // 1 .. 2^32, exact
-    double m = __builtin_amdgcn_frexp_mant(d);              // [1/2, 1)
-    int e = __builtin_amdgcn_frexp_exp(d);                  // d = m 2^e
-    const int s = m < 0.70703125 ? 1 : 0;
-    m = __builtin_amdgcn_ldexp(m, s);                       // [0.70703125, 1.4140625)
-    e -= s;
-    const int i = (int) __builtin_fma(m, 128., -90.5);      // exact; floor
-    const double2 ent = tab[i];
-    const double r = __builtin_fma(m, ent.x, -1.);
-    double p = 2. / 8.;
-    p = __builtin_fma(p, r, -2. / 7.);
-    p = __builtin_fma(p, r, 2. / 6.);
-    p = __builtin_fma(p, r, -2. / 5.);
-    p = __builtin_fma(p, r, 2. / 4.);
-    p = __builtin_fma(p, r, -2. / 3.);
-    p = __builtin_fma(p, r, 1.);
-    p = __builtin_fma(p, r, -2.);
-    const double base = __builtin_fma((double) (32 - e), 0x1.62e42fefa39efp+0, ent.y);
-    return __builtin_fma(p, r, base);
+    const int k = (int) __builtin_fma(s, 0x1.71547652b82fep+0, 0.5);
+    const double dk = (double) k;
+    double r = __builtin_fma(-dk, 0x1.62e42fefa3800p-1, s);
+    r = __builtin_fma(-dk, 0x1.ef35793c76730p-45, r);
+    const double y = -r;
+    double p = 0x1.6124613a86d09p-33;               // 1/13!
+    p = __builtin_fma(p, y, 0x1.1eed8eff8d898p-29); // 1/12!
+    p = __builtin_fma(p, y, 0x1.ae64567f544e4p-26); // 1/11!
+    p = __builtin_fma(p, y, 0x1.27e4fb7789f5cp-22); // 1/10!
+    p = __builtin_fma(p, y, 0x1.71de3a556c734p-19); // 1/9!
+    p = __builtin_fma(p, y, 0x1.a01a01a01a01ap-16); // 1/8!
+    p = __builtin_fma(p, y, 0x1.a01a01a01a01ap-13); // 1/7!
+    p = __builtin_fma(p, y, 0x1.6c16c16c16c17p-10); // 1/6!
+    p = __builtin_fma(p, y, 0x1.1111111111111p-7);  // 1/5!
+    p = __builtin_fma(p, y, 0x1.5555555555555p-5);  // 1/4!
+    p = __builtin_fma(p, y, 0x1.5555555555555p-3);  // 1/3!
+    p = __builtin_fma(p, y, 0.5);
+    p = __builtin_fma(p, y, 1.);
+    p = __builtin_fma(p, y, 1.);
+    return __builtin_amdgcn_ldexp(p, -k);
 }
 
-// (sin, cos) of a uniform direction from 32 bits
-__device__ inline void sincos_oct(uint32_t b, double &sn, double &cs)
+// the 0.43 % of the draws the fast test does not settle (see above); slot = which of the four
+// words of Philox call c1 this draw was
+__device__ inline double zig_slow(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t slot,
+        uint32_t c2, uint32_t c3, uint32_t idx, uint32_t t, uint32_t sign)
 {
-    const double x = __builtin_fma((double) (b >> 3), 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);
-    const double z = x * x;
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
-    const double sx = __builtin_fma(x * z, ps, x);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
-    const double cx = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.));
-    const bool sw = (b & 1u) != 0;
-    const double s0 = sw ? cx : sx, c0 = sw ? sx : cx;
-    sn = __longlong_as_double(__double_as_longlong(s0) ^ ((long long) (b & 2u) << 62));
-    cs = __longlong_as_double(__double_as_longlong(c0) ^ ((long long) (b & 4u) << 61));
+    for (uint32_t attempt = 0;; attempt++) {
+        const u32x4 w = philox4x32_10(seed, c0, c1 | ((slot + 1u) << 12) | (attempt << 16), c2, c3);
+        if (idx == 0) {
+            const double xx = -log_unit(u01_open0(w.x, w.y)) * BBO_ZIG_INV_R;
+            const double yy = -log_unit(u01_open0(w.z, w.w));
+            if (yy + yy > xx * xx) {
+                const double v = BBO_ZIG_R + xx;
+                return sign ? -v : v;
+            }
+        } else {
+            const double x = (double) t * zig_w(idx);
+            const double f0 = ZIG_F[idx], f1 = ZIG_F[idx + 1];
+            const double y = __builtin_fma(u01(w.x, w.y), f1 - f0, f0);
+            if (y < exp_neg(0.5 * (x * x))) return sign ? -x : x;
+            idx = w.z & 1023u;
+            t = (w.z >> 10) | 1u;
+            sign = (w.z >> 10) & 1u;
+            if (t < zig_k(idx)) {
+                const double x2 = (double) t * zig_w(idx);
+                return sign ? -x2 : x2;
+            }
+        }
+    }
 }
 
+// the fast path of one word: the candidate +/- t W[i] and whether it stands
+__device__ inline double zig_candidate(uint32_t w, const double2 *tab, bool &settled)
+{
+    const double2 e = tab[w & 1023u];
+    const uint32_t t = (w >> 10) | 1u;
+    const double x = (double) t * e.x;
+    settled = t < (uint32_t) __double_as_longlong(e.y);
+    // (sign = bit 10 of the word -> bit 63 of the double)
+    return __longlong_as_double(__double_as_longlong(x) ^ ((long long) (w & 0x400u) << 53));
+}
+
+// A slow path taken by ONE lane is paid by the whole wavefront, and with 256 draws per wavefront
+// and call SOME lane takes it two times out of three.  The samplers therefore draw in two steps:
+// normal_quad_fast for every call they hold (candidates + a 4-bit mask of the unsettled ones,
+// no branch), then normal_quad_settle once per unsettled draw -- over the 16-32 calls a lane
+// holds that is one or two rounds per wavefront instead of one per call.
+__device__ inline uint32_t normal_quad_fast(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
+        uint32_t c3, const double2 *tab, double &z0, double &z1, double &z2, double &z3)
+{
+    const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
+    bool s0, s1, s2, s3;
+    z0 = zig_candidate(w.x, tab, s0);
+    z1 = zig_candidate(w.y, tab, s1);
+    z2 = zig_candidate(w.z, tab, s2);
+    z3 = zig_candidate(w.w, tab, s3);
+    return (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
+}
+
+// draw `slot` of call c1, which normal_quad_fast reported unsettled (the call is recomputed)
+__device__ inline double normal_quad_settle(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t slot,
+        uint32_t c2, uint32_t c3)
+{
+    const u32x4 w4 = philox4x32_10(seed, c0, c1, c2, c3);
+    const uint32_t w = slot == 0 ? w4.x : slot == 1 ? w4.y : slot == 2 ? w4.z : w4.w;
+    return zig_slow(seed, c0, c1, slot, c2, c3, w & 1023u, (w >> 10) | 1u, (w >> 10) & 1u);
+}
+
+// both steps at once, for the places that draw one call at a time
 __device__ inline void normal_quad(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2,
         uint32_t c3, const double2 *tab, double &z0, double &z1, double &z2, double &z3)
 {
     const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
-    double s, c;
-    const double ra = sqrt(neg2log32(w.x, tab));
-    sincos_oct(w.y, s, c);
-    z0 = ra * c;
-    z1 = ra * s;
-    const double rb = sqrt(neg2log32(w.z, tab));
-    sincos_oct(w.w, s, c);
-    z2 = rb * c;
-    z3 = rb * s;
+    bool s0, s1, s2, s3;
+    z0 = zig_candidate(w.x, tab, s0);
+    z1 = zig_candidate(w.y, tab, s1);
+    z2 = zig_candidate(w.z, tab, s2);
+    z3 = zig_candidate(w.w, tab, s3);
+    if (!(s0 && s1 && s2 && s3)) {
+        if (!s0) z0 = zig_slow(seed, c0, c1, 0, c2, c3, w.x & 1023u, (w.x >> 10) | 1u, (w.x >> 10) & 1u);
+        if (!s1) z1 = zig_slow(seed, c0, c1, 1, c2, c3, w.y & 1023u, (w.y >> 10) | 1u, (w.y >> 10) & 1u);
+        if (!s2) z2 = zig_slow(seed, c0, c1, 2, c2, c3, w.z & 1023u, (w.z >> 10) | 1u, (w.z >> 10) & 1u);
+        if (!s3) z3 = zig_slow(seed, c0, c1, 3, c2, c3, w.w & 1023u, (w.w >> 10) | 1u, (w.w >> 10) & 1u);
+    }
 }
 
 // CMA-ES sampling: Philox call q of a candidate fills columns 16 (q >> 2) + (q & 3) + 4 i,

@@ -19,55 +19,90 @@
 namespace bbo {
 
 // ---------------------------------------------------------------------------
-// sample + evaluate: x = m + sigma d z (sep_cmaes.cpp:73), G lanes per candidate, the row
-// staged in LDS for the objective.  grid (ceil(lambda_pad / (256/G)), P), 256 threads,
-// dynamic LDS (256/G) * ld doubles.  Normals: the same (candidate, column) -> Philox mapping
-// as the full-covariance sampler (cma_quad_col0), so the oracle's statement covers both.
+// sample + evaluate: x = m + sigma d z (sep_cmaes.cpp:73), G lanes per candidate (G | 64, so a
+// row is drawn and evaluated by ONE wavefront: no workgroup barrier after the table is staged),
+// the row kept in LDS for the objective (at row_swizzle(j): a lane writes the four columns of a
+// Philox call 4 apart, which unswizzled lands 16 lanes on each LDS bank).  A workgroup takes chunks of T/G candidates, blockIdx.x,
+// blockIdx.x + gridDim.x, ...: the 16 KB table of the normal generator is staged once per
+// workgroup, so the host sizes the grid for a few thousand workgroups, not one per chunk.
+// The draw is the two-step one (normal_quad_fast / normal_quad_settle, bbo_rng.hpp).
+// grid (<= ceil(lambda_pad / (T/G)), P), T threads, dynamic LDS (T/G) * ld doubles; ld <= 64 G.
+// Normals: the same (candidate, column) -> Philox mapping as the full-covariance sampler
+// (cma_quad_col0), so the oracle's statement covers both.
 // ---------------------------------------------------------------------------
-template<int G>
-__global__ __launch_bounds__(256) void sep_sample_eval(CmaDev d, CmaConst c)
+// FULL: n == ld, no box, lambda == lambda_pad, no injected / recorded normals -- the guards of
+// the general form (a third of its vector instructions) are gone at compile time.
+template<int G, int T = 256, bool FULL = false>
+__global__ __launch_bounds__(T) void sep_sample_eval(CmaDev d, CmaConst c)
 {
+    static_assert(64 % G == 0, "a candidate's lanes must sit in one wavefront");
     const int p = blockIdx.y;
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int R = 256 / G;
+    constexpr int R = T / G;
     const int tid = threadIdx.x, r = tid / G, g = tid % G;
-    const int row = blockIdx.x * R + r, ld = c.ld;
+    const int ld = c.ld;
     double *xr = lds + (size_t) r * ld;
     const int gen = sc->it;
     const double sigma = sc->sigma;
     const double *xm = d.xmean + (size_t) p * ld, *dd = d.D + (size_t) p * ld;
-    double *Xp = d.X + ((size_t) p * c.lambda_pad + row) * ld;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
     __shared__ double2 ntab[NORMAL_TABLE_N];
-    normal_table_fill(ntab, tid, 256);
+    normal_table_fill(ntab, tid, T);
     __syncthreads();
-    if (row < c.lambda_pad) {
-        for (int q = g; q < ld / 4; q += G) {
-            double z[4];
-            cma_draw_quad(d, c, p, row, q, gen, sw, ntab, z);
-            const int j0 = cma_quad_col0(q);
+    const int chunks = (c.lambda_pad + R - 1) / R;
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const int row = chunk * R + r;
+        double *Xp = d.X + ((size_t) p * c.lambda_pad + row) * ld;
+        if (row < c.lambda_pad) {
+            uint64_t pend = 0;                       // 4 bits per call, <= 16 calls per lane
+            int it = 0;
+            for (int q = g; q < ld / 4; q += G, it++) {
+                double z[4];
+                if (FULL)
+                    pend |= (uint64_t) normal_quad_fast(c.seed, (uint32_t) row, (uint32_t) q,
+                            (uint32_t) gen, sw, ntab, z[0], z[1], z[2], z[3]) << (4 * it);
+                else
+                    pend |= (uint64_t) cma_draw_quad_fast(d, c, p, row, q, gen, sw, ntab, z)
+                            << (4 * it);
+                const int j0 = cma_quad_col0(q);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int j = j0 + 4 * i;
-                double v = 0.;
-                if (j < c.n) {
-                    v = xm[j] + sigma * dd[j] * z[i];
-                    if (c.bound) v = fmax(d.lower[j], fmin(v, d.upper[j]));
+                for (int i = 0; i < 4; i++) {
+                    const int j = j0 + 4 * i;
+                    double v = 0.;
+                    if (FULL) {
+                        v = xm[j] + sigma * dd[j] * z[i];
+                    } else if (j < c.n) {
+                        v = xm[j] + sigma * dd[j] * z[i];
+                        if (c.bound) v = fmax(d.lower[j], fmin(v, d.upper[j]));
+                    }
+                    xr[row_swizzle(j)] = v;
+                    Xp[j] = v;
                 }
-                xr[j] = v;
+            }
+            while (pend) {                           // the draws the fast step left open
+                const int b = __ffsll((unsigned long long) pend) - 1;
+                pend &= pend - 1;
+                const int q = g + G * (b >> 2), j = cma_quad_col0(q) + 4 * (b & 3);
+                const double z = FULL ? normal_quad_settle(c.seed, (uint32_t) row, (uint32_t) q,
+                                                (uint32_t) (b & 3), (uint32_t) gen, sw)
+                                      : cma_settle_draw(d, c, p, row, q, b & 3, gen, sw);
+                double v = xm[j] + sigma * dd[j] * z;
+                if (!FULL && c.bound) v = fmax(d.lower[j], fmin(v, d.upper[j]));
+                xr[row_swizzle(j)] = v;
                 Xp[j] = v;
             }
         }
-    }
-    __syncthreads();
-    if (c.obj >= 0 && row < c.lambda_pad) {
-        double f = eval_row_group<G>(c.obj, c.n, xr, d.aux, g);
-        if (g == 0) {
-            if (!(row < c.lambda) || f != f) f = BBO_INF;
-            d.f[(size_t) p * c.lambda_pad + row] = f;
+        cma_wave_sync();
+        if (c.obj >= 0 && row < c.lambda_pad) {
+            double f = eval_row_group<G, true>(c.obj, c.n, xr, d.aux, g);
+            if (g == 0) {
+                if ((!FULL && !(row < c.lambda)) || f != f) f = BBO_INF;
+                d.f[(size_t) p * c.lambda_pad + row] = f;
+            }
         }
+        cma_wave_sync();                     // the rows are reused by the next chunk
     }
 }
 

@@ -1055,8 +1055,20 @@ void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 }
 double orc_log_unit(double u) { return bbo_log_unit(u); }
 void orc_sincos_turn(double t, double *s, double *c) { bbo_sincos_turn(t, s, c); }
-double orc_neg2log32(uint32_t a) { return bbo_neg2log32(a); }
-void orc_sincos_oct(uint32_t b, double *s, double *c) { bbo_sincos_oct(b, s, c); }
+double orc_exp_neg(double s) { return bbo_exp_neg(s); }
+void orc_normal_quad(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double *z)
+{
+    bbo_normal_quad(seed, c0, c1, c2, c3, z);
+}
+/* strip i of the ziggurat: x_i = W 2^22, K, f(x_i); n = BBO_ZIG_N on i < 0 */
+int orc_zig_strip(int i, double *w, uint32_t *k, double *f)
+{
+    if (i < 0 || i > BBO_ZIG_N) return BBO_ZIG_N;
+    *w = i < BBO_ZIG_N ? bbo_zig_w[i] : 0.;
+    *k = i < BBO_ZIG_N ? bbo_zig_k[i] : 0u;
+    *f = bbo_zig_f[i];
+    return BBO_ZIG_N;
+}
 void orc_philox_normals(uint64_t seed, int gen, int rows, int n, double *out)
 {
     for (int k = 0; k < rows; k++)

@@ -176,62 +176,73 @@ static inline void bbo_normal_pair(uint64_t seed, uint32_t c0, uint32_t c1,
 
 /*
  * The samplers' generator (device twin: normal_quad in bbo_rng.hpp): ONE Philox call -> FOUR
- * standard normals, two Box-Muller pairs from 32 + 32 bits each.
- *   radius^2 = -2 ln u, u = (a + 1) 2^-32: table of 91 (1/c_i, 2 ln(1/c_i)) pairs on
- *              m in [0.70703125, 1.4140625) (normal_table.inc, generated by
- *              scripts/gen_normal_table.py) + degree-8 polynomial in r = m/c_i - 1
- *   direction  x = (k + 1/2)(pi/4) 2^-29 from 29 bits, fdlibm kernels on (0, pi/4), three
- *              more bits choose among the 8 symmetries of the square
+ * standard normals by the Marsaglia-Tsang ziggurat on 1024 strips of exp(-x^2 / 2)
+ * (zig_table.inc, generated by scripts/gen_ziggurat_table.py).  A 32-bit word is one draw:
+ *   strip i = w & 1023,  t = (w >> 10) | 1 (odd, 22 bits),  sign = bit 10,  z = +/- t W[i];
+ *   t < K[i]: the point lies under the curve for sure (99.57 % of the draws);
+ *   the rest (bbo_zig_slow) takes fresh Philox words at counters no first draw uses
+ *   (c1 | (slot + 1) << 12 | attempt << 16): the tail beyond r by Marsaglia's -ln(u)/r method in
+ *   the base strip, the wedge test in the others, a fresh strip after a rejection.
+ * Only integer operations, +, *, fma, ldexp and conversions, in the device's order.
  */
-static const double bbo_normal_table[91][2] = {
-#include "normal_table.inc"
-};
+#include "zig_table.inc"
+static const double bbo_zig_w[BBO_ZIG_N] = BBO_ZIG_TABLE_W;
+static const uint32_t bbo_zig_k[BBO_ZIG_N] = BBO_ZIG_TABLE_K;
+static const double bbo_zig_f[BBO_ZIG_N + 1] = BBO_ZIG_TABLE_F;
 
-static inline double bbo_neg2log32(uint32_t a)
+/* exp(-s), s in [0, 700]: s = k ln 2 + r, |r| <= 0.35, Taylor to the 13th power
+ * (device twin: exp_neg) */
+static inline double bbo_exp_neg(double s)
 {
-    const double d = (double) a + 1.;
-    int e;
-    double m = frexp(d, &e);                 /* [1/2, 1) */
-    if (m < 0.70703125) {
-        m *= 2.;
-        e -= 1;
-    }
-    const int i = (int) fma(m, 128., -90.5);
-    const double inv = bbo_normal_table[i][0], t2 = bbo_normal_table[i][1];
-    const double r = fma(m, inv, -1.);
-    double p = 2. / 8.;
-    p = fma(p, r, -2. / 7.);
-    p = fma(p, r, 2. / 6.);
-    p = fma(p, r, -2. / 5.);
-    p = fma(p, r, 2. / 4.);
-    p = fma(p, r, -2. / 3.);
-    p = fma(p, r, 1.);
-    p = fma(p, r, -2.);
-    const double base = fma((double) (32 - e), 0x1.62e42fefa39efp+0, t2);
-    return fma(p, r, base);
+    const int k = (int) fma(s, 0x1.71547652b82fep+0, 0.5);
+    const double dk = (double) k;
+    double r = fma(-dk, 0x1.62e42fefa3800p-1, s);
+    r = fma(-dk, 0x1.ef35793c76730p-45, r);
+    const double y = -r;
+    double p = 0x1.6124613a86d09p-33;
+    p = fma(p, y, 0x1.1eed8eff8d898p-29);
+    p = fma(p, y, 0x1.ae64567f544e4p-26);
+    p = fma(p, y, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, y, 0x1.71de3a556c734p-19);
+    p = fma(p, y, 0x1.a01a01a01a01ap-16);
+    p = fma(p, y, 0x1.a01a01a01a01ap-13);
+    p = fma(p, y, 0x1.6c16c16c16c17p-10);
+    p = fma(p, y, 0x1.1111111111111p-7);
+    p = fma(p, y, 0x1.5555555555555p-5);
+    p = fma(p, y, 0x1.5555555555555p-3);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.);
+    p = fma(p, y, 1.);
+    return ldexp(p, -k);
 }
 
-static inline void bbo_sincos_oct(uint32_t b, double *sn, double *cs)
+static inline double bbo_zig_slow(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t slot,
+        uint32_t c2, uint32_t c3, uint32_t idx, uint32_t t, uint32_t sign)
 {
-    const double x = fma((double) (b >> 3), 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);
-    const double z = x * x;
-    double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
-    const double sx = fma(x * z, ps, x);
-    double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
-    const double cx = fma(z * z, pc, fma(z, -0.5, 1.));
-    const double s0 = (b & 1u) ? cx : sx, c0 = (b & 1u) ? sx : cx;
-    *sn = (b & 2u) ? -s0 : s0;
-    *cs = (b & 4u) ? -c0 : c0;
+    for (uint32_t attempt = 0;; attempt++) {
+        uint32_t w[4];
+        bbo_philox(seed, c0, c1 | ((slot + 1u) << 12) | (attempt << 16), c2, c3, w);
+        if (idx == 0) {
+            const double xx = -bbo_log_unit(bbo_u01_open0(w[0], w[1])) * BBO_ZIG_INV_R;
+            const double yy = -bbo_log_unit(bbo_u01_open0(w[2], w[3]));
+            if (yy + yy > xx * xx) {
+                const double v = BBO_ZIG_R + xx;
+                return sign ? -v : v;
+            }
+        } else {
+            const double x = (double) t * bbo_zig_w[idx];
+            const double f0 = bbo_zig_f[idx], f1 = bbo_zig_f[idx + 1];
+            const double y = fma(bbo_u01(w[0], w[1]), f1 - f0, f0);
+            if (y < bbo_exp_neg(0.5 * (x * x))) return sign ? -x : x;
+            idx = w[2] & 1023u;
+            t = (w[2] >> 10) | 1u;
+            sign = (w[2] >> 10) & 1u;
+            if (t < bbo_zig_k[idx]) {
+                const double x2 = (double) t * bbo_zig_w[idx];
+                return sign ? -x2 : x2;
+            }
+        }
+    }
 }
 
 static inline void bbo_normal_quad(uint64_t seed, uint32_t c0, uint32_t c1,
@@ -239,15 +250,15 @@ static inline void bbo_normal_quad(uint64_t seed, uint32_t c0, uint32_t c1,
 {
     uint32_t w[4];
     bbo_philox(seed, c0, c1, c2, c3, w);
-    double sn, cs;
-    const double ra = sqrt(bbo_neg2log32(w[0]));
-    bbo_sincos_oct(w[1], &sn, &cs);
-    z[0] = ra * cs;
-    z[1] = ra * sn;
-    const double rb = sqrt(bbo_neg2log32(w[2]));
-    bbo_sincos_oct(w[3], &sn, &cs);
-    z[2] = rb * cs;
-    z[3] = rb * sn;
+    for (uint32_t s = 0; s < 4; s++) {
+        const uint32_t idx = w[s] & 1023u, t = (w[s] >> 10) | 1u, sign = (w[s] >> 10) & 1u;
+        if (t < bbo_zig_k[idx]) {
+            const double x = (double) t * bbo_zig_w[idx];
+            z[s] = sign ? -x : x;
+        } else {
+            z[s] = bbo_zig_slow(seed, c0, c1, s, c2, c3, idx, t, sign);
+        }
+    }
 }
 
 /*

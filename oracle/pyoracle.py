@@ -31,7 +31,7 @@ def build_oracle(force=False):
     """compile the oracle restatement (g++, a few seconds)"""
     if force or not os.path.exists(ORACLE_SO) or any(
             os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(ORACLE_SO)
-            for f in ("bbo_oracle.cpp", "bbo_oracle_pop.inc", "objectives.h", "philox.h")):
+            for f in ("bbo_oracle.cpp", "bbo_oracle_pop.inc", "objectives.h", "philox.h", "zig_table.inc")):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     return ORACLE_SO
 
@@ -166,12 +166,15 @@ class _Lib:
                 f("sincos_turn").argtypes = [C.c_double, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double)]
                 f("sincos_turn").restype = None
-            if hasattr(L, p + "neg2log32"):
-                f("neg2log32").argtypes = [C.c_uint32]
-                f("neg2log32").restype = C.c_double
-                f("sincos_oct").argtypes = [C.c_uint32, C.POINTER(C.c_double),
-                                            C.POINTER(C.c_double)]
-                f("sincos_oct").restype = None
+            if hasattr(L, p + "exp_neg"):
+                f("exp_neg").argtypes = [C.c_double]
+                f("exp_neg").restype = C.c_double
+                f("normal_quad").argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, _dp]
+                f("normal_quad").restype = None
+                f("zig_strip").argtypes = [C.c_int, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+                f("zig_strip").restype = C.c_int
             if hasattr(L, p + "pop_set_mode"):
                 f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
                 f("pop_set_mode").restype = None

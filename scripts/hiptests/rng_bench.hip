@@ -36,11 +36,36 @@ __global__ __launch_bounds__(256) void k(double *out, int reps)
             normal_quad(1234, tid, i, 7, 1 << 24, tab, a, b, c2, d2);
             acc += a + b + c2 + d2;
         } else if (V == 13) {
-            acc += neg2log32(tid * 977u + i * 31u, tab);
-        } else if (V == 14) {
-            double s, c;
-            sincos_oct(tid * 977u + i * 31u, s, c);
-            acc += s + c;
+            // the same from the global copy of the table (no LDS fill)
+            double a, b, c2, d2;
+            normal_quad(1234, tid, i, 7, 1 << 24, reinterpret_cast<const double2*>(ZIG_WK), a, b,
+                    c2, d2);
+            acc += a + b + c2 + d2;
+        } else if (V == 14 || V == 15) {
+            // two-step: 8 calls' candidates, then the unsettled draws together
+            if ((i & 7) == 0) {
+                const double2 *t = V == 14 ? tab : reinterpret_cast<const double2*>(ZIG_WK);
+                double z[32];
+                uint32_t pend = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    pend |= normal_quad_fast(1234, tid, i + q, 7, 1 << 24, t, z[4 * q],
+                            z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]) << (4 * q);
+                while (pend) {
+                    const int b = __ffs(pend) - 1;
+                    pend &= pend - 1;
+                    const double v = normal_quad_settle(1234, tid, i + (b >> 2), b & 3, 7, 1 << 24);
+#pragma unroll
+                    for (int j = 0; j < 32; j++) z[j] = (j == b) ? v : z[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 32; j++) acc += z[j];
+            }
+        } else if (V == 16) {
+            // fast path only (what the two-step form costs without its settle rounds)
+            double a, b, c2, d2;
+            acc += (double) normal_quad_fast(1234, tid, i, 7, 1 << 24, tab, a, b, c2, d2);
+            acc += a + b + c2 + d2;
         } else if (V == 7) {
             const double u1 = (tid * 977u + i * 31u + 1u) * 0x1.0p-33;
             acc += log_unit(u1);
@@ -113,7 +138,9 @@ int main()
     run<10>("division", out);
     run<11>("philox+u01 x2", out);
     run<12>("normal_quad (4 normals)", out);
-    run<13>("neg2log32", out);
-    run<14>("sincos_oct", out);
+    run<13>("normal_quad, global table", out);
+    run<14>("two-step x8, LDS table", out);
+    run<15>("two-step x8, global table", out);
+    run<16>("normal_quad_fast only", out);
     return 0;
 }

@@ -150,37 +150,79 @@ def test_device_normal_arithmetic_is_accurate(oracle_lib):
     assert float(np.abs(np.array(Cc) - np.cos(ang)).max()) <= 4 * 2.0 ** -53
 
 
-def test_sampler_normal_arithmetic_is_accurate(oracle_lib):
-    """The pieces of the samplers' four-normals-per-Philox-call generator (normal_quad in
-    bbo_rng.hpp, bbo_normal_quad in oracle/philox.h): table-driven -2 ln((a+1) 2^-32) and the
-    direction from 32 bits, against long-double libm."""
+def _zig_strips(oracle_lib):
     import ctypes
+    w, k, f = ctypes.c_double(), ctypes.c_uint32(), ctypes.c_double()
+    n = oracle_lib.f("zig_strip")(-1, ctypes.byref(w), ctypes.byref(k), ctypes.byref(f))
+    W, K, F = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n + 1)
+    for i in range(n + 1):
+        oracle_lib.f("zig_strip")(i, ctypes.byref(w), ctypes.byref(k), ctypes.byref(f))
+        if i < n:
+            W[i], K[i] = w.value, k.value
+        F[i] = f.value
+    return n, W, K, F
+
+
+def test_ziggurat_tables_are_a_ziggurat(oracle_lib):
+    """The strips of the samplers' normal generator (normal_quad in bbo_rng.hpp, bbo_normal_quad
+    in oracle/philox.h; tables from scripts/gen_ziggurat_table.py): decreasing right edges down
+    to 0, equal areas, F = exp(-x^2 / 2) at the edges, K the largest integer position that is
+    surely under the curve, and the base strip's area split between rectangle and tail."""
+    from scipy.special import erfc
+    n, W, K, F = _zig_strips(oracle_lib)
+    assert n == 1024
+    x = np.append(W * 2.0 ** 22, 0.)                 # x[0] virtual, x[1] = r, x[n] = 0
+    assert (np.diff(x) < 0).all() and x[n] == 0.
+    assert np.allclose(F[1:], np.exp(-0.5 * x[1:] ** 2), rtol=2e-14, atol=0)
+    r = x[1]
+    v = r * np.exp(-0.5 * r * r) + np.sqrt(np.pi / 2) * erfc(r / np.sqrt(2))
+    assert abs(x[0] * F[1] / v - 1) < 1e-13          # x_0 = v / f(r)
+    area = x[1:n] * (F[2:] - F[1:n])                 # strips 1 .. n-1
+    assert np.abs(area / v - 1).max() < 1e-9
+    ratio = 2.0 ** 22 * x[1:] / x[:n]
+    assert (K <= ratio).all() and (K + 1 > ratio).all()
+    assert K[n - 1] == 0 and (K[:n - 1] > 0).all()
+    # what leaves the fast path (t odd in [1, 2^22): t >= K)
+    slow = np.mean(1 - K / 2.0 ** 22)
+    assert 0.004 < slow < 0.0045
+
+
+def test_sampler_exp_is_accurate(oracle_lib):
+    """exp(-s) of the wedge test (exp_neg / bbo_exp_neg) against long-double libm on the range
+    the wedge test uses (s = x^2 / 2 <= r^2 / 2 = 8.2) and well beyond."""
     rng = np.random.default_rng(11)
-    a = np.concatenate([rng.integers(0, 2 ** 32, 20000, dtype=np.uint64),
-                        [0, 1, 2, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1],
-                        2 ** rng.integers(0, 32, 200, dtype=np.uint64) - 1]).astype(np.uint64)
-    got = np.array([oracle_lib.f("neg2log32")(int(x)) for x in a])
-    ref = -2 * np.log((a.astype(np.longdouble) + 1) / np.longdouble(2 ** 32))
-    rel = np.abs((got - ref) / np.where(ref == 0, 1, ref)).astype(float)
-    assert rel.max() <= 4 * 2.0 ** -53
-    assert oracle_lib.f("neg2log32")(2 ** 32 - 1) == 0.0           # u = 1
-    assert (got >= 0).all()
-    s, c = ctypes.c_double(), ctypes.c_double()
-    worst = 0.
-    quarter_pi = np.arctan(np.longdouble(1))
-    for b in rng.integers(0, 2 ** 32, 20000, dtype=np.uint64):
-        b = int(b)
-        oracle_lib.f("sincos_oct")(b, ctypes.byref(s), ctypes.byref(c))
-        x = (np.longdouble(b >> 3) + np.longdouble(0.5)) * quarter_pi / np.longdouble(2 ** 29)
-        ss, cc = np.sin(x), np.cos(x)
-        if b & 1:
-            ss, cc = cc, ss
-        if b & 2:
-            ss = -ss
-        if b & 4:
-            cc = -cc
-        worst = max(worst, abs(float(ss - s.value)), abs(float(cc - c.value)))
-    assert worst <= 4 * 2.0 ** -53
+    s = np.concatenate([rng.uniform(0, 8.2, 20000), rng.uniform(0, 700, 5000),
+                        [0., 1e-300, 0.5 * np.log(2.), np.log(2.), 8.156, 700.]])
+    got = np.array([oracle_lib.f("exp_neg")(float(v)) for v in s])
+    ref = np.exp(-s.astype(np.longdouble))
+    assert float(np.abs(got / ref - 1).max()) <= 4 * 2.0 ** -53
+    assert oracle_lib.f("exp_neg")(0.) == 1.
+
+
+def test_sampler_normals_are_standard_normal(oracle_lib):
+    """2^22 normals of the samplers' generator: moments, Kolmogorov distance, tail counts
+    (including the tail beyond the base strip's edge r = 4.04, which only the slow path makes) and
+    a chi-square over 64 equiprobable cells."""
+    from scipy import stats
+    rows, n = 4096, 1024
+    z = np.zeros(rows * n)
+    oracle_lib.f("philox_normals")(20240611, 3, rows, n, z)
+    N = z.size
+    assert abs(z.mean()) < 4 / np.sqrt(N)
+    assert abs(z.var() - 1) < 4 * np.sqrt(2. / N)
+    assert abs(np.mean(z ** 3)) < 4 * np.sqrt(15. / N)
+    assert abs(np.mean(z ** 4) - 3) < 4 * np.sqrt(96. / N)
+    assert stats.kstest(z, "norm").statistic < 1.63 / np.sqrt(N)       # 1 % level
+    for a in (1., 2., 3., 4., 4.0388498461095045, 4.5):
+        pr = 2 * stats.norm.sf(a)
+        cnt = int((np.abs(z) > a).sum())
+        assert abs(cnt - N * pr) < 4.5 * np.sqrt(N * pr) + 1, (a, cnt, N * pr)
+    assert (z > 4.0388498461095045).any() and (z < -4.0388498461095045).any()
+    # chi-square over 64 equiprobable cells
+    edges = stats.norm.ppf(np.linspace(0, 1, 65)[1:-1])
+    cells = np.bincount(np.searchsorted(edges, z), minlength=64)
+    chi2 = float(((cells - N / 64.) ** 2 / (N / 64.)).sum())
+    assert chi2 < stats.chi2.ppf(0.999, 63), chi2
 
 
 def test_philox_normals_are_standard_normal(oracle_lib):

@@ -148,3 +148,23 @@ def test_lean_sampler_build_equals_the_general_one(hip, lam, P):
     for a, b in zip(runs[0], runs[1]):
         for u, v in zip(a, b):
             np.testing.assert_array_equal(u, v)
+
+
+def test_lean_separable_sampler_equals_the_general_one(hip):
+    """sep_sample_eval has the same kind of lean build (n == ld, no box, lambda == lambda_pad: the
+    benchmark's SEP shape): X, f and the state downstream BIT-IDENTICAL to the general build."""
+    n, lam, P = 1024, 256, 4
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(6).uniform(-5, 5, (P, n))
+    runs = []
+    for dbg in (0, 256):
+        g = hip.SepCMAES(mfev=10 ** 9, tol=0., np=lam, seed=78, populations=P)
+        g.initialize(hip.objectives.ellipsoid, lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [float(dbg)])
+        g.run(5)
+        runs.append([(g.get_state("arx", p), g.get_state("fitness", p), g.get_state("D", p), g.get_state("csep", p),
+                      g.get_state("sigma", p)) for p in (0, P - 1)])
+    for a, b in zip(runs[0], runs[1]):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
