@@ -116,10 +116,10 @@ __device__ inline uint32_t cma_draw_quad_fast(const CmaDev &d, const CmaConst &c
 }
 
 __device__ inline double cma_settle_draw(const CmaDev &d, const CmaConst &c, int p, int row, int q,
-        int slot, int gen, uint32_t sw)
+        int slot, int gen, uint32_t sw, const double2 *tab)
 {
     const double v = normal_quad_settle(c.seed, (uint32_t) row, (uint32_t) q, (uint32_t) slot,
-            (uint32_t) gen, sw);
+            (uint32_t) gen, sw, tab, zig_global_f());
     if (d.zrecord)
         d.zrecord[((size_t) p * c.lambda + row) * c.n + cma_quad_col0(q) + 4 * slot] = v;
     return v;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
         pend &= pend - 1;
         const int qi = tid + 256 * (b >> 2), r = qi / nquads, q = qi - r * nquads;
         lds[r * ldz + cma_quad_col0(q) + 4 * (b & 3)] =
-                cma_settle_draw(d, c, p, mt * 16 + r, q, b & 3, gen, sw);
+                cma_settle_draw(d, c, p, mt * 16 + r, q, b & 3, gen, sw, ntab);
     }
     __syncthreads();
 
@@ -272,7 +272,7 @@ __device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaCon
         pend &= pend - 1;
         const int qi = tid + 256 * (b >> 2), r = qi / nquads, q = qi - r * nquads;
         lds[r * ldz + cma_quad_col0(q) + 4 * (b & 3)] =
-                cma_settle_draw(d, c, p, row0 + r, q, b & 3, gen, sw);
+                cma_settle_draw(d, c, p, row0 + r, q, b & 3, gen, sw, ntab);
     }
     __syncthreads();
 
@@ -405,7 +405,7 @@ __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, in
 
 template<bool FULL>
 __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaConst &c,
-        int rows_per_wg, double *bd, const double2 *ntab)
+        int rows_per_wg, double *bd, const double2 *ntab, const double *ftab)
 {
     const int p = blockIdx.y, row0 = blockIdx.x * rows_per_wg;
     const CmaScal *sc = d.scal + p;
@@ -440,7 +440,8 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
                 const int b = __ffs(pend) - 1;
                 pend &= pend - 1;
                 const double v = normal_quad_settle(c.seed, (uint32_t) row,
-                        (uint32_t) (4 * (b >> 2) + fk), (uint32_t) (b & 3), (uint32_t) gen, sw);
+                        (uint32_t) (4 * (b >> 2) + fk), (uint32_t) (b & 3), (uint32_t) gen, sw,
+                        ntab, ftab);
 #pragma unroll
                 for (int i = 0; i < 32; i++) z[i] = (i == b) ? v : z[i];
             }
@@ -505,10 +506,12 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
         for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
     }
     __shared__ double2 ntab[NORMAL_TABLE_N];
+    __shared__ double ftab[NORMAL_FTABLE_N];
     normal_table_fill(ntab, tid, 512);
+    normal_ftable_fill(ftab, tid, 512);
     __syncthreads();
-    if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab);
-    else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab);
+    if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab, ftab);
+    else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab, ftab);
 }
 
 // ---------------------------------------------------------------------------

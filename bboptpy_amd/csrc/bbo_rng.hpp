@@ -182,8 +182,15 @@ __device__ inline void normal_table_fill(double2 *tab, int tid, int nthreads)
     const double2 *src = reinterpret_cast<const double2*>(ZIG_WK);
     for (int i = tid; i < NORMAL_TABLE_N; i += nthreads) tab[i] = src[i];
 }
-__device__ inline double zig_w(uint32_t i) { return ZIG_WK[i].w; }
-__device__ inline uint32_t zig_k(uint32_t i) { return (uint32_t) __double_as_longlong(ZIG_WK[i].kbits); }
+// the global copies, as the pointers zig_slow / normal_quad_settle take when the caller has
+// no LDS copy to offer
+__device__ inline const double2 *zig_global_wk() { return reinterpret_cast<const double2*>(ZIG_WK); }
+__device__ inline const double *zig_global_f() { return ZIG_F; }
+constexpr int NORMAL_FTABLE_N = BBO_ZIG_N + 1;      // optional LDS copy of ZIG_F (8 KB)
+__device__ inline void normal_ftable_fill(double *ftab, int tid, int nthreads)
+{
+    for (int i = tid; i < NORMAL_FTABLE_N; i += nthreads) ftab[i] = ZIG_F[i];
+}
 
 // exp(-s) for s in [0, 700]: s = k ln 2 + r, |r| <= 0.35, Taylor to the 13th power (oracle twin:
 // bbo_exp_neg)
@@ -212,9 +219,12 @@ __device__ inline double exp_neg(double s)
 }
 
 // the 0.43 % of the draws the fast test does not settle (see above); slot = which of the four
-// words of Philox call c1 this draw was
+// words of Philox call c1 this draw was.  wk / f: the tables, LDS or global copies (a settle round
+// is a chain of dependent look-ups: from LDS it is latency the other wavefront of the SIMD does
+// not have to cover)
 __device__ inline double zig_slow(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t slot,
-        uint32_t c2, uint32_t c3, uint32_t idx, uint32_t t, uint32_t sign)
+        uint32_t c2, uint32_t c3, uint32_t idx, uint32_t t, uint32_t sign, const double2 *wk,
+        const double *f)
 {
     for (uint32_t attempt = 0;; attempt++) {
         const u32x4 w = philox4x32_10(seed, c0, c1 | ((slot + 1u) << 12) | (attempt << 16), c2, c3);
@@ -226,15 +236,16 @@ __device__ inline double zig_slow(uint64_t seed, uint32_t c0, uint32_t c1, uint3
                 return sign ? -v : v;
             }
         } else {
-            const double x = (double) t * zig_w(idx);
-            const double f0 = ZIG_F[idx], f1 = ZIG_F[idx + 1];
+            const double x = (double) t * wk[idx].x;
+            const double f0 = f[idx], f1 = f[idx + 1];
             const double y = __builtin_fma(u01(w.x, w.y), f1 - f0, f0);
             if (y < exp_neg(0.5 * (x * x))) return sign ? -x : x;
             idx = w.z & 1023u;
             t = (w.z >> 10) | 1u;
             sign = (w.z >> 10) & 1u;
-            if (t < zig_k(idx)) {
-                const double x2 = (double) t * zig_w(idx);
+            const double2 e = wk[idx];
+            if (t < (uint32_t) __double_as_longlong(e.y)) {
+                const double x2 = (double) t * e.x;
                 return sign ? -x2 : x2;
             }
         }
@@ -271,11 +282,11 @@ __device__ inline uint32_t normal_quad_fast(uint64_t seed, uint32_t c0, uint32_t
 
 // draw `slot` of call c1, which normal_quad_fast reported unsettled (the call is recomputed)
 __device__ inline double normal_quad_settle(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t slot,
-        uint32_t c2, uint32_t c3)
+        uint32_t c2, uint32_t c3, const double2 *wk, const double *f)
 {
     const u32x4 w4 = philox4x32_10(seed, c0, c1, c2, c3);
     const uint32_t w = slot == 0 ? w4.x : slot == 1 ? w4.y : slot == 2 ? w4.z : w4.w;
-    return zig_slow(seed, c0, c1, slot, c2, c3, w & 1023u, (w >> 10) | 1u, (w >> 10) & 1u);
+    return zig_slow(seed, c0, c1, slot, c2, c3, w & 1023u, (w >> 10) | 1u, (w >> 10) & 1u, wk, f);
 }
 
 // both steps at once, for the places that draw one call at a time
@@ -289,10 +300,10 @@ __device__ inline void normal_quad(uint64_t seed, uint32_t c0, uint32_t c1, uint
     z2 = zig_candidate(w.z, tab, s2);
     z3 = zig_candidate(w.w, tab, s3);
     if (!(s0 && s1 && s2 && s3)) {
-        if (!s0) z0 = zig_slow(seed, c0, c1, 0, c2, c3, w.x & 1023u, (w.x >> 10) | 1u, (w.x >> 10) & 1u);
-        if (!s1) z1 = zig_slow(seed, c0, c1, 1, c2, c3, w.y & 1023u, (w.y >> 10) | 1u, (w.y >> 10) & 1u);
-        if (!s2) z2 = zig_slow(seed, c0, c1, 2, c2, c3, w.z & 1023u, (w.z >> 10) | 1u, (w.z >> 10) & 1u);
-        if (!s3) z3 = zig_slow(seed, c0, c1, 3, c2, c3, w.w & 1023u, (w.w >> 10) | 1u, (w.w >> 10) & 1u);
+        if (!s0) z0 = zig_slow(seed, c0, c1, 0, c2, c3, w.x & 1023u, (w.x >> 10) | 1u, (w.x >> 10) & 1u, tab, zig_global_f());
+        if (!s1) z1 = zig_slow(seed, c0, c1, 1, c2, c3, w.y & 1023u, (w.y >> 10) | 1u, (w.y >> 10) & 1u, tab, zig_global_f());
+        if (!s2) z2 = zig_slow(seed, c0, c1, 2, c2, c3, w.z & 1023u, (w.z >> 10) | 1u, (w.z >> 10) & 1u, tab, zig_global_f());
+        if (!s3) z3 = zig_slow(seed, c0, c1, 3, c2, c3, w.w & 1023u, (w.w >> 10) | 1u, (w.w >> 10) & 1u, tab, zig_global_f());
     }
 }
 

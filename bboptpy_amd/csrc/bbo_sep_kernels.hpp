@@ -86,8 +86,9 @@ __global__ __launch_bounds__(T) void sep_sample_eval(CmaDev d, CmaConst c)
                 pend &= pend - 1;
                 const int q = g + G * (b >> 2), j = cma_quad_col0(q) + 4 * (b & 3);
                 const double z = FULL ? normal_quad_settle(c.seed, (uint32_t) row, (uint32_t) q,
-                                                (uint32_t) (b & 3), (uint32_t) gen, sw)
-                                      : cma_settle_draw(d, c, p, row, q, b & 3, gen, sw);
+                                                (uint32_t) (b & 3), (uint32_t) gen, sw, ntab,
+                                                zig_global_f())
+                                      : cma_settle_draw(d, c, p, row, q, b & 3, gen, sw, ntab);
                 double v = xm[j] + sigma * dd[j] * z;
                 if (!FULL && c.bound) v = fmax(d.lower[j], fmin(v, d.upper[j]));
                 xr[row_swizzle(j)] = v;

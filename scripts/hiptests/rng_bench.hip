@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k(double *out, int reps)
                 while (pend) {
                     const int b = __ffs(pend) - 1;
                     pend &= pend - 1;
-                    const double v = normal_quad_settle(1234, tid, i + (b >> 2), b & 3, 7, 1 << 24);
+                    const double v = normal_quad_settle(1234, tid, i + (b >> 2), b & 3, 7, 1 << 24, t, zig_global_f());
 #pragma unroll
                     for (int j = 0; j < 32; j++) z[j] = (j == b) ? v : z[j];
                 }
