@@ -128,14 +128,20 @@ def test_generation_phases_match_oracle(hip, oracle_lib, variant, n, lam, obj):
         assert int(g.get_state("flag")[0]) == o.converged()
 
 
-@pytest.mark.parametrize("n,lam", [(10, 20), (37, 50), (128, 256), (128, 4096), (200, 64)])
-def test_device_normals_bit_identical_to_oracle(hip, oracle_lib, n, lam):
+@pytest.mark.parametrize("algo,n,lam", [("CMAES", 10, 20), ("CMAES", 37, 50), ("CMAES", 128, 256),
+                                        ("CMAES", 128, 4096), ("CMAES", 200, 64),
+                                        ("CMAES", 300, 48), ("CMAES", 512, 32),
+                                        ("SepCMAES", 100, 40), ("SepCMAES", 1024, 64),
+                                        ("SepCMAES", 1500, 24), ("SepCMAES", 4096, 12)])
+def test_device_normals_bit_identical_to_oracle(hip, oracle_lib, algo, n, lam):
     """The sampling normals are a pure function of (seed, candidate, column, generation): the
-    device draws (bbo_rng.hpp) and the CPU statement (oracle/philox.h) agree to the last bit,
-    through every sampling kernel variant (n <= 128 register path, n = 128 / 4096 streaming
-    path, n > 128 generic path)."""
+    device draws (bbo_rng.hpp: ziggurat, first step and settle step, whatever the kernel's way of
+    collecting the unsettled draws) and the CPU statement (oracle/philox.h) agree to the last
+    bit, through every sampling kernel variant (n <= 128 register path, n = 128 / 4096 streaming
+    path, n > 128 generic path up to ld = 512, the separable sampler with 16 lanes or one
+    wavefront per candidate and 4 .. 16 Philox calls per lane)."""
     from bboptpy_amd import _ffi
-    g = hip.CMAES(mfev=10 ** 7, tol=1e-12, np=lam, seed=987654321)
+    g = getattr(hip, algo)(mfev=10 ** 7, tol=1e-12, np=lam, seed=987654321)
     g.initialize(hip.objectives.sphere, -5. * np.ones(n), 5. * np.ones(n), np.ones(n))
     g.set_state("record_normals", [1.0])
     for gen in range(2):
