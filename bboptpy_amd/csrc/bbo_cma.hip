@@ -98,6 +98,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.mu_pad = round_up(c.mu, 16);
     c.variant = sep ? 2 : params_.algo == BBO_ALGO_ACTIVE_CMAES ? 1 : 0;
     c.bound = params_.bound ? 1 : 0;
+    // (16 < ld <= 128: the samplers there always hand down ||z||^2, so without a box nothing in
+    // a generation reads C^-1/2 but cma_paths, which can work from B and D)
+    c.lazy_isc = (!sep && !c.bound && c.ld > 16 && c.ld <= 128) ? 1 : 0;
     c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
     c.mfev = params_.mfev;
     c.mit = params_.mfev / lambda;
@@ -533,7 +536,9 @@ void CmaEngine::launch_eigen()
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_POST);
-    if (!small) launch_post(0);
+    // (lazy_isc: the eigensolver has written the packed B D itself and C^-1/2 is not formed)
+    const bool packed_by_eigen = c.lazy_isc && pl.dc && pl.reg_path && !(d_.dbg & 2);
+    if (!small && !packed_by_eigen) launch_post(0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
@@ -846,7 +851,17 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "csep") return vec(csep_);
     if (k == "B") return mat(B_, n, ld, n, p * ld * ld);
     if (k == "C") return mat(C_, n, ld, n, p * ld * ld);
-    if (k == "invsqrtC") return mat(isc_, n, ld, n, p * ld * ld);
+    if (k == "invsqrtC") {
+        if (c.lazy_isc && out) {         // not kept current by the generations: form it now
+            const int hs = c_.honor_stop;
+            c_.honor_stop = 0;
+            launch_post(3);
+            c_.honor_stop = hs;
+            BBO_HIP(hipGetLastError());
+            BBO_HIP(hipStreamSynchronize(stream_));
+        }
+        return mat(isc_, n, ld, n, p * ld * ld);
+    }
     if (k == "arx") return mat(X_, c.lambda, ld, n, (size_t) p * c.lambda_pad * ld);
     if (k == "weights") {
         if (out && cap >= c.mu) weights_.download(out, c.mu);

@@ -1141,15 +1141,74 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
     const double den = c.variant == 1 ? c.cm * sigma : sigma;
     const double *isc = d.isc + (size_t) p * ld * ld;
     double ssq = 0.;
-    for (int i = tid; i < ld; i += 256) {
-        double v = 0.;
-        if (i < c.n) {
-            double acc = 0.;
-            for (int j = 0; j < c.n; j++) acc += isc[(size_t) j * ld + i] * dm[j];
-            v = (1. - c.cs) * ps[i] + csc * acc / den;
+    if (c.lazy_isc && sc->basis_ok) {
+        // C^-1/2 dm = B (D^-1 (B^T dm)) from the basis itself: 2 n^2 operations instead of the
+        // n^3 of forming C^-1/2 after every decomposition (cma_post then only packs B D)
+        __shared__ double sv[128], cv[128], part[128];
+        const double *B = d.B + (size_t) p * ld * ld, *D = d.D + (size_t) p * ld;
+        // (both products with the loads of a thread independent of each other: the matrix comes
+        // from L2 / HBM once, latency is what there is to hide)
+        {
+            // t = B^T dm: column j by threads j and j + 128 (even / odd rows), 8 rows in flight
+            const int j = tid & 127, h = tid >> 7;
+            double t0 = 0., t1 = 0., t2 = 0., t3 = 0.;
+            if (j < c.n) {
+                int i = h;
+                for (; i + 14 < c.n; i += 16) {
+                    double b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) b[u] = B[(size_t) (i + 2 * u) * ld + j];
+                    t0 += b[0] * dm[i] + b[4] * dm[i + 8];
+                    t1 += b[1] * dm[i + 2] + b[5] * dm[i + 10];
+                    t2 += b[2] * dm[i + 4] + b[6] * dm[i + 12];
+                    t3 += b[3] * dm[i + 6] + b[7] * dm[i + 14];
+                }
+                for (; i < c.n; i += 2) t0 += B[(size_t) i * ld + j] * dm[i];
+            }
+            const double t = (t0 + t1) + (t2 + t3);
+            if (h == 1) part[j] = t;
+            __syncthreads();
+            if (h == 0) sv[j] = j < c.n ? (t + part[j]) / D[j] : 0.;
         }
-        ps[i] = v;
-        ssq += v * v;
+        __syncthreads();
+        {
+            // cv = B sv: rows r, r + 16, ... by the 16 lanes of a DPP row (128-byte segments)
+            const int g = tid & 15, r = tid >> 4;
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = r + 16 * u;
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int j = g + 16 * k;
+                    x[k] = (i < c.n && j < c.n) ? B[(size_t) i * ld + j] * sv[j] : 0.;
+                }
+                a[u] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double v = group_sum<16>(a[u]);
+                if (g == 0 && r + 16 * u < c.n) cv[r + 16 * u] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < ld; i += 256) {
+            const double v = i < c.n ? (1. - c.cs) * ps[i] + csc * cv[i] / den : 0.;
+            ps[i] = v;
+            ssq += v * v;
+        }
+    } else {
+        for (int i = tid; i < ld; i += 256) {
+            double v = 0.;
+            if (i < c.n) {
+                double acc = 0.;
+                for (int j = 0; j < c.n; j++) acc += isc[(size_t) j * ld + i] * dm[j];
+                v = (1. - c.cs) * ps[i] + csc * acc / den;
+            }
+            ps[i] = v;
+            ssq += v * v;
+        }
     }
     ssq = wave_sum(ssq);
     if ((tid & 63) == 0) red[tid >> 6] = ssq;
@@ -1277,6 +1336,11 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
     const CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     if (mode == 0 && !sc->eigen_done) return;
+    if (mode == 3 && !sc->basis_ok) return;
+    // modes: 0 after a decomposition, 1 after B or D were set, 2 pack the operands of the C^-1/2
+    // that is there (init), 3 only C^-1/2 of the current basis (a reader asked for it while the
+    // engine runs with lazy_isc: cma_paths then works from B and D and nothing else needs it)
+    const bool gemm = mode == 3 || (mode != 2 && !c.lazy_isc);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ld = c.ld, n = c.n, ldp = ld + 2;
     double *Bs = lds, *Dv = lds + ld * ldp;
@@ -1311,7 +1375,7 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
     const int fr = lane & 15, fk = lane >> 4;
     const int wb = blockIdx.y;            // workgroup wb of NBW: tile rows wb, wb + NBW, ...
     constexpr int NR = 8 / NBW;           // tile rows per workgroup (NBW = 4: 2, NBW = 1: 8)
-    if (mode != 2 && NBW == 1) {
+    if (gemm && NBW == 1) {
         // one workgroup per population: wavefront w owns tile ROWS w, w + 4 and sweeps all eight
         // column tiles, so the divisions B[i][k] / D[k] (the reference's term order, kept) are
         // made once per row and k-step, not once per wavefront
@@ -1354,7 +1418,7 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
             }
         }
     }
-    if (mode != 2 && NBW != 1) {
+    if (gemm && NBW != 1) {
         // wavefront w: column tiles w, w + 4 of this workgroup's tile rows
         d4_t acc[NR][2];
 #pragma unroll
@@ -1397,6 +1461,7 @@ __global__ __launch_bounds__(256) void cma_post_mfma(CmaDev d, CmaConst c, int m
             }
         }
     }
+    if (mode == 3) return;
     if (mode != 2 && tid == 0 && wb == 0) d.scal[p].basis_ok = 1;
     // packed operands: element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
     const int q0 = wb * (ld * ld / NBW), q1 = q0 + ld * ld / NBW;   // this workgroup's share

@@ -766,6 +766,23 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         sc->eigenlastev = sc->fev;
         sc->eigen_done = 1;
     }
+    if (use_dc && pl.reg_path && c.lazy_isc) {
+        // the sampler's packed operand B D straight from the LDS copy of B (what cma_post would
+        // re-read B for; C^-1/2 is not formed in this configuration, see CmaConst::lazy_isc):
+        // element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
+        __syncthreads();
+        for (int j = tid; j < n; j += T) dv[j] = sqrt(gv[j]);
+        __syncthreads();
+        double *BDp = d.BDp + (size_t) p * ld * ld;
+        const int KS = ld >> 2;
+        for (int q = tid; q < ld * ld; q += T) {
+            const int t4 = q >> 6, l = q & 63;
+            const int nt = t4 / KS, ks = t4 - nt * KS;
+            const int i = nt * 16 + (l & 15), j = 4 * ks + (l >> 4);
+            BDp[q] = (i < n && j < n) ? A(i, j) * dv[j] : 0.;
+        }
+        if (tid == 0) sc->basis_ok = 1;
+    }
     EIG_STAMP(5);
 #undef EIG_STAMP
 }
