@@ -469,7 +469,10 @@ void CmaEngine::launch_update()
         const size_t lds = (size_t) (2 * G128_CH * G128_LDY + 4 * G128_CH) * sizeof(double);
         allow_lds((const void*) cma_gram128, 80 * 1024);
         timer_.begin(stream_, K_GRAM);
-        hipLaunchKernelGGL(cma_gram128, dim3(c.splits, c.npop), dim3(256), lds, stream_, d_, c_);
+        if (d_.dbg & 512)   // (diagnostic: the LDS-staged form, same bits)
+            hipLaunchKernelGGL(cma_gram128, dim3(c.splits, c.npop), dim3(256), lds, stream_, d_, c_);
+        else
+            hipLaunchKernelGGL(cma_gram128s, dim3(c.splits, c.npop), dim3(256), 0, stream_, d_, c_);
         timer_.end(stream_);
         BBO_HIP(hipGetLastError());
     } else {

@@ -1105,6 +1105,171 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
 }
 
 // ---------------------------------------------------------------------------
+// The same Gram slab WITHOUT the shared LDS tile and its barriers: every wavefront loads the
+// fragments its tile set needs (5-6 of the 8 column tiles of a row) straight from X in MFMA
+// layout -- lane (fr, fk) of k-step ks reads X[base + 4 ks + fk][16 i + fr], 128-byte segments,
+// the re-reads of the four wavefronts served by L1/L2 -- and turns them into y = (x - m) / sigma
+// itself.  With cma_gram128 the chunk barrier cost a quarter of the kernel (measured by running
+// it without: 420 -> 305 us at M): two wavefronts per SIMD cannot cover a workgroup that waits.
+// Here the wavefronts of a workgroup never wait for each other; the loads run four k-steps
+// (~2300 cycles of MFMA) ahead in a register ring of four slots, the rank -> coefficient
+// look-ups a whole chunk ahead in a wavefront-private LDS strip.  Same products in the same
+// order: bit-identical to cma_gram128.
+// grid (splits, P), 256 threads, no dynamic LDS
+// ---------------------------------------------------------------------------
+template<int WV>
+__device__ __forceinline__ void gram128_stream(const CmaDev &d, const CmaConst &c, int p, int s,
+        double *coef, int lane)
+{
+    const CmaScal *sc = d.scal + p;
+    const double *Xp = d.X + (size_t) p * c.lambda_pad * 128;
+    const double *xold = d.xmean + (size_t) p * 128;
+    const int *rank = d.rank + (size_t) p * c.lambda_pad;
+    const double isig = 1. / sc->sigma;
+    const int row0 = s * c.rps;
+    const int nrows = min(c.rps, c.lambda_pad - row0);
+    const int nch = (nrows + G128_CH - 1) / G128_CH;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    double xo[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) xo[i] = g128_needs_y(WV, i) ? xold[16 * i + fr] : 0.;
+    d4_t acc[9];
+    double macc[8];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = d4_t { 0., 0., 0., 0. };
+#pragma unroll
+    for (int i = 0; i < 8; i++) macc[i] = 0.;
+
+    // raw X fragments, four k-steps deep: slot j holds k-step j, then j + 4 (reloaded as soon as
+    // it has been swept), then k-step j of the next chunk, ...
+    double ring[4][8];
+    const int lane_off = fk * 128 + fr;
+    auto load_step = [&](int ch, int ks, int slot) {
+        // four whole rows or none (lambda_pad is a multiple of 16): a uniform clamp keeps the
+        // loads unconditional and the address a scalar base + a per-lane constant; rows past the
+        // population carry zero coefficients in the sweep, whatever is loaded for them
+        const int blk = min(row0 + ch * G128_CH + 4 * ks, c.lambda_pad - 4);
+        const double *src = Xp + (size_t) blk * 128;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (g128_needs_y(WV, i)) ring[slot][i] = src[lane_off + 16 * i];
+    };
+    // Coefficients of a chunk's 32 rows (rank_coefficients, same arithmetic): lanes 0..31 look
+    // them up, the LDS strip hands them round.  The look-up is a chain of two dependent loads; it
+    // runs TWO chunks ahead, one link per chunk, branch-free with clamped indices -- the memory
+    // counter retires in order, so a load that is consumed long after it was issued costs no wait,
+    // while one consumed at once would drain the whole prefetch ring first.
+    const double cmu1 = c.variant == 1 ? c.cmu + c.cneg * (1. - c.alphaold) : c.cmu;
+    const double *Sp = d.S + (size_t) p * c.mu_pad;
+    int rk = 0;                           // link 1: the rank of the row (chunk ch + 2)
+    int rk2 = 0;                          // ... one chunk on, while link 2 is in flight
+    double wa = 0., sk = 1., sm = 1.;     // link 2: weights[.], S[k], S[mu - 1 - k] (chunk ch + 1)
+    auto coef_link1 = [&](int ch) {
+        const int row = row0 + ch * G128_CH + lane;
+        const bool ok = lane < G128_CH && ch < nch && row < c.lambda;
+        rk = rank[ok ? row : 0];
+        if (!ok) rk = -1;
+    };
+    auto coef_link2 = [&]() {             // from the rank loaded one chunk ago
+        rk2 = rk;
+        const bool pos = rk2 >= 0 && rk2 < c.mu;
+        const int k = min(max(c.lambda - 1 - rk2, 0), c.mu - 1);
+        wa = d.weights[pos ? rk2 : k];
+        sk = Sp[k];
+        sm = Sp[c.mu - 1 - k];
+    };
+    auto put_coef = [&](int buf) {        // from the values loaded one chunk ago
+        double pv = 0., pw = 0.;
+        if (rk2 >= 0 && rk2 < c.mu) {
+            pw = wa;
+            pv = cmu1 * wa;
+        } else if (rk2 >= 0 && c.variant == 1 && rk2 >= c.lambda - c.mu) {
+            const double ycoeff = sk / fmax(sm, 1e-8);
+            pv = -c.cneg * wa * ycoeff;
+        }
+        if (lane < G128_CH) {
+            coef[buf * 2 * G128_CH + lane] = pv;
+            coef[buf * 2 * G128_CH + G128_CH + lane] = pw;
+        }
+    };
+    auto sweep_step = [&](int slot, double vk, double wk) {
+        double y[8], a[8];
+        // (no masks: columns >= n are zero in X and in the mean alike, rows >= lambda have
+        // v = w = 0 -- cma_gram128 zeroes y there instead, the products are the same zeros)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            y[i] = a[i] = 0.;
+            if (g128_needs_y(WV, i)) y[i] = (ring[slot][i] - xo[i]) * isig;
+            if (g128_needs_a(WV, i)) a[i] = vk * y[i];
+        }
+        if (WV == 1 || WV == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (g128_mean(WV, i)) macc[i] = fma(wk, y[i], macc[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[G128_TI[WV][t]], y[G128_TJ[WV][t]],
+                    acc[t], 0, 0, 0);
+    };
+
+    // prologue: coefficients of chunks 0 and 1, the first four k-steps
+    coef_link1(0);
+    coef_link2();
+    put_coef(0);
+    coef_link1(1);
+    coef_link2();                         // (chunk 1's values: written to the strip at the end of chunk 0)
+    coef_link1(2);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) load_step(0, ks, ks);
+    cma_wave_sync();
+    for (int ch = 0; ch < nch; ch++) {
+        const int buf = ch & 1;
+        // (this k-step's coefficients were read from the strip a k-step ago: with the scheduling
+        // barrier below the LDS latency would otherwise sit in front of every k-step)
+        double vk = coef[buf * 2 * G128_CH + fk], wk = coef[buf * 2 * G128_CH + G128_CH + fk];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            double vn = 0., wn = 0.;
+            if (ks < 7) {
+                vn = coef[buf * 2 * G128_CH + 4 * (ks + 1) + fk];
+                if (WV == 1 || WV == 2) wn = coef[buf * 2 * G128_CH + G128_CH + 4 * (ks + 1) + fk];
+            }
+            sweep_step(ks & 3, vk, wk);
+            vk = vn;
+            wk = wn;
+            if (ks < 4) load_step(ch, ks + 4, ks & 3);
+            else load_step(ch + 1, ks - 4, ks & 3);
+            // (keeps a slot's subtraction next to ITS k-step: hoisted to the top of the chunk, as
+            // the scheduler would, the four slots are waited for at once and nothing is ahead)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        put_coef(buf ^ 1);                // chunk ch + 1, loaded during chunk ch - 1 / the prologue
+        coef_link2();                     // chunk ch + 2, from the rank loaded a chunk ago
+        coef_link1(ch + 3);
+        cma_wave_sync();
+    }
+    double *G = d.gram_part + ((size_t) p * c.splits + s) * 128 * 128;
+    double *mp = d.mean_part + ((size_t) p * c.splits + s) * 128;
+    gram128_store<WV>(G, mp, acc, macc, lane);
+}
+
+__global__ __launch_bounds__(256, 2) void cma_gram128s(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y, s = blockIdx.x;
+    if (pop_frozen(c, d.scal + p)) return;
+    __shared__ double coef[4][2 * 2 * G128_CH];      // per wavefront: [buffer][v | w][row of chunk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    switch (wave) {
+    case 0: gram128_stream<0>(d, c, p, s, coef[0], lane); break;
+    case 1: gram128_stream<1>(d, c, p, s, coef[1], lane); break;
+    case 2: gram128_stream<2>(d, c, p, s, coef[2], lane); break;
+    default: gram128_stream<3>(d, c, p, s, coef[3], lane); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, int p)

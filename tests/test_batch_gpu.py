@@ -168,3 +168,26 @@ def test_lean_separable_sampler_equals_the_general_one(hip):
     for a, b in zip(runs[0], runs[1]):
         for u, v in zip(a, b):
             np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.parametrize("variant,n,lam,P", [("ActiveCMAES", 128, 4096, 8), ("ActiveCMAES", 128, 1000, 16),
+                                             ("CMAES", 120, 300, 40)])
+def test_streaming_gram_equals_the_lds_staged_one(hip, variant, n, lam, P):
+    """cma_gram128s (every wavefront loads its own MFMA fragments from X, no LDS tile, no
+    barrier) against cma_gram128 (diagnostic bit 512): the same products in the same order, so C,
+    the mean and everything downstream are BIT-IDENTICAL -- full and ragged shapes (lambda not a
+    multiple of the chunk, n < ld)."""
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = np.random.default_rng(4).uniform(-10, 10, (P, n))
+    runs = []
+    for dbg in (0, 512):
+        g = getattr(hip, variant)(mfev=10 ** 9, tol=0., np=lam, seed=79, populations=P)
+        g.initialize(hip.objectives.rosenbrock, lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [float(dbg)])
+        g.run(4)
+        runs.append([(g.get_state("C", p), g.get_state("xmean", p), g.get_state("sigma", p),
+                      g.get_state("arx", p)) for p in (0, P - 1)])
+    for a, b in zip(runs[0], runs[1]):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
