@@ -447,13 +447,18 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
             }
 #pragma unroll
             for (int i = 0; i < 32; i++) zz = __builtin_fma(z[i], z[i], zz);
+            // (two bases, 64 KB apart: every operand read then is base + a 16-bit immediate; from
+            // one base the upper half costs a vector add per read)
+            int hi = lane + 8192;
+            asm volatile("" : "+v"(hi));          // (opaque: keeps the second base in its register)
 #pragma unroll
             for (int i = 0; i < 32; i++) {
-                const double *bk = bd + (i >> 3) * 8 * 64 + lane;
 #pragma unroll
-                for (int t = 0; t < 8; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[i], bk[(t * 32 + (i & 7)) * 64],
-                            acc[t], 0, 0, 0);
+                for (int t = 0; t < 8; t++) {
+                    const int idx = (i >> 3) * 8 + t * 32 + (i & 7);      // fragment number
+                    const double bv = idx < 128 ? bd[lane + idx * 64] : bd[hi + (idx - 128) * 64];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[i], bv, acc[t], 0, 0, 0);
+                }
                 // (keeps the scheduler from hoisting the operand loads of all 32 k-steps at once)
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
