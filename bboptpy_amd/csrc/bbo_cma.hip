@@ -487,7 +487,10 @@ void CmaEngine::launch_update()
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_PATHS);
-    hipLaunchKernelGGL(cma_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
+    if (c.lazy_isc)
+        hipLaunchKernelGGL(cma_paths_lazy, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
+    else
+        hipLaunchKernelGGL(cma_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     {

@@ -1277,6 +1277,7 @@ __global__ __launch_bounds__(256, 2) void cma_gram128s(CmaDev d, CmaConst c)
 // ---------------------------------------------------------------------------
 // paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
 // ---------------------------------------------------------------------------
+template<bool LAZY = false>     // LAZY: c.lazy_isc configurations (C^-1/2 dm from B and D)
 __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, int p)
 {
     CmaScal *sc = d.scal + p;
@@ -1311,7 +1312,7 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
     const double den = c.variant == 1 ? c.cm * sigma : sigma;
     const double *isc = d.isc + (size_t) p * ld * ld;
     double ssq = 0.;
-    if (c.lazy_isc && sc->basis_ok) {
+    if (LAZY && sc->basis_ok) {
         // C^-1/2 dm = B (D^-1 (B^T dm)) from the basis itself: 2 n^2 operations instead of the
         // n^3 of forming C^-1/2 after every decomposition (cma_post then only packs B D)
         __shared__ double sv[128], cv[128], part[128];
@@ -1412,7 +1413,11 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
 
 __global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
 {
-    paths_body(d, c, blockIdx.x);
+    paths_body<false>(d, c, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void cma_paths_lazy(CmaDev d, CmaConst c)
+{
+    paths_body<true>(d, c, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
