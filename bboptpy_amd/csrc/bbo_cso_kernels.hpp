@@ -105,19 +105,31 @@ __global__ __launch_bounds__(256) void cso_colsum(CsoDev d, CsoConst c, int step
     const int per = (count + c.parts - 1) / c.parts;
     const int q0 = part * per, q1 = min(count, q0 + per);
     const size_t pb = (size_t) p * c.np;
-    for (int j = threadIdx.x; j < c.ld; j += 256) {
-        double s = 0.;
+    // two columns per thread (16-byte loads; ld is a multiple of 16), every column summed over the
+    // rows in the same order as before
+    for (int j = 2 * threadIdx.x; j < c.ld; j += 512) {
+        double s0 = 0., s1 = 0.;
         int q = q0;
         for (; q + 8 <= q1; q += 8) {          // eight independent row reads in flight
-            double x[8];
+            double2 x[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                x[u] = d.X[(pb + d.occ[pb + (size_t) (q + u) * step]) * c.ld + j];
+                x[u] = *reinterpret_cast<const double2*>(
+                        &d.X[(pb + d.occ[pb + (size_t) (q + u) * step]) * c.ld + j]);
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += x[u];
+            for (int u = 0; u < 8; u++) {
+                s0 += x[u].x;
+                s1 += x[u].y;
+            }
         }
-        for (; q < q1; q++) s += d.X[(pb + d.occ[pb + (size_t) q * step]) * c.ld + j];
-        d.colpart[((size_t) p * c.parts + part) * c.ld + j] = s;
+        for (; q < q1; q++) {
+            const double2 x = *reinterpret_cast<const double2*>(
+                    &d.X[(pb + d.occ[pb + (size_t) q * step]) * c.ld + j]);
+            s0 += x.x;
+            s1 += x.y;
+        }
+        *reinterpret_cast<double2*>(&d.colpart[((size_t) p * c.parts + part) * c.ld + j]) =
+                make_double2(s0, s1);
     }
 }
 

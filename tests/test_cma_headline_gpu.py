@@ -160,3 +160,63 @@ def test_c3_batched_matches_oracle(hip, oracle_lib):
     guess = rng.uniform(-10, 10, (P, n))
     _run_against_oracle(hip, oracle_lib, n, lam, P, [0, 17, 63], 4, "rosenbrock", False, 5,
                         lo, up, guess)
+
+
+@pytest.mark.parametrize("n,lam,obj", [(128, 512, "rosenbrock"), (128, 4096, "ellipsoid"),
+                                       (64, 200, "rosenbrock")])
+def test_eigen_to_sample_coupling_with_the_oracles_own_basis(hip, oracle_lib, n, lam, obj):
+    """The phase tests above hand the device's (B, D, C^-1/2) to the oracle every generation, so
+    what the NEXT generation samples through is only checked by invariants.  Here the oracle
+    keeps the basis its OWN decomposition produced (the reference's tred2 + tql2 restated) and
+    only the SIGNS of its eigenvector columns are aligned with the device's (an eigenvector is
+    defined up to its sign, and for n > 16 the divide and conquer's convention is not tql2's):
+    the oracle then samples x = m + sigma B D z from the device's recorded z through its own B
+    and D, and candidates, ranking, mean, step size and covariance must keep agreeing over
+    several generations -- the eigensolver's output, values and all, is what couples them.
+    Tolerance: eigenvectors of a matrix with relative eigenvalue gaps g carry eps / g of
+    rounding (smallest g of these runs: 2e-5 .. 8e-4, scripts/dev_coupling_err.py): measured
+    <= 1.1e-11 on B, 3.4e-12 on the candidates, 1.7e-12 on the mean and 1.2e-13 on C over eight
+    generations; asserted at 1e-9 (1e-10 for C and D)."""
+    from bboptpy_amd import _ffi
+    rng = np.random.default_rng(n + lam)
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = rng.uniform(-5, 5, n)
+    g = hip.ActiveCMAES(mfev=10 ** 9, tol=1e-14, np=lam, seed=99)
+    g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+    g.set_state("record_normals", [1.0])
+    o = po.cma(oracle_lib, "active", 10 ** 9, 1e-14, lam)
+    o.set_rng(po.RNG_INJECT)
+    o.init(obj, lo, up, guess)
+    for gen in range(8):
+        Bd = g.get_state("B").reshape(n, n)
+        Bo = o.get("B").reshape(n, n)
+        sg = np.sign(np.sum(Bd * Bo, axis=0))
+        assert np.all(sg != 0)
+        o.set("B", (Bo * sg[None, :]).ravel())        # signs only: the values stay the oracle's
+        tol = 1e-9
+        _close(Bd, Bo * sg[None, :], tol, "B up to signs, gen %d" % gen)
+        g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+        o.inject_z(g.get_state("zlast"))
+        o.step("sample")
+        o.step("evaluate_sort")
+        _close(g.get_state("arx"), o.get("arx"), tol, "arx gen %d" % gen)
+        g.phase(_ffi.PHASE_RANK)
+        fo = o.get("fit_val")
+        _close(g.get_state("fit_val"), fo, tol, "sorted fitness gen %d" % gen)
+        if not np.array_equal(g.get_state("fit_idx").astype(int), o.get("fit_idx").astype(int)):
+            bad = np.nonzero(g.get_state("fit_idx").astype(int) != o.get("fit_idx").astype(int))[0]
+            near = np.minimum(np.abs(fo[bad] - fo[np.maximum(bad - 1, 0)]),
+                              np.abs(fo[bad] - fo[np.minimum(bad + 1, fo.size - 1)]))
+            assert np.all(near <= 100 * tol * np.abs(fo[bad]) + 1e-300)
+            pytest.skip("two candidates tie to the accuracy of the basis: ranking not comparable")
+        g.phase(_ffi.PHASE_UPDATE)
+        g.phase(_ffi.PHASE_EIGEN)
+        g.phase(_ffi.PHASE_HISTORY_STOP)
+        o.step("update_distribution")
+        o.step("update_history")
+        _close(g.get_state("xmean"), o.get("xmean"), tol, "xmean gen %d" % gen)
+        _close(g.get_state("sigma"), o.get("sigma"), tol, "sigma gen %d" % gen)
+        _close(np.tril(g.get_state("C").reshape(n, n)), np.tril(o.get("C").reshape(n, n)),
+               1e-10, "C gen %d" % gen)
+        _close(g.get_state("D"), o.get("D"), 1e-10, "D gen %d" % gen)
+    o.destroy()
