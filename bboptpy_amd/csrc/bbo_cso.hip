@@ -90,6 +90,11 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     mean_.alloc(P * ld);
     meanw_.alloc(P * ld);
     colpart_.alloc((size_t) P * c.parts * ld);
+    // the swarm mean from cso_compete's own sums where a lane's share of a row is at most four
+    // column pairs (ld <= 512 with up to 64 lanes per group) and the global mean is what is used
+    fuse_g_ = (c.ring || c.ld > 512) ? 0 : c.ld <= 128 ? 16 : c.ld <= 256 ? 32 : 64;
+    c.nwg = fuse_g_ ? (c.ngroup + 256 / fuse_g_ - 1) / (256 / fuse_g_) : 1;
+    wgpart_.alloc(fuse_g_ ? (size_t) P * c.nwg * ld : 1);
     fpart_.alloc((size_t) P * c.fparts * CSO_FPART);
     lower_.alloc(ld);
     upper_.alloc(ld);
@@ -116,6 +121,7 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     d.X = X_.p; d.V = V_.p; d.PM = PM_.p; d.f = f_.p; d.radius = radius_.p;
     d.occ = occ_.p; d.occ2 = occ2_.p;
     d.mean = mean_.p; d.meanw = meanw_.p; d.colpart = colpart_.p; d.fpart = fpart_.p;
+    d.wgpart = wgpart_.p;
     d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
     c.honor_stop = 0;
     inited_ = true;
@@ -127,6 +133,13 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     if (!obj_.on_device()) host_evaluate(false);
     hipLaunchKernelGGL(cso_finish_part, dim3(c_.fparts, P), dim3(256), 0, stream_, d_, c_);
     hipLaunchKernelGGL(cso_finish, dim3(P), dim3(64), 0, stream_, d_, c_, 1);
+    if (fuse_g_) {      // the sums cso_compete maintains from now on, of the initial swarm
+        const size_t lds = (size_t) (256 / fuse_g_) * c.ld * sizeof(double);
+        const dim3 grid(c.nwg, P);
+        if (fuse_g_ == 16) hipLaunchKernelGGL(cso_team_colsum<16>, grid, dim3(256), lds, stream_, d_, c_);
+        else if (fuse_g_ == 32) hipLaunchKernelGGL(cso_team_colsum<32>, grid, dim3(256), lds, stream_, d_, c_);
+        else hipLaunchKernelGGL(cso_team_colsum<64>, grid, dim3(256), lds, stream_, d_, c_);
+    }
     BBO_HIP(hipGetLastError());
     BBO_HIP(hipStreamSynchronize(stream_));
 }
@@ -165,6 +178,9 @@ void CsoEngine::generation(bool honor_stop)
     timer_.begin(stream_, K_MEAN);
     if (c.ring) {
         hipLaunchKernelGGL(cso_ring_mean, dim3((c.np + 15) / 16, P), dim3(256), 0, stream_, d_, c_);
+    } else if (fuse_g_) {
+        hipLaunchKernelGGL(cso_wgsum, dim3(c.parts, P), dim3(256), 0, stream_, d_, c_);
+        hipLaunchKernelGGL(cso_mean, dim3(P), dim3(256), 0, stream_, d_, c_, 0, c.np);
     } else {
         hipLaunchKernelGGL(cso_colsum, dim3(c.parts, P), dim3(256), 0, stream_, d_, c_, 1, c.np);
         hipLaunchKernelGGL(cso_mean, dim3(P), dim3(256), 0, stream_, d_, c_, 0, c.np);
@@ -188,9 +204,20 @@ void CsoEngine::generation(bool honor_stop)
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_COMPETE);
-    const int R = rows_per_wg16(c.ld);     // groups staged in LDS per workgroup
-    hipLaunchKernelGGL(cso_compete, dim3((c.ngroup + R - 1) / R, P), dim3(16 * R),
-            (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
+    if (fuse_g_) {
+        const size_t lds = (size_t) (256 / fuse_g_) * c.ld * sizeof(double);
+        const dim3 grid(c.nwg, P);
+        if (fuse_g_ == 16)
+            hipLaunchKernelGGL((cso_compete<16, true>), grid, dim3(256), lds, stream_, d_, c_);
+        else if (fuse_g_ == 32)
+            hipLaunchKernelGGL((cso_compete<32, true>), grid, dim3(256), lds, stream_, d_, c_);
+        else
+            hipLaunchKernelGGL((cso_compete<64, true>), grid, dim3(256), lds, stream_, d_, c_);
+    } else {
+        const int R = rows_per_wg16(c.ld);     // groups staged in LDS per workgroup
+        hipLaunchKernelGGL((cso_compete<16, false>), dim3((c.ngroup + R - 1) / R, P), dim3(16 * R),
+                (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
+    }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) host_evaluate(true);

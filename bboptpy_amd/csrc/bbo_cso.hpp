@@ -22,6 +22,7 @@ struct CsoScal {
 
 struct CsoConst {
     int n, ld, np, pc, ngroup, ring, correct, obj, mfev, honor_stop, npop, parts, fparts;
+    int nwg;                  // workgroups of the fused cso_compete per population (rows of wgpart)
     double stol, vmax, phil, phih;
     uint64_t seed;
 };
@@ -32,6 +33,7 @@ struct CsoDev {
     int *occ, *occ2;         // [P][np] slot -> row: current order, and scratch for the shuffle
     double *mean, *meanw;    // [P][ld] swarm mean, winners' mean
     double *colpart;         // [P][parts][ld]
+    double *wgpart;          // [P][nwg][ld] column sums per cso_compete workgroup (fused swarm mean)
     double *fpart;           // [P][fparts][5] slab results of cso_finish_part
     const double *lower, *upper, *aux;
     CsoScal *scal;
@@ -64,7 +66,8 @@ private:
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
     std::vector<double> aux_h_;
-    DevBuf<double> X_, V_, PM_, f_, radius_, mean_, meanw_, colpart_, fpart_, lower_, upper_, aux_;
+    DevBuf<double> X_, V_, PM_, f_, radius_, mean_, meanw_, colpart_, wgpart_, fpart_, lower_, upper_, aux_;
+    int fuse_g_ = 0;            // > 0: lanes per group of cso_compete, which then maintains the swarm mean's sums
     DevBuf<int> occ_, occ2_;
     DevBuf<CsoScal> scal_;
     KernelTimer timer_;

@@ -24,6 +24,14 @@ __device__ inline bool cso_frozen(const CsoConst &c, const CsoScal *sc)
     return c.honor_stop && sc->stop != 0;
 }
 
+// orders a wavefront's LDS accesses among its own lanes (hardware keeps them in order; the fence
+// stops the compiler from moving loads across the point)
+__device__ inline void cso_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template<int G>
 __device__ inline double cso_group_sum(double v)
 {
@@ -197,19 +205,43 @@ __global__ __launch_bounds__(256) void cso_groups(CsoDev d, CsoConst c)
 // the losers of 16 groups per workgroup, 16 lanes per group, worst first (each learns from the
 // next better particle of its group BEFORE that one moves, cso.cpp:222-228).
 // grid (ceil(ngroup/16), P), 256 threads, LDS 16 * ld doubles
+// the workgroup's team rows (LDS, `teams` x ld) summed in team order -> wgpart[p][blockIdx.x]
+__device__ inline void cso_team_rows_to_wgpart(const CsoDev &d, const CsoConst &c, int p,
+        const double *lds, int teams)
+{
+    const int ld = c.ld;
+    double *dst = d.wgpart + ((size_t) p * c.nwg + blockIdx.x) * ld;
+    for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+        double sum = lds[j];
+        for (int rr = 1; rr < teams; rr++) sum += lds[rr * ld + j];
+        dst[j] = sum;
+    }
+}
+
+// G lanes per group (16, 32 or 64: one or several groups per wavefront), blockDim.x / G groups
+// per workgroup.  FUSE (the host picks G so that a lane owns at most four column pairs, i.e.
+// ld <= 8 G): the kernel also leaves the column sums of ALL rows of its groups -- the losers'
+// new positions and the winners -- in wgpart[p][workgroup][ld], from which the next generation
+// takes the swarm mean (cso_wgsum + cso_mean) instead of reading the whole swarm again (a quarter
+// of the generation's HBM traffic).  Per column: a team adds its group's rows from the worst
+// loser up to the winner, the workgroup its teams in order.
+template<int G, bool FUSE>
 __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
 {
     const int p = blockIdx.y;
     const CsoScal *sc = d.scal + p;
     if (cso_frozen(c, sc)) return;
     extern __shared__ double lds[];
-    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int gI = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld, n = c.n, gen = sc->gen;
+    const int tid = threadIdx.x, r = tid / G, g = tid % G;
+    const int gI = blockIdx.x * (blockDim.x / G) + r, ld = c.ld, n = c.n, gen = sc->gen;
     const bool live = gI < c.ngroup;
     double *trial = lds + r * ld;
     const size_t pb = (size_t) p * c.np;
     const int *occ = d.occ + pb + (size_t) (live ? gI : 0) * c.pc;
     const double *gmean = d.mean + (size_t) p * ld, *wmean = d.meanw + (size_t) p * ld;
+    double2 csum[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) csum[u] = make_double2(0., 0.);
     for (int k = c.pc - 1; k >= 1; k--) {
         const int slot = gI * c.pc + k;
         const int row = occ[k], prow = occ[k - 1];
@@ -224,11 +256,11 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
             const uint32_t swr = stream_word(STREAM_PSO_R, (uint32_t) p);
             // four column pairs per lane at a time, their sixteen row loads issued first
             const int npair = ld >> 1;
-            for (int pj0 = g; pj0 < npair; pj0 += 64) {
+            for (int pj0 = g; pj0 < npair; pj0 += 4 * G) {
                 double2 xi4[4], vi4[4], pa4[4], me4[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int pj = pj0 + 16 * u;
+                    const int pj = pj0 + G * u;
                     const int j = pj < npair ? 2 * pj : 0;
                     xi4[u] = *reinterpret_cast<const double2*>(&x[j]);
                     vi4[u] = *reinterpret_cast<const double2*>(&v[j]);
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int pj = pj0 + 16 * u;
+                    const int pj = pj0 + G * u;
                     if (pj >= npair) continue;
                     const int j = 2 * pj;
                     const double2 xi = xi4[u], vi = vi4[u], pa = pa4[u], me = me4[u];
@@ -272,14 +304,22 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
                     *reinterpret_cast<double2*>(&v[j]) = vn;
                     *reinterpret_cast<double2*>(&trial[j]) = xn;
                     ssq += xn.x * xn.x + xn.y * xn.y;
+                    if (FUSE) {                  // (one pass over the row: u names the column pair)
+                        csum[u].x += xn.x;
+                        csum[u].y += xn.y;
+                        if (k == 1) {            // the winner's row is this loser's parent
+                            csum[u].x += pa.x;
+                            csum[u].y += pa.y;
+                        }
+                    }
                 }
             }
         }
-        __syncthreads();
-        ssq = cso_group_sum<16>(ssq);
+        cso_wave_sync();          // (a team sits inside one wavefront: its row is its own)
+        ssq = cso_group_sum<G>(ssq);
         double f = CSO_INF;
         if (c.obj >= 0) {
-            f = eval_row_group<16>(c.obj, n, trial, d.aux, g);
+            f = eval_row_group<G>(c.obj, n, trial, d.aux, g);
             if (f != f) f = CSO_INF;
         }
         if (live && g == 0) {
@@ -287,8 +327,72 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
             d.radius[pb + row] = sqrt(ssq);
         }
         // the next (better) loser of this group reads x of its own parent only; its own row
-        // was last written in an earlier generation.  The barrier orders the LDS reuse.
+        // was last written in an earlier generation.  The wavefront barrier orders the LDS reuse.
+        cso_wave_sync();
+    }
+    if (FUSE) {
+        // the teams' sums through their (now free) LDS rows, then the workgroup's teams in order
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pj = g + G * u;
+            if (pj < (ld >> 1))
+                *reinterpret_cast<double2*>(&trial[2 * pj]) = live ? csum[u] : make_double2(0., 0.);
+        }
         __syncthreads();
+        cso_team_rows_to_wgpart(d, c, p, lds, blockDim.x / G);
+    }
+}
+
+// The same sums from the swarm as it stands (after cso_init: no cso_compete has run yet), in the
+// same order: a team adds its group's rows from the last slot of the group up to the first, the
+// workgroup its teams in order.  grid (nwg, P), 256 threads, LDS (256 / G) * ld doubles
+template<int G>
+__global__ __launch_bounds__(256) void cso_team_colsum(CsoDev d, CsoConst c)
+{
+    const int p = blockIdx.y;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, r = tid / G, g = tid % G, ld = c.ld;
+    const int gI = blockIdx.x * (blockDim.x / G) + r;
+    const bool live = gI < c.ngroup;
+    const size_t pb = (size_t) p * c.np;
+    const int *occ = d.occ + pb + (size_t) (live ? gI : 0) * c.pc;
+    double *trial = lds + r * ld;
+    for (int pj = g; pj < (ld >> 1); pj += G) {
+        double2 sum = make_double2(0., 0.);
+        if (live)
+            for (int k = c.pc - 1; k >= 0; k--) {
+                const double2 x = *reinterpret_cast<const double2*>(
+                        &d.X[(pb + occ[k]) * ld + 2 * pj]);
+                sum.x += x.x;
+                sum.y += x.y;
+            }
+        *reinterpret_cast<double2*>(&trial[2 * pj]) = sum;
+    }
+    __syncthreads();
+    cso_team_rows_to_wgpart(d, c, p, lds, blockDim.x / G);
+}
+
+// colpart[p][part] = the workgroup sums [part * per, (part + 1) * per) of wgpart, in order
+// (cso_mean finishes).  grid (parts, P), 256 threads
+__global__ __launch_bounds__(256) void cso_wgsum(CsoDev d, CsoConst c)
+{
+    const int p = blockIdx.y, part = blockIdx.x;
+    if (cso_frozen(c, d.scal + p)) return;
+    const int per = (c.nwg + c.parts - 1) / c.parts;
+    const int q0 = part * per, q1 = min(c.nwg, q0 + per);
+    const double *src = d.wgpart + (size_t) p * c.nwg * c.ld;
+    for (int j = threadIdx.x; j < c.ld; j += 256) {
+        double s = 0.;
+        int q = q0;
+        for (; q + 8 <= q1; q += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = src[(size_t) (q + u) * c.ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += x[u];
+        }
+        for (; q < q1; q++) s += src[(size_t) q * c.ld + j];
+        d.colpart[((size_t) p * c.parts + part) * c.ld + j] = s;
     }
 }
 

@@ -77,8 +77,13 @@ CCPSO_KERNELS = ["ccp_regroup", "ccp_eval", "ccp_update", "ccp_position", "ccp_f
 def cso_kernel_costs(n, np_, P, pc=3):
     """CSO (bbo_cso_kernels.hpp): streaming passes; the learning step moves np (pc-1)/pc losers"""
     losers = np_ * (pc - 1) // pc
+    # n <= 512 (the benchmark's CSO): the swarm mean comes from the column sums cso_compete leaves
+    # per workgroup (4 groups each at 256 < n <= 512), not from another pass over the swarm
+    ld = (n + 15) // 16 * 16
+    lanes = 16 if ld <= 128 else 32 if ld <= 256 else 64
+    nwg = -(-(np_ // pc) // (256 // lanes))
     return {
-        "cso_mean": ("hbm", P * np_ * 8 * n),
+        "cso_mean": ("hbm", P * (nwg if ld <= 512 else np_) * 8 * n),
         "cso_shuffle": ("hbm", P * np_ * 24),
         "cso_groups": ("hbm", P * (np_ * 16 + (np_ // pc) * 8 * n)),
         "cso_compete": ("hbm", P * losers * (48 * n + 8)),
