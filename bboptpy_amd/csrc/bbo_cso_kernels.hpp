@@ -149,6 +149,14 @@ __global__ __launch_bounds__(256) void cso_mean(CsoDev d, CsoConst c, int winner
     for (int j = threadIdx.x; j < c.ld; j += 256) {
         double s = 0.;
         int q = 0;
+        // (four workgroups in all: what this kernel costs is load latency, so many loads at once)
+        for (; q + 32 <= c.parts; q += 32) {
+            double x[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) x[u] = d.colpart[((size_t) p * c.parts + q + u) * c.ld + j];
+#pragma unroll
+            for (int u = 0; u < 32; u++) s += x[u];
+        }
         for (; q + 8 <= c.parts; q += 8) {
             double x[8];
 #pragma unroll
