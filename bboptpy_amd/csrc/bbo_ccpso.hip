@@ -194,17 +194,17 @@ void CcpsoEngine::launch_regroup_eval()
     hipLaunchKernelGGL(ccp_regroup, dim3(P), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
-    // the largest candidate count any subset size can ask for (the device knows the real one)
+    // the largest swarm count any subset size can ask for (the device knows the real one)
     int cpmin = c.pps[0];
     for (int k = 1; k < c.npps; k++) cpmin = std::min(cpmin, c.pps[k]);
-    const int maxcand = 2 * (c.n / cpmin) * c.np;
+    const int maxswarm = c.n / cpmin;
     timer_.begin(stream_, K_EVAL);
     if (obj_.on_device()) {
         if (c.ld <= 256)
-            hipLaunchKernelGGL(ccp_eval<16>, dim3((maxcand + 15) / 16, P), dim3(256),
+            hipLaunchKernelGGL(ccp_eval<16>, dim3((CCP_SPLIT * maxswarm + 15) / 16, P), dim3(256),
                     (size_t) 16 * c.ld * sizeof(double), stream_, d_, c_);
         else
-            hipLaunchKernelGGL(ccp_eval<64>, dim3((maxcand + 3) / 4, P), dim3(256),
+            hipLaunchKernelGGL(ccp_eval<64>, dim3((CCP_SPLIT * maxswarm + 3) / 4, P), dim3(256),
                     (size_t) 4 * c.ld * sizeof(double), stream_, d_, c_);
     } else {
         host_eval_candidates();

@@ -137,9 +137,25 @@ __global__ __launch_bounds__(256) void ccp_regroup(CcpDev d, CcpConst c)
     for (int j = tid; j < c.ld; j += 256) d.ysave[(size_t) p * c.ld + j] = d.yhat[(size_t) p * c.ld + j];
 }
 
+// orders a wavefront's LDS accesses among its own lanes
+__device__ inline void ccp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // candidate (j, i, which): yhat with the coordinates of swarm j taken from X_i (which = 0) or
-// Y_i (1).  G lanes per candidate, 256 / G candidates per workgroup, LDS (256/G) * ld doubles.
-// grid (ceil(2 * nswarm_max * np / (256/G)), P) -- candidates past 2 nswarm np return
+// Y_i (1) -- ccpso.cpp:241-260, 2 np nswarm context evaluations per generation.  CCP_SPLIT TEAMS
+// of G lanes per SWARM j: a team stages yhat in its LDS row once and then walks its share of the
+// swarm's 2 np candidates, which all replace the SAME coordinates -- a candidate costs the gather of its cp
+// values and one evaluation, not a copy of the n-vector (the form with one team per candidate
+// spent its time staging 8 KB per evaluation: 749 us per generation at n = 1000 against
+// the figure in DESIGN.md section 3).  The values in the row and the reduction are what they
+// were: f is bit-identical.  Teams sit inside one wavefront: syncs at wavefront scope.
+// grid (ceil(CCP_SPLIT nswarm_max / (256/G)), P), 256 threads, LDS (256/G) * ld doubles -- swarms past
+// nswarm, or outside this rank's shard [nswarm r / W, nswarm (r + 1) / W), return
+constexpr int CCP_SPLIT = 4;          // teams per swarm (candidate t goes to team t mod CCP_SPLIT)
+
 template<int G>
 __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
 {
@@ -148,35 +164,52 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
     if (ccp_frozen(c, sc)) return;
     extern __shared__ double lds[];
     constexpr int R = 256 / G;
+    constexpr int MAXQ = 256 / G;                // a swarm has at most 256 coordinates
     const int tid = threadIdx.x, r = tid / G, g = tid % G;
-    const int cand = blockIdx.x * R + r, ld = c.ld, np = c.np;
+    const int team = blockIdx.x * R + r, ld = c.ld, np = c.np;
+    const int j = team / CCP_SPLIT, part = team - j * CCP_SPLIT;
     const int nswarm = sc->nswarm, cp = sc->cpswarm;
-    if (blockIdx.x * R >= 2 * nswarm * np) return;   // the grid is sized for the smallest subset size
-    // swarm groups sharded over ranks: candidates are swarm-major, so this rank's swarms
-    // [nswarm r / W, nswarm (r + 1) / W) are one contiguous candidate range
-    const int clo = 2 * np * (int) ((long) nswarm * c.shard_rank / c.shard_world);
-    const int chi = 2 * np * (int) ((long) nswarm * (c.shard_rank + 1) / c.shard_world);
-    if ((int) (blockIdx.x * R + R) <= clo || (int) (blockIdx.x * R) >= chi) return;
-    const bool live = cand >= clo && cand < chi;
+    const int jlo = (int) ((long) nswarm * c.shard_rank / c.shard_world);
+    const int jhi = (int) ((long) nswarm * (c.shard_rank + 1) / c.shard_world);
+    if ((int) (blockIdx.x * R) >= jhi * CCP_SPLIT || (int) (blockIdx.x * R + R) <= jlo * CCP_SPLIT)
+        return;
+    if (j < jlo || j >= jhi) return;             // (whole teams: nobody waits for them)
     double *row = lds + (size_t) r * ld;
-    const int which = cand & 1, t = cand >> 1;
-    const int i = live ? t % np : 0, j = live ? t / np : 0;
     const double *yh = d.yhat + (size_t) p * ld;
     for (int q = g; q < ld; q += G) row[q] = yh[q];
-    __syncthreads();
-    if (live) {
-        const double *src = (which ? d.Y : d.X) + ((size_t) p * np + i) * ld;
-        const int *rg = d.range + (size_t) p * c.n + (size_t) j * cp;
-        for (int q = g; q < cp; q += G) {
-            const int coord = rg[q];
-            row[coord] = src[coord];
-        }
+    // this lane's coordinates of the swarm (the same for every candidate) and, one candidate
+    // ahead, the values that go there: the gather is a chain of two dependent loads, taken off
+    // the evaluation's path
+    const int *rg = d.range + (size_t) p * c.n + (size_t) j * cp;
+    int coord[MAXQ];
+#pragma unroll
+    for (int u = 0; u < MAXQ; u++) coord[u] = g + G * u < cp ? rg[g + G * u] : -1;
+    const size_t fb = (size_t) p * c.n * np + (size_t) j * np;
+    auto source = [&](int t) {
+        return ((t & 1) ? d.Y : d.X) + ((size_t) p * np + (t >> 1)) * ld;
+    };
+    double val[MAXQ];
+    {
+        const double *src = source(part);
+#pragma unroll
+        for (int u = 0; u < MAXQ; u++) val[u] = coord[u] >= 0 ? src[coord[u]] : 0.;
     }
-    __syncthreads();
-    if (c.obj >= 0) {
-        double f = eval_row_group<G>(c.obj, c.n, row, d.aux, g);
-        if (f != f) f = CCP_INF;
-        if (live && g == 0) (which ? d.fY : d.fX)[(size_t) p * c.n * np + (size_t) j * np + i] = f;
+    for (int t = part; t < 2 * np; t += CCP_SPLIT) {
+        ccp_wave_sync();                         // the previous evaluation has read the row
+#pragma unroll
+        for (int u = 0; u < MAXQ; u++)
+            if (coord[u] >= 0) row[coord[u]] = val[u];
+        if (t + CCP_SPLIT < 2 * np) {
+            const double *src = source(t + CCP_SPLIT);
+#pragma unroll
+            for (int u = 0; u < MAXQ; u++) val[u] = coord[u] >= 0 ? src[coord[u]] : 0.;
+        }
+        ccp_wave_sync();
+        if (c.obj >= 0) {
+            double f = eval_row_group<G, false, 4>(c.obj, c.n, row, d.aux, g);
+            if (f != f) f = CCP_INF;
+            if (g == 0) ((t & 1) ? d.fY : d.fX)[fb + (t >> 1)] = f;
+        }
     }
 }
 

@@ -92,7 +92,7 @@ __device__ inline double group_prod(double v)
 // per lane, see sep_sample_eval).
 __host__ __device__ inline int row_swizzle(int j) { return j ^ (((j >> 4) & 3) << 2); }
 
-template<int G, bool SWZ = false>
+template<int G, bool SWZ = false, int UNR = 1>
 __device__ inline double eval_row_group(int obj, int n, const double *xrow, const double *aux,
         int g)
 {
@@ -101,12 +101,18 @@ __device__ inline double eval_row_group(int obj, int n, const double *xrow, cons
         __device__ double operator[](int j) const { return p[SWZ ? row_swizzle(j) : j]; }
     };
     const Row x { xrow };
+    // (UNR > 1 unrolls the strided loops: the LDS reads and products of UNR terms are in flight
+    // together, the terms are still ADDED in the loop's order -- same bits, a fraction of the
+    // latency.  For the kernels whose evaluation IS the latency chain (CCPSO's context
+    // evaluations); elsewhere the extra registers cost occupancy)
     double a = 0., b = 0.;
     switch (obj) {
     case OBJ_SPHERE:
+#pragma unroll UNR
         for (int j = g; j < n; j += G) a += x[j] * x[j];
         return group_sum<G>(a);
     case OBJ_ROSENBROCK:
+#pragma unroll UNR
         for (int j = g; j + 1 < n; j += G) {
             const double xj = x[j];
             const double t = x[j + 1] - xj * xj;
@@ -115,12 +121,15 @@ __device__ inline double eval_row_group(int obj, int n, const double *xrow, cons
         }
         return group_sum<G>(a);
     case OBJ_RASTRIGIN:
+#pragma unroll UNR
         for (int j = g; j < n; j += G) a += x[j] * x[j] - 10. * cos_2pi(x[j]);
         return 10. * n + group_sum<G>(a);
     case OBJ_ELLIPSOID:
+#pragma unroll UNR
         for (int j = g; j < n; j += G) a += aux[j] * (x[j] * x[j]);
         return group_sum<G>(a);
     case OBJ_ACKLEY:
+#pragma unroll UNR
         for (int j = g; j < n; j += G) {
             a += x[j] * x[j];
             b += cos_2pi(x[j]);
@@ -130,6 +139,7 @@ __device__ inline double eval_row_group(int obj, int n, const double *xrow, cons
         return -20. * exp(-0.2 * sqrt(a / n)) - exp(b / n) + 20. + EULER_E;
     case OBJ_GRIEWANK:
         b = 1.;
+#pragma unroll UNR
         for (int j = g; j < n; j += G) {
             a += x[j] * x[j];
             b *= cos(x[j] * aux[j]);
@@ -138,14 +148,17 @@ __device__ inline double eval_row_group(int obj, int n, const double *xrow, cons
         b = group_prod<G>(b);
         return 1. + a / 4000. - b;
     case OBJ_CIGAR:
+#pragma unroll UNR
         for (int j = g; j < n; j += G)
             if (j > 0) a += x[j] * x[j];
         return x[0] * x[0] + 1.0e6 * group_sum<G>(a);
     case OBJ_DISCUS:
+#pragma unroll UNR
         for (int j = g; j < n; j += G)
             if (j > 0) a += x[j] * x[j];
         return 1.0e6 * (x[0] * x[0]) + group_sum<G>(a);
     case OBJ_DIFFPOW:
+#pragma unroll UNR
         for (int j = g; j < n; j += G) a += pow(fabs(x[j]), aux[j]);
         return group_sum<G>(a);
     case OBJ_SCHWEFEL12: {
