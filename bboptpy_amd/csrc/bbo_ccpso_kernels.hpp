@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
     if (ccp_frozen(c, sc)) return;
     extern __shared__ double lds[];
     constexpr int R = 256 / G;
-    constexpr int MAXQ = 256 / G;                // a swarm has at most 256 coordinates
+    constexpr int MAXQ = 256 / G;                // coordinates of the swarm held in registers: 256
     const int tid = threadIdx.x, r = tid / G, g = tid % G;
     const int team = blockIdx.x * R + r, ld = c.ld, np = c.np;
     const int j = team / CCP_SPLIT, part = team - j * CCP_SPLIT;
@@ -199,6 +199,13 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
 #pragma unroll
         for (int u = 0; u < MAXQ; u++)
             if (coord[u] >= 0) row[coord[u]] = val[u];
+        if (cp > G * MAXQ) {                     // (swarms wider than 256 coordinates: the rest, plainly)
+            const double *src = source(t);
+            for (int q = g + G * MAXQ; q < cp; q += G) {
+                const int co = rg[q];
+                row[co] = src[co];
+            }
+        }
         if (t + CCP_SPLIT < 2 * np) {
             const double *src = source(t + CCP_SPLIT);
 #pragma unroll

@@ -24,7 +24,11 @@ def _close(a, b, rtol, what):
     (12, 8, "rastrigin", [2, 3, 6], {}),
     (20, 10, "rosenbrock", [5, 10], dict(correct=False)),
     (16, 6, "sphere", [1, 2, 4, 8, 16], dict(pcauchy=0.3)),
-    (300, 24, "ellipsoid", [5, 10, 50], {}),             # ld > 256: 64 lanes per candidate
+    (300, 24, "ellipsoid", [5, 10, 50], {}),             # ld > 256: 64 lanes per team
+    (600, 7, "rosenbrock", [300, 600], {}),              # swarms wider than the 256 coordinates a
+                                                         # team holds in registers; 2 np = 14 is
+                                                         # not a multiple of the teams per swarm
+    (40, 5, "sphere", [20, 40], {}),                     # the same with 16 lanes per team
 ])
 def test_generations_match_oracle(hip, oracle_lib, n, npp, obj, pps, kw):
     seed = 555
