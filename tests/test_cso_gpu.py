@@ -25,7 +25,8 @@ def _close(a, b, rtol, what):
     (7, 31, "sphere", dict(pcompete=4, ring=True)),                 # np rounded up to 32, ring
     (12, 202, "ackley", dict(pcompete=2, ring=True, correct=False, vmax=0.1)),   # np > 100: phi > 0
     (16, 9000, "sphere", dict(pcompete=3)),                         # a large swarm
-    (301, 30, "ellipsoid", dict(pcompete=3)),                       # > 128 columns: chunked row loop
+    (200, 45, "rosenbrock", dict(pcompete=3)),                      # 32 lanes per group (fused swarm mean)
+    (301, 30, "ellipsoid", dict(pcompete=3)),                       # 64 lanes per group
     (513, 30, "sphere", dict(pcompete=3)),                          # > 512 columns: 8 groups per workgroup
     (1024, 24, "rastrigin", dict(pcompete=2, ring=True)),
 ])
