@@ -4,9 +4,10 @@
 //   ccp_init        :76-100 uniform swarm, Y = X, yhat = the best particle
 //   ccp_regroup     :188-231 subset size (kept while yhat improves), random regrouping
 //                   (std::shuffle -> the keyed Feistel bijection of bbo_cso_kernels.hpp)
-//   ccp_eval<G>     :233-247 + evaluate :150-168: 2 nswarm np context-vector evaluations,
-//                   one candidate per G lanes built in LDS (yhat with one swarm's coordinates
-//                   replaced): objective-bound, the throughput driver
+//   ccp_eval<G>     :233-247 + evaluate :150-168: 2 nswarm np context-vector evaluations (yhat
+//                   with one swarm's coordinates replaced), teams of G lanes per SWARM walking
+//                   its candidates in one LDS row: evaluation latency x occupancy, the
+//                   throughput driver
 //   ccp_update      :251-290 personal bests, swarm bests into yhat (last qualifying particle
 //                   wins, stale fY -- both kept), ring local bests
 //   ccp_yhat        :292-303 re-evaluation of a moved yhat, accept / revert; :306-332 Cauchy rate

@@ -5,11 +5,11 @@
 //   cma_rank               std::sort in base_cmaes.cpp:221                 L2 / VALU (lambda^2 compares)
 //   cma_whiten             active_cmaes.cpp:115-132 (ycoeff norms)         fp64 MFMA (2 n^2 flop/cand, worst mu)
 //   cma_gram               active_cmaes.cpp:135-161 rank-mu +/- terms,     fp64 MFMA (2 n^2 flop/cand)
-//                          and the weighted mean :75-85
+//   (cma_gram128s, n = 128) and the weighted mean :75-85
 //   cma_paths              active_cmaes.cpp:75-112 + base_cmaes.cpp:176-189 latency (1 workgroup)
 //   cma_cov                active_cmaes.cpp:137-160 (assembly of C)        HBM/L2 (slab reduce)
 //   cma_eigen              cmaes.cpp:229-478 (tred2 + tql2 + repair)       serial latency (1 workgroup)
-//   cma_post               cmaes.cpp:274-282 (C^-1/2) + operand packing    L2
+//   cma_post               cmaes.cpp:274-282 (C^-1/2) + operand packing    L2 (on demand where lazy_isc)
 //   cma_history_stop       base_cmaes.cpp:191-209, cmaes.cpp:151-227       latency
 //
 // All arithmetic is fp64.  MFMA is v_mfma_f64_16x16x4_f64: A fragment = one double

@@ -3,7 +3,8 @@
 //   kernel            reference lines (cso.cpp)                       bytes per particle
 //   cso_init          :84-97 uniform swarm, v = 0                      16n written
 //   cso_ring_mean     :117-123 ring neighbourhood mean                 24n read + 8n written
-//   cso_colsum/mean   :124-131 swarm mean (also the winners' mean)     8n read
+//   cso_colsum/mean   :124-131 swarm mean (also the winners' mean)     8n read (the swarm mean
+//                     for n <= 512: cso_wgsum over the sums cso_compete leaves per workgroup)
 //   cso_shuffle       :136 Random::shuffle (keyed Feistel bijection)     8
 //   cso_groups        :137-143 sort inside every group                 (f only)
 //   cso_compete       :219-276 velocity / position / evaluate of the losers: parent x, own x,
