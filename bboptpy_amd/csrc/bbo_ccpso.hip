@@ -77,6 +77,7 @@ void CcpsoEngine::init(int n, const double *lower, const double *upper, const do
     range_.alloc((size_t) P * n);
     grp_of_.alloc((size_t) P * n);
     radius_.alloc(rows);
+    rpart_.alloc(rows * ((ld / 2 + 255) / 256));
     lower_.alloc(ld);
     upper_.alloc(ld);
     aux_.alloc(ld);
@@ -106,7 +107,7 @@ void CcpsoEngine::init(int n, const double *lower, const double *upper, const do
     d = CcpDev {};
     d.X = X_.p; d.Y = Y_.p; d.yhat = yhat_.p; d.ysave = ysave_.p; d.fX = fX_.p; d.fY = fY_.p;
     d.ibest = ibest_.p; d.strat = strat_.p; d.range = range_.p; d.grp_of = grp_of_.p;
-    d.radius = radius_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
+    d.radius = radius_.p; d.rpart = rpart_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p; d.scal = scal_.p;
     c.honor_stop = 0;
     inited_ = true;
 
@@ -220,7 +221,7 @@ void CcpsoEngine::launch_rest()
     int cpmin = c.pps[0];
     for (int k = 1; k < c.npps; k++) cpmin = std::min(cpmin, c.pps[k]);
     timer_.begin(stream_, K_UPDATE);
-    hipLaunchKernelGGL(ccp_update, dim3(c.n / cpmin, P), dim3(256), 0, stream_, d_, c_);
+    hipLaunchKernelGGL(ccp_update, dim3(c.n / cpmin, P), dim3(64), 0, stream_, d_, c_);
     if (!obj_.on_device()) host_eval_yhat();
     hipLaunchKernelGGL(ccp_yhat, dim3(P), dim3(256), (size_t) c.ld * sizeof(double), stream_, d_,
             c_);
@@ -229,11 +230,12 @@ void CcpsoEngine::launch_rest()
     timer_.begin(stream_, K_POSITION);
     hipLaunchKernelGGL(ccp_strategy, dim3(((c.n / cpmin) * c.np + 255) / 256, P), dim3(256), 0,
             stream_, d_, c_);
-    hipLaunchKernelGGL(ccp_position, dim3((c.np + 15) / 16, P), dim3(256), 0, stream_, d_, c_);
+    const int rparts = (c.ld / 2 + 255) / 256;
+    hipLaunchKernelGGL(ccp_position, dim3(rparts, c.np, P), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_FINISH);
-    hipLaunchKernelGGL(ccp_finish, dim3(P), dim3(256), 0, stream_, d_, c_);
+    hipLaunchKernelGGL(ccp_finish, dim3(P), dim3(256), 0, stream_, d_, c_, rparts);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }

@@ -36,6 +36,7 @@ struct CcpDev {
     int *ibest, *strat;      // [P][n * np]
     int *range, *grp_of;     // [P][n]: position -> coordinate, coordinate -> swarm
     double *radius;          // [P][np]
+    double *rpart;           // [P][np][ceil(ld / 512)] partial sums of squares (ccp_position)
     const double *lower, *upper, *aux;
     CcpScal *scal;
 };
@@ -78,7 +79,7 @@ private:
     bool inited_ = false;
     int shard_rank_ = 0, shard_world_ = 1;     // survive init() (c_ is rebuilt there)
     std::vector<double> aux_h_;
-    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, lower_, upper_, aux_, gather_;
+    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, rpart_, lower_, upper_, aux_, gather_;
     DevBuf<int> ibest_, strat_, range_, grp_of_;
     DevBuf<CcpScal> scal_;
     KernelTimer timer_;

@@ -240,36 +240,37 @@ __global__ __launch_bounds__(256) void ccp_merge(CcpDev d, CcpConst c, const dou
     d.fY[q] = rec[cap + q];
 }
 
-// one workgroup per swarm j: personal bests, the swarm's contribution to yhat, ring local bests.
-// grid (n (>= nswarm), P), 256 threads
-__global__ __launch_bounds__(256) void ccp_update(CcpDev d, CcpConst c)
+// one WAVEFRONT per swarm j: personal bests, the swarm's contribution to yhat, ring local bests
+// (np cp elements, often a few dozen: a wider workgroup only adds idle wavefronts to schedule).
+// grid (n (>= nswarm), P), 64 threads
+__global__ __launch_bounds__(64) void ccp_update(CcpDev d, CcpConst c)
 {
     const int p = blockIdx.y, j = blockIdx.x;
     CcpScal *sc = d.scal + p;
     if (ccp_frozen(c, sc)) return;
     if (j >= sc->nswarm) return;
-    __shared__ int s_last[4];
     const int tid = threadIdx.x, np = c.np, ld = c.ld, cp = sc->cpswarm;
     const size_t fb = (size_t) p * c.n * np + (size_t) j * np;
     const double *fX = d.fX + fb, *fY = d.fY + fb;
     const int *rg = d.range + (size_t) p * c.n + (size_t) j * cp;
     const double fyhat = sc->fyhat0;
     // personal bests: Y_i <- X_i on this swarm's coordinates where X scored better
-    for (int q = tid; q < np * cp; q += 256) {
+    for (int q = tid; q < np * cp; q += 64) {
         const int i = q / cp, coord = rg[q - i * cp];
         if (fX[i] < fY[i]) d.Y[((size_t) p * np + i) * ld + coord] = d.X[((size_t) p * np + i) * ld + coord];
     }
     // the LAST particle whose (stale) fY beats fyhat gives the swarm's coordinates to yhat
     int last = -1;
-    for (int i = tid; i < np; i += 256)
+    for (int i = tid; i < np; i += 64)
         if (fY[i] < fyhat) last = i;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
-    if ((tid & 63) == 0) s_last[tid >> 6] = last;
-    __syncthreads();                       // (also orders the Y writes above)
-    last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    // (one wavefront: the reduction above is the whole workgroup's; the fence orders the Y writes
+    // above before the reads below)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     if (last >= 0) {
-        for (int q = tid; q < cp; q += 256) {
+        for (int q = tid; q < cp; q += 64) {
             const int coord = rg[q];
             d.yhat[(size_t) p * ld + coord] = d.Y[((size_t) p * np + last) * ld + coord];
         }
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void ccp_update(CcpDev d, CcpConst c)
     }
     // ring local best: the first smallest of (i-1, i, i+1)
     int *ib = d.ibest + fb;
-    for (int i = tid; i < np; i += 256) {
+    for (int i = tid; i < np; i += 64) {
         const int a = (i - 1 + np) % np, b = (i + 1) % np;
         int im = a;
         if (fY[i] < fY[im]) im = i;
@@ -372,60 +373,75 @@ __global__ __launch_bounds__(256) void ccp_strategy(CcpDev d, CcpConst c)
 // new positions: 16 lanes per particle sweep its coordinates.  grid (ceil(np/16), P)
 __global__ __launch_bounds__(256) void ccp_position(CcpDev d, CcpConst c)
 {
-    const int p = blockIdx.y;
+    // one thread per coordinate pair: grid (ceil(ld / 512), np, P).  (With 16 lanes per particle
+    // the whole resampling was 2 np workgroups -- 32 for the benchmark's 16 populations -- walking
+    // chains of dependent look-ups, tangents and Box-Muller pairs: 90 us of latency.)  The
+    // squared radius leaves as one partial per workgroup; ccp_finish adds them in order.
+    const int p = blockIdx.z, i = blockIdx.y;
     const CcpScal *sc = d.scal + p;
     if (ccp_frozen(c, sc)) return;
-    const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r, np = c.np, ld = c.ld, gen = sc->gen;
+    __shared__ double red[4];
+    const int tid = threadIdx.x, np = c.np, ld = c.ld, gen = sc->gen;
+    const int pj = blockIdx.x * 256 + tid;
     double ssq = 0.;
-    if (i < np) {
+    if (pj < ld / 2) {
         const size_t fb = (size_t) p * c.n * np;
         const int *grp = d.grp_of + (size_t) p * c.n;
         const double *Y = d.Y + (size_t) p * np * ld;
         double *x = d.X + ((size_t) p * np + i) * ld;
         const uint32_t sw = stream_word(STREAM_PSO_R, (uint32_t) p);
-        for (int pj = g; pj < ld / 2; pj += 16) {
-            const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw);
-            double z0 = 0., z1 = 0.;
-            bool have_z = false;
+        const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw);
+        double z0 = 0., z1 = 0.;
+        bool have_z = false;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int dd = 2 * pj + h;
-                if (dd >= c.n) continue;
-                const int j = grp[dd];
-                const int st = d.strat[fb + (size_t) j * np + i];
-                const int ihat = d.ibest[fb + (size_t) j * np + i];
-                const double yi = Y[(size_t) i * ld + dd], yl = Y[(size_t) ihat * ld + dd];
-                double dev;
-                if (st == 0) {
-                    const double u = h ? u01(w.z, w.w) : u01(w.x, w.y);
-                    dev = tan(CCP_PI * (u - 0.5));
-                } else {
-                    if (!have_z) {
-                        normal_pair(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw, z0, z1);
-                        have_z = true;
-                    }
-                    dev = h ? z1 : z0;
+        for (int h = 0; h < 2; h++) {
+            const int dd = 2 * pj + h;
+            if (dd >= c.n) continue;
+            const int j = grp[dd];
+            const int st = d.strat[fb + (size_t) j * np + i];
+            const int ihat = d.ibest[fb + (size_t) j * np + i];
+            const double yi = Y[(size_t) i * ld + dd], yl = Y[(size_t) ihat * ld + dd];
+            double dev;
+            if (st == 0) {
+                const double u = h ? u01(w.z, w.w) : u01(w.x, w.y);
+                dev = tan(CCP_PI * (u - 0.5));
+            } else {
+                if (!have_z) {
+                    normal_pair(c.seed, (uint32_t) i, (uint32_t) pj, (uint32_t) gen, sw, z0, z1);
+                    have_z = true;
                 }
-                double v = (st == 0 ? yi : yl) + dev * fabs(yi - yl);
-                if (c.correct) v = fmax(d.lower[dd], fmin(v, d.upper[dd]));
-                x[dd] = v;
-                ssq += v * v;
+                dev = h ? z1 : z0;
             }
+            double v = (st == 0 ? yi : yl) + dev * fabs(yi - yl);
+            if (c.correct) v = fmax(d.lower[dd], fmin(v, d.upper[dd]));
+            x[dd] = v;
+            ssq += v * v;
         }
     }
-    ssq = ccp_group_sum<16>(ssq);
-    if (g == 0 && i < np) d.radius[(size_t) p * np + i] = sqrt(ssq);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ssq += __shfl_xor(ssq, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ssq;
+    __syncthreads();
+    if (tid == 0)
+        d.rpart[((size_t) p * np + i) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // grid (P), 256 threads
-__global__ __launch_bounds__(256) void ccp_finish(CcpDev d, CcpConst c)
+// rparts > 0: the radii come as `rparts` partial sums of squares per particle (ccp_position)
+__global__ __launch_bounds__(256) void ccp_finish(CcpDev d, CcpConst c, int rparts)
 {
     const int p = blockIdx.x;
     CcpScal *sc = d.scal + p;
     if (ccp_frozen(c, sc)) return;
     __shared__ double red[4];
     const int tid = threadIdx.x, np = c.np;
+    if (rparts > 0)
+        for (int q = tid; q < np; q += 256) {
+            const double *rp = d.rpart + ((size_t) p * np + q) * rparts;
+            double s2 = rp[0];
+            for (int k = 1; k < rparts; k++) s2 += rp[k];
+            d.radius[(size_t) p * np + q] = sqrt(s2);
+        }
     auto block_sum = [&](double v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
