@@ -12,9 +12,10 @@ import bboptpy_amd as bb   # noqa: E402
 from bboptpy_amd import _ffi   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-g = bb.ActiveCMAES(mfev=10 ** 9, tol=0., np=4 * n, seed=3)
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+g = bb.ActiveCMAES(mfev=10 ** 9, tol=0., np=4 * n, seed=3, populations=P)
 g.initialize(bb.objectives.rosenbrock, -10 * np.ones(n), 10 * np.ones(n),
-             np.random.default_rng(1).uniform(-10, 10, n))
+             np.random.default_rng(1).uniform(-10, 10, (P, n)) if P > 1 else np.random.default_rng(1).uniform(-10, 10, n))
 g.run(30)                       # a covariance with some structure
 g.set_state("eig_stamps", [1.0])
 for rep in range(3):
