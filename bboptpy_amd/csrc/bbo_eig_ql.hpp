@@ -56,6 +56,26 @@ __device__ inline void ql_wave_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// reciprocal and reciprocal root from the hardware estimates + Newton corrections (full fp64 to
+// a rounding error).  The sweep's shift and its closing quotient sit on the serial path of the
+// recurrence -- four IEEE divisions and a hypot per sweep were a third of a leaf's time
+__device__ inline double ql_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
+}
+__device__ inline double ql_hypot1(double p)       // sqrt(p^2 + 1)
+{
+    const double t = fma(p, p, 1.);
+    double y = __builtin_amdgcn_rsq(t);
+    const double err = fma(-t * y, y, 1.);
+    y = fma(y * err, fma(err, 0.375, 0.5), y);
+    double r = t * y;
+    return fma(fma(-r, r, t), 0.5 * y, r);         // one more step on the root itself
+}
+
 // state of the QL recurrence, uniform across the producer wavefront
 struct QlState {
     int l, m, need_m, done;
@@ -110,10 +130,10 @@ __device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, dou
 
         // implicit shift (cmaes.cpp:405-417)
         const double g0 = dv[l], d1 = dv[l + 1], el = ev[l];
-        const double p0 = (d1 - g0) / (2. * el);
-        double r0 = hypot(p0, 1.);
-        r0 = p0 >= 0. ? fabs(r0) : -fabs(r0);
-        const double dl_new = el / (p0 + r0);
+        const double p0 = (d1 - g0) * ql_rcp(2. * el);
+        double r0 = ql_hypot1(p0);
+        r0 = p0 >= 0. ? r0 : -r0;
+        const double dl_new = el * ql_rcp(p0 + r0);
         const double dl1 = el * (p0 + r0);
         const double h0 = g0 - dl_new;
         ql_wave_fence();
@@ -153,7 +173,7 @@ __device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, dou
                 ei = ein;
                 di = din;
             }
-            pp = -s * s2 * c3 * el1 * ev[l] / dl1;
+            pp = -s * s2 * c3 * el1 * ev[l] * ql_rcp(dl1);
             ev[l] = s * pp;
             dv[l] = cth * pp;
         }
