@@ -583,19 +583,12 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
 __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv_in,
         const double *ev_in, double *dv_out, double *ws, int lane, long long *dbgout)
 {
-    double *dl = ws + 2;                  // front pads: the producer prefetches index -1
-    double *el = ws + 22;
+    // (d, e) of the block in registers, lane i its row i (ql_produce_reg); LDS: the Givens pairs
+    // and sweep descriptors of a round, for the consumer
     double2 *rot = reinterpret_cast<double2*>(ws + 42);
     int *desc = reinterpret_cast<int*>(ws + 42 + 128);
-    if (lane < 20) {
-        ws[lane] = 0.;
-        ws[20 + lane] = 0.;
-    }
-    dc_wave_sync();
-    if (lane < s) {
-        dl[lane] = dv_in[a + lane];
-        el[lane] = lane + 1 < s ? ev_in[a + lane] : 0.;
-    }
+    double d = lane < s ? dv_in[a + lane] : 0.;
+    double e = lane + 1 < s ? ev_in[a + lane] : 0.;
     for (int q = lane; q < s * s; q += 64) {
         const int r = q / s, c = q - r * s;
         Q(a + r, a + c) = r == c ? 1. : 0.;
@@ -605,14 +598,10 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     QlState st { 0, 0, 1, 0, 0., 0. };
     // QL has no iteration limit in the reference either; the guard only bounds a run on
     // non-finite input (30 sweeps per eigenvalue is far beyond anything observed)
-    for (int guard = 0; guard < 30 * s && !st.done; guard++) {
-        const int ns = ql_produce(st, s, dl, el, rot, desc, 64, lane);
-        dc_wave_sync();
-        if (lane < s) ql_apply_row(blk, lane, rot, desc, ns);
-        dc_wave_sync();
-        if (dbgout && lane == 0) dbgout[0] = guard + 1;
-    }
-    if (lane < s) dv_out[a + lane] = dl[lane];
+    // (a lane touches only its own row of the block: the rotations need no fence among lanes)
+    const int sweeps = ql_produce_reg<true>(st, s, d, e, rot, desc, 64, lane, blk);
+    if (dbgout && lane == 0) dbgout[0] = sweeps;
+    if (lane < s) dv_out[a + lane] = d;
     dc_wave_sync();
 }
 

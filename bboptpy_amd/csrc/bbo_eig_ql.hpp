@@ -197,6 +197,143 @@ __device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, dou
     return ns;
 }
 
+// The same recurrence for a block of at most 64 rows (the leaves of the divide and conquer, the
+// whole matrix for n <= 16) with (d, e) in REGISTERS -- lane i holds d[i] and e[i] -- and every
+// lane walking the recurrence on uniform values: an element is fetched by v_readlane and put
+// back by a one-lane select, where the LDS form paid an LDS round trip per hand-over (a sweep's
+// set-up alone was six of them, one after the other) and a wavefront fence at each.  The same
+// operations in the same order: the same bits.  Only the Givens pairs and the sweep descriptors go
+// through LDS (the consumer reads them).
+__device__ inline double ql_lane(double v, int idx)      // v of lane idx (idx uniform)
+{
+    const int k = __builtin_amdgcn_readfirstlane(idx);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
+// FUSED: every rotation is applied to the eigenvector block at once -- lane k < n owns row k of
+// `blk` (the consumer's streaming form: one LDS read and one write per rotation, the carried
+// element in a register) -- in the latency shadow of the recurrence, which issues a dozen
+// dependent instructions per rotation and leaves the pipe idle in between; no pairs are recorded,
+// no rounds.  Same operations per row in the same order as ql_apply_row.
+template<bool FUSED>
+__device__ inline int ql_produce_reg(QlState &st, int n, double &d, double &e, double2 *rot,
+        int *desc, int rc, int lane, const EigMat &blk)
+{
+    const double eps = 0x1.0p-52;
+    int count = 0, ns = 0;
+    double *zrow = blk.a + (size_t) (lane < n ? lane : 0) * blk.ld;
+    while (!st.done) {
+        if (st.need_m) {
+            const double dl = ql_lane(d, st.l), el = ql_lane(e, st.l);
+            st.tst1 = fmax(st.tst1, fabs(dl) + fabs(el));
+            const double thr = eps * st.tst1;
+            const bool ok = lane >= st.l && lane < n && fabs(e) <= thr;
+            const unsigned long long mask = __ballot(ok);
+            const int m = mask ? (int) __builtin_ctzll(mask) : n;
+            st.m = m;
+            st.need_m = 0;
+            if (m >= n) {   // unreachable for finite input: e[n-1] == 0
+                st.done = 1;
+                break;
+            }
+            if (m == st.l) {
+                if (lane == st.l) {
+                    d = dl + st.f;
+                    e = 0.;
+                }
+                st.l++;
+                st.need_m = 1;
+                if (st.l >= n) st.done = 1;
+                continue;
+            }
+        }
+        const int l = st.l, m = st.m, len = m - l;
+        if (!FUSED && (count + len > rc || ns >= EIG_MAXSEQ)) break;
+        const double thr = eps * st.tst1;
+
+        // implicit shift (cmaes.cpp:405-417)
+        const double g0 = ql_lane(d, l), d1 = ql_lane(d, l + 1), el = ql_lane(e, l);
+        const double p0 = (d1 - g0) * ql_rcp(2. * el);
+        double r0 = ql_hypot1(p0);
+        r0 = p0 >= 0. ? r0 : -r0;
+        const double dl_new = el * ql_rcp(p0 + r0);
+        const double dl1 = el * (p0 + r0);
+        const double h0 = g0 - dl_new;
+        if (lane >= l + 2 && lane < n) d -= h0;
+        st.f += h0;
+        if (lane == l) d = dl_new;
+        if (lane == l + 1) d = dl1;
+
+        // implicit QL sweep (cmaes.cpp:419-449)
+        double pp = ql_lane(d, m);
+        double cth = 1., c2 = 1., c3 = 1., sn = 0., s2 = 0.;
+        const double el1 = ql_lane(e, l + 1);
+        double ei = ql_lane(e, m - 1), di = ql_lane(d, m - 1);
+        double2 *out = rot + count;
+        double hcur = FUSED ? zrow[m] : 0., zx = FUSED ? zrow[m - 1] : 0.;
+        for (int i = m - 1; i >= l; i--) {
+            const int ip = i > 0 ? i - 1 : 0;              // (the value for i = l is not used)
+            const double ein = ql_lane(e, ip), din = ql_lane(d, ip);
+            const double zn = FUSED ? zrow[ip] : 0.;       // next column's element of this lane's row
+            c3 = c2;
+            c2 = cth;
+            s2 = sn;
+            const double g = cth * ei;
+            const double h = cth * pp;
+            const double t = fma(pp, pp, ei * ei);
+            // 1/sqrt(t): hardware estimate + one third-order correction (full fp64)
+            double y = __builtin_amdgcn_rsq(t);
+            const double err = fma(-t * y, y, 1.);
+            y = fma(y * err, fma(err, 0.375, 0.5), y);
+            const double r = t * y;             // = hypot(pp, ei) to rounding
+            const double e_up = sn * r;
+            sn = ei * y;
+            cth = pp * y;
+            pp = fma(cth, di, -(sn * g));
+            const double d_up = h + sn * fma(cth, g, sn * di);
+            if (lane == i + 1) {
+                e = e_up;
+                d = d_up;
+            }
+            if (FUSED) {
+                if (lane < n) zrow[i + 1] = sn * zx + cth * hcur;
+                hcur = cth * zx - sn * hcur;
+                zx = zn;
+            } else if (lane == 0) {
+                out[i - l] = make_double2(cth, sn);
+            }
+            ei = ein;
+            di = din;
+        }
+        if (FUSED && lane < n) zrow[l] = hcur;
+        pp = -sn * s2 * c3 * el1 * ql_lane(e, l) * ql_rcp(dl1);
+        const double el_new = sn * pp;
+        if (lane == l) {
+            e = el_new;
+            d = cth * pp;
+        }
+        if (!FUSED && lane == 0) {
+            desc[3 * ns + 0] = l;
+            desc[3 * ns + 1] = m;
+            desc[3 * ns + 2] = count;
+        }
+        count += len;
+        ns++;
+        if (!(fabs(el_new) > thr)) {
+            if (lane == l) {
+                d += st.f;
+                e = 0.;
+            }
+            st.l++;
+            st.need_m = 1;
+            if (st.l >= n) st.done = 1;
+        }
+    }
+    return ns;
+}
+
 // Consumer: applies the recorded sweeps to row k of the eigenvector matrix
 // (the inner k-loop of cmaes.cpp:438-443, one lane per k)
 __device__ inline void ql_apply_row(const EigMat &A, int k, const double2 *rot,
