@@ -96,7 +96,7 @@ void bbo_params_default(bbo_params *p, int algo)
     p->device = 0;
     p->populations = 1;
     p->poll_every = 8;
-    p->adjustlr = 0;
+    p->adjustlr = 1;   /* py/multivariate_py.cpp:131-135: "adjustlr"_a = true */
     p->crref = 5;
     p->pupdate = 50;
     p->crupdate = 25;

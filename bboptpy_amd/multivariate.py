@@ -307,11 +307,11 @@ class ActiveCMAES(CMAES):
 
 
 class SepCMAES(BaseCMAES):
-    """SepCMAES(mfev, tol, np, sigma0=2., bound=False, adjustlr=False) -- :131-135
+    """SepCMAES(mfev, tol, np, sigma0=2., bound=False, adjustlr=True) -- :131-135
     (diagonal covariance, Ros & Hansen 2008; sep_cmaes.cpp)"""
     _algo = _ffi.ALGO_SEP_CMAES
 
-    def __init__(self, mfev, tol, np, sigma0=2., bound=False, adjustlr=False, **ext):
+    def __init__(self, mfev, tol, np, sigma0=2., bound=False, adjustlr=True, **ext):
         super().__init__(**ext)
         p = self._params
         p.mfev, p.tol, p.np = int(mfev), float(tol), int(np)

@@ -105,7 +105,7 @@ typedef struct {
     int np;                /* population size: CMA `np` (lambda), JADE/APSO `np`, SHADE `npinit` */
     /* CMAES(mfev,tol,np,sigma0=2,bound=False,eigenrate=0.25)            :103-108
      * ActiveCMAES(...,alphacov=2,eigenrate=0.25)                         :110-115
-     * SepCMAES(mfev,tol,np,sigma0=2,bound=False,adjustlr=False)          :131-135 */
+     * SepCMAES(mfev,tol,np,sigma0=2,bound=False,adjustlr=True)          :131-135 */
     double sigma0;
     int bound;
     double alphacov;

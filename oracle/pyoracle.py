@@ -284,7 +284,7 @@ class Handle:
 
 
 def cma(lib, variant, mfev, tol, np_, sigma0=2., bound=False, alphacov=2., eigenrate=0.25,
-        adjustlr=False):
+        adjustlr=True):
     """variant: 'cmaes' | 'active' | 'sep' (SepCmaes: the alphacov slot carries adjustlr)"""
     v = {"cmaes": 0, "active": 1, "sep": 2}[variant]
     if v == 2:

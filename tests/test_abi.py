@@ -30,46 +30,105 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _ffi.lib().bbo_version()
 
 
+# the 11 optimizer classes of the path (SURVEY section 8 rows a, f) + the two abstract bases
+PATH_CLASSES = ("CMAES", "ActiveCMAES", "SepCMAES", "IPopCMAES", "BiPopCMAES", "JADE", "SHADE",
+                "SANSDE", "APSO", "CSO", "CCPSO")
+# reference keyword -> bbo_params field where the names differ (include/bbopt_hip.h comments)
+FIELD_OF = {("JADE", "sigma"): "jade_sigma", ("SHADE", "npinit"): "np", ("CSO", "stol"): "tol",
+            ("CCPSO", "sigmatol"): "tol", ("BiPopCMAES", "nbipop"): "nipop"}
+# keywords with no bbo_params field: objects / lists marshalled by the Python class itself
+NOT_A_FIELD = {("IPopCMAES", "base"), ("BiPopCMAES", "base"), ("CCPSO", "pps"), ("CCPSO", "local"),
+               ("CCPSO", "localfreq")}
+# the ONE declared relaxation: the reference requires CCPSO's `npps`; here it may be omitted
+# (len(pps)), every reference call still means the same
+RELAXED_REQUIRED = {("CCPSO", "npps")}
+
+
+def _surface():
+    """tests/golden/class_surface.json: parsed from the text of py/multivariate_py.cpp by
+    scripts/gen_class_surface.py (build container) -- names, order, defaults, bases"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "class_surface.json")) as fh:
+        return json.load(fh)["classes"]
+
+
+def test_class_surface_fixture_is_current():
+    """where the reference is present (the build container) the committed fixture is what the
+    parser produces from it today"""
+    src = "/root/reference/py/multivariate_py.cpp"
+    if not os.path.exists(src):
+        pytest.skip("the reference is not on this machine")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "gen_class_surface", os.path.join(ROOT, "scripts", "gen_class_surface.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(src) as fh:
+        assert mod.parse(fh.read()) == _surface()
+
+
 def test_default_parameters_are_the_reference_defaults():
+    """bbo_params_default(algo) holds, field by field, the default of every optional keyword of
+    the reference's py::init for that class (py/multivariate_py.cpp:103-177,265-295)"""
+    import bboptpy_amd as bb
     from bboptpy_amd import _ffi
-    p = _ffi.default_params(_ffi.ALGO_ACTIVE_CMAES)
-    # py/multivariate_py.cpp:103-171,265-269
-    assert (p.sigma0, p.bound, p.alphacov, p.eigenrate) == (2., 0, 2., 0.25)
-    assert (p.archive, p.repaircr, p.pelite, p.cdamp, p.jade_sigma) == (1, 1, 0.05, 0.1, 0.07)
-    assert (p.h, p.npmin, p.correct) == (100, 4, 1)
-    assert (p.print, p.nipop, p.ksigmadec, p.boundlambda, p.maxlargeruns, p.kbudget) == \
-        (0, 1, 1.6, 1, 9, 2.)
-    assert p.populations == 1
+    surf = _surface()
+    checked = 0
+    for name in PATH_CLASSES:
+        p = _ffi.default_params(getattr(bb, name)._algo)
+        assert p.algo == getattr(bb, name)._algo
+        for kw in surf[name]["init"]["keywords"]:
+            if kw["required"] or (name, kw["name"]) in NOT_A_FIELD:
+                continue
+            field = FIELD_OF.get((name, kw["name"]), kw["name"])
+            got, want = getattr(p, field), kw["default"]
+            assert got == (int(want) if isinstance(want, bool) else want), (name, kw["name"])
+            checked += 1
+    assert checked >= 40
+    assert _ffi.default_params(_ffi.ALGO_ACTIVE_CMAES).populations == 1
 
 
 def test_class_surface_matches_the_reference():
+    """every class of the path: the reference's Python name, base class, keyword names in the
+    reference's order, required / optional, and default values -- all from the fixture"""
     import bboptpy_amd as bb
-
-    def sig(cls):
-        ps = inspect.signature(cls.__init__).parameters
-        return [(k, v.default) for k, v in ps.items() if k not in ("self", "ext")]
-
+    surf = _surface()
     E = inspect.Parameter.empty
-    assert sig(bb.CMAES) == [("mfev", E), ("tol", E), ("np", E), ("sigma0", 2.), ("bound", False),
-                             ("eigenrate", 0.25)]
-    assert sig(bb.ActiveCMAES) == [("mfev", E), ("tol", E), ("np", E), ("sigma0", 2.),
-                                   ("bound", False), ("alphacov", 2.), ("eigenrate", 0.25)]
-    assert sig(bb.IPopCMAES) == [("base", E), ("mfev", E), ("print", False), ("sigma0", 2.),
-                                 ("nipop", True), ("ksigmadec", 1.6), ("boundlambda", True)]
-    assert sig(bb.BiPopCMAES) == [("base", E), ("mfev", E), ("print", False), ("sigma0", 2.),
-                                  ("maxlargeruns", 9), ("nbipop", True), ("ksigmadec", 1.6),
-                                  ("kbudget", 2.)]
-    assert sig(bb.JADE) == [("mfev", E), ("np", E), ("tol", E), ("archive", True),
-                            ("repaircr", True), ("pelite", 0.05), ("cdamp", 0.1), ("sigma", 0.07)]
-    assert sig(bb.SHADE) == [("mfev", E), ("npinit", E), ("tol", E), ("archive", True),
-                             ("repaircr", True), ("h", 100), ("npmin", 4)]
-    assert sig(bb.APSO) == [("mfev", E), ("tol", E), ("np", E), ("correct", True)]
-    # ActiveCMAES -> CMAES -> BaseCMAES -> MultivariateSearch (multivariate_py.cpp:99-115)
+    for name in PATH_CLASSES:
+        cls, ref = getattr(bb, name), surf[name]
+        ps = inspect.signature(cls.__init__).parameters
+        mine = [(k, v.default) for k, v in ps.items() if k not in ("self", "ext")]
+        want = [(kw["name"], E if kw["required"] else kw["default"]) for kw in ref["init"]["keywords"]]
+        assert [k for k, _ in mine] == [k for k, _ in want], name
+        for (k, got), (_, exp) in zip(mine, want):
+            if (name, k) in RELAXED_REQUIRED:
+                assert exp is E and got is None
+                continue
+            assert (got is E) == (exp is E), (name, k)
+            if exp is not E:
+                assert got == exp and type(got) is type(exp), (name, k, got, exp)
+        # extensions are keyword-only (**ext): a positional reference call cannot hit them
+        assert any(v.kind is inspect.Parameter.VAR_KEYWORD for v in ps.values()), name
+        # the reference's base class is an ancestor here (helper classes may sit in between)
+        assert getattr(bb, ref["base"]) in cls.__mro__[1:], name
+    # the abstract bases: BaseCMAES(MultivariateSearch), no constructor in the reference
+    assert surf["BaseCMAES"]["init"] is None and surf["BaseCMAES"]["base"] == "MultivariateSearch"
+    assert bb.BaseCMAES.__mro__[1] is bb.MultivariateSearch
     assert bb.ActiveCMAES.__mro__[:4] == (bb.ActiveCMAES, bb.CMAES, bb.BaseCMAES,
                                           bb.MultivariateSearch)
-    for cls in (bb.CMAES, bb.JADE, bb.SHADE, bb.APSO, bb.IPopCMAES, bb.BiPopCMAES):
-        for m in ("optimize", "initialize", "iterate", "solution"):
-            assert callable(getattr(cls, m))
+    # MultivariateSearch: optimize / initialize (f, lower, upper, guess), iterate, solution
+    for d in surf["MultivariateSearch"]["defs"]:
+        fn = getattr(bb.MultivariateSearch, d["name"])
+        names = [k for k in inspect.signature(fn).parameters if k != "self"]
+        assert names[:len(d["keywords"])] == d["keywords"], d["name"]
+        for cls in (getattr(bb, n) for n in PATH_CLASSES):
+            assert callable(getattr(cls, d["name"]))
+    # MultivariateSolution: __str__ and the read-only properties
+    sol = surf["MultivariateSolution"]
+    assert [d["name"] for d in sol["defs"]] == ["__str__"]
+    for prop in sol["properties"]:
+        assert isinstance(getattr(bb.MultivariateSolution, prop), property)
+        assert getattr(bb.MultivariateSolution, prop).fset is None
 
 
 def test_solution_string_is_the_reference_format():

@@ -22,18 +22,27 @@ def _close(a, b, rtol=1e-12, atol=0., what=""):
     (37, 50, "rastrigin", True, True),        # ragged n and lambda, box, learning-rate adjustment
     (128, 256, "rosenbrock", False, False),
     (1500, 64, "sphere", False, True),        # n > 1024: 64 lanes per candidate
+    (24, 32, "ellipsoid", False, None),       # None: keyword omitted -> the reference's default
 ])
 def test_generation_matches_oracle(hip, oracle_lib, n, lam, obj, bound, adjustlr):
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     guess = rng.uniform(-4, 4, n)
-    g = hip.SepCMAES(mfev=10 ** 8, tol=1e-14, np=lam, sigma0=1.5, bound=bound, adjustlr=adjustlr,
-                     seed=99)
+    kw = {} if adjustlr is None else {"adjustlr": adjustlr}
+    g = hip.SepCMAES(mfev=10 ** 8, tol=1e-14, np=lam, sigma0=1.5, bound=bound, seed=99, **kw)
     g.initialize(getattr(hip.objectives, obj), lo, up, guess)
     g.set_state("record_normals", [1.0])
+    # the default path (py/multivariate_py.cpp:131-135 binds adjustlr=true): the oracle is told
+    # True explicitly, the device gets no keyword -- it must pick the same variant by itself
     o = po.cma(oracle_lib, "sep", 10 ** 8, 1e-14, lam, sigma0=1.5, bound=bound,
-               adjustlr=adjustlr)
+               adjustlr=True if adjustlr is None else adjustlr)
+    if adjustlr is None:
+        off = po.cma(oracle_lib, "sep", 10 ** 8, 1e-14, lam, sigma0=1.5, bound=bound,
+                     adjustlr=False)
+        off.init(obj, lo, up, guess)
+        o.init(obj, lo, up, guess)
+        assert off.scalar("ccov") != o.scalar("ccov")      # the variants do differ here
     o.set_rng(po.RNG_INJECT)
     o.init(obj, lo, up, guess)
     for key in ("mueff", "cc", "cs", "ccov", "damps", "chi"):
