@@ -67,16 +67,6 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    # A torch.distributed program (RANK set by torchrun) uses torch's CUDA tensors for its
-    # collectives, and torch bundles its own HIP runtime: it must be the one the process loads
-    # FIRST -- imported after this library's, torch finds "no HIP GPUs" (measured).  Programs
-    # that import torch themselves before creating an optimizer need nothing.
-    import sys
-    if "torch" not in sys.modules and os.environ.get("RANK") is not None:
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "bboptpy_amd: %s is missing. Build it with `python __graft_entry__.py` (hipcc, "

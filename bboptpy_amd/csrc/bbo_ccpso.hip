@@ -271,19 +271,38 @@ void CcpsoEngine::phase(int which)
     timer_.collect();
 }
 
+// doubles per table in one rank's record: room for the largest block a rank can own
+// (ceil(max swarms / world) swarms of np particles; max swarms = n / the smallest swarm size)
+int CcpsoEngine::shard_stride() const
+{
+    int smin = c_.pps[0];
+    for (int k = 1; k < c_.npps; k++) smin = std::min(smin, c_.pps[k]);
+    const int smax = c_.n / std::max(1, smin);
+    return ((smax + c_.shard_world - 1) / c_.shard_world) * c_.np;
+}
+
 int CcpsoEngine::table_record() const
 {
-    return 2 * c_.n * c_.np;      // fX | fY at full capacity (n swarms of one coordinate)
+    return 2 * shard_stride();    // fX block | fY block of this rank's swarms
 }
 
 void CcpsoEngine::export_tables(double *dst, bool device_memory)
 {
     if (!inited_) throw Error(BBO_ERR_STATE, "export_tables before initialize()");
     BBO_HIP(hipSetDevice(params_.device));
-    const size_t cap = (size_t) c_.n * c_.np;
-    const hipMemcpyKind kind = device_memory ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    BBO_HIP(hipMemcpyAsync(dst, fX_.p, cap * sizeof(double), kind, stream_));
-    BBO_HIP(hipMemcpyAsync(dst + cap, fY_.p, cap * sizeof(double), kind, stream_));
+    const int stride = shard_stride();
+    double *out = dst;
+    if (!device_memory) {
+        if (stage_.count != (size_t) 2 * stride) stage_.alloc((size_t) 2 * stride);
+        out = stage_.p;
+    }
+    hipLaunchKernelGGL(ccp_export, dim3((stride + 255) / 256), dim3(256), 0, stream_, d_, c_, out,
+            stride);
+    BBO_HIP(hipGetLastError());
+    if (!device_memory)
+        BBO_HIP(hipMemcpyAsync(dst, out, (size_t) 2 * stride * sizeof(double),
+                hipMemcpyDeviceToHost, stream_));
+    // the caller's collective runs on another stream: the record must be complete when we return
     BBO_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -292,23 +311,37 @@ void CcpsoEngine::merge_tables(const double *gathered, int world, bool device_me
     if (!inited_) throw Error(BBO_ERR_STATE, "merge_tables before initialize()");
     BBO_REQUIRE(world == c_.shard_world, "merge_tables: world differs from the shard setting");
     BBO_HIP(hipSetDevice(params_.device));
-    const int cap = c_.n * c_.np;
+    const int stride = shard_stride();
     const double *src = gathered;
     if (!device_memory) {
-        const size_t cnt = (size_t) world * 2 * cap;
+        const size_t cnt = (size_t) world * 2 * stride;
         if (gather_.count != cnt) gather_.alloc(cnt);
         gather_.upload(gathered, cnt);
         src = gather_.p;
     }
+    const int cap = c_.n * c_.np;
     hipLaunchKernelGGL(ccp_merge, dim3((cap + 255) / 256), dim3(256), 0, stream_, d_, c_, src,
-            world, cap);
+            world, stride);
     BBO_HIP(hipGetLastError());
-    BBO_HIP(hipStreamSynchronize(stream_));
+    // (no host synchronisation: phase(1) is ordered behind the merge on the engine's stream; a
+    // device-memory `gathered` must stay untouched until the next export, which synchronises)
+    if (!device_memory) BBO_HIP(hipStreamSynchronize(stream_));
+}
+
+// Once the swarm groups are sharded, a generation is phase(0) / merge / phase(1): the plain entry
+// points would evaluate this rank's block only and update from stale rows for every other swarm.
+void CcpsoEngine::require_unsharded(const char *what) const
+{
+    if (c_.shard_world > 1)
+        throw Error(BBO_ERR_STATE, std::string(what) + ": the swarm groups are sharded over " +
+                std::to_string(c_.shard_world) + " ranks -- drive generations with "
+                "bbo_ccpso_phase(0) / bbo_ccpso_merge_tables / bbo_ccpso_phase(1)");
 }
 
 void CcpsoEngine::iterate()
 {
     if (!inited_) throw Error(BBO_ERR_STATE, "iterate() before initialize()");
+    require_unsharded("iterate()");
     BBO_HIP(hipSetDevice(params_.device));
     generation(false);
     BBO_HIP(hipStreamSynchronize(stream_));
@@ -327,6 +360,7 @@ bool CcpsoEngine::all_stopped()
 int CcpsoEngine::run(int max_generations)
 {
     if (!inited_) throw Error(BBO_ERR_STATE, "run() before initialize()");
+    require_unsharded("run()");
     BBO_HIP(hipSetDevice(params_.device));
     // (the reference's loop is `while (true) { iterate(); ... }`: at least one generation)
     const int poll = params_.poll_every > 0 ? params_.poll_every : 8;
@@ -371,6 +405,7 @@ void CcpsoEngine::solution(int population, double *x_out, int *n_evals, int *con
 void CcpsoEngine::optimize(int n, const double *lower, const double *upper, const double *guess,
         const ObjectiveSpec &obj, double *x_out, int *n_evals, int *converged)
 {
+    require_unsharded("optimize()");
     init(n, lower, upper, guess, obj);
     run(std::numeric_limits<int>::max());
     int conv = 0;

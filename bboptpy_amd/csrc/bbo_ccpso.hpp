@@ -59,7 +59,7 @@ public:
     // ---- swarm groups sharded over GPUs (one population; bbo_ccpso_* of the C ABI) ----------
     void set_shard(int rank, int world);
     void phase(int which);                 // 0: regroup + evaluate this rank's swarms, 1: the rest
-    int table_record() const;              // doubles in one rank's record: fX | fY, full capacity
+    int table_record() const;              // doubles in one rank's record: fX | fY blocks of its swarms
     void export_tables(double *dst, bool device_memory);
     void merge_tables(const double *gathered, int world, bool device_memory);
 
@@ -70,6 +70,8 @@ private:
     void host_eval_candidates();
     void host_eval_yhat();
     bool all_stopped();
+    int shard_stride() const;
+    void require_unsharded(const char *what) const;
 
     bbo_params params_;
     ObjectiveSpec obj_;
@@ -79,7 +81,7 @@ private:
     bool inited_ = false;
     int shard_rank_ = 0, shard_world_ = 1;     // survive init() (c_ is rebuilt there)
     std::vector<double> aux_h_;
-    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, rpart_, lower_, upper_, aux_, gather_;
+    DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, rpart_, lower_, upper_, aux_, gather_, stage_;
     DevBuf<int> ibest_, strat_, range_, grp_of_;
     DevBuf<CcpScal> scal_;
     KernelTimer timer_;

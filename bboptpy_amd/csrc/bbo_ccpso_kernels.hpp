@@ -221,11 +221,31 @@ __global__ __launch_bounds__(256) void ccp_eval(CcpDev d, CcpConst c)
     }
 }
 
-// sharded swarm groups: record r of `gathered` (fX | fY of rank r, `cap` doubles each) holds the
-// fitness of the swarms rank r evaluated; take every swarm's rows from its owner.
+// sharded swarm groups.  A rank's record holds ONLY the rows of the swarms it evaluated: with
+// `stride` = ceil(max swarms / world) * np doubles per table, record r = [fX block | fY block],
+// block element (j - j0_r) * np + i for swarm j of rank r's range [j0_r, j1_r), particle i.
+// (Round 2 exchanged the two full-capacity tables per rank: W times the live data.)
+__device__ inline int ccp_shard_lo(int nswarm, int r, int world)
+{
+    return (int) ((long) nswarm * r / world);
+}
+
+// this rank's block into `dst` (device memory).  grid (ceil(stride / 256)), 256 threads
+__global__ __launch_bounds__(256) void ccp_export(CcpDev d, CcpConst c, double *dst, int stride)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x, np = c.np, nswarm = d.scal->nswarm;
+    if (q >= stride) return;
+    const int j0 = ccp_shard_lo(nswarm, c.shard_rank, c.shard_world);
+    const int j1 = ccp_shard_lo(nswarm, c.shard_rank + 1, c.shard_world);
+    const bool live = q < (j1 - j0) * np;
+    dst[q] = live ? d.fX[(size_t) j0 * np + q] : 0.;
+    dst[stride + q] = live ? d.fY[(size_t) j0 * np + q] : 0.;
+}
+
+// take every swarm's rows from the record of its owner.
 // grid (ceil(n * np / 256)), 256 threads; population 0 only
 __global__ __launch_bounds__(256) void ccp_merge(CcpDev d, CcpConst c, const double *gathered,
-        int world, int cap)
+        int world, int stride)
 {
     const CcpScal *sc = d.scal;
     const int q = blockIdx.x * 256 + threadIdx.x, np = c.np, nswarm = sc->nswarm;
@@ -233,11 +253,12 @@ __global__ __launch_bounds__(256) void ccp_merge(CcpDev d, CcpConst c, const dou
     const int j = q / np;
     int owner = 0;
     for (int r = 0; r < world; r++)
-        if (j >= (int) ((long) nswarm * r / world) && j < (int) ((long) nswarm * (r + 1) / world))
+        if (j >= ccp_shard_lo(nswarm, r, world) && j < ccp_shard_lo(nswarm, r + 1, world))
             owner = r;
-    const double *rec = gathered + (size_t) owner * 2 * cap;
-    d.fX[q] = rec[q];
-    d.fY[q] = rec[cap + q];
+    const double *rec = gathered + (size_t) owner * 2 * stride;
+    const int off = q - ccp_shard_lo(nswarm, owner, world) * np;
+    d.fX[q] = rec[off];
+    d.fY[q] = rec[stride + off];
 }
 
 // one WAVEFRONT per swarm j: personal bests, the swarm's contribution to yhat, ring local bests

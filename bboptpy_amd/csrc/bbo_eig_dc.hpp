@@ -596,8 +596,8 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     dc_wave_sync();
     EigMat blk { &Q(a, a), Q.ld };
     QlState st { 0, 0, 1, 0, 0., 0. };
-    // QL has no iteration limit in the reference either; the guard only bounds a run on
-    // non-finite input (30 sweeps per eigenvalue is far beyond anything observed)
+    // QL has no iteration limit in the reference; ql_produce_reg<true> stops after 30 sweeps per
+    // eigenvalue (a uniform counter), which only bounds a run on non-finite / subnormal input
     // (a lane touches only its own row of the block: the rotations need no fence among lanes)
     const int sweeps = ql_produce_reg<true>(st, s, d, e, rot, desc, 64, lane, blk);
     if (dbgout && lane == 0) dbgout[0] = sweeps;

@@ -251,6 +251,15 @@ __device__ inline int ql_produce_reg(QlState &st, int n, double &d, double &e, d
         }
         const int l = st.l, m = st.m, len = m - l;
         if (!FUSED && (count + len > rc || ns >= EIG_MAXSEQ)) break;
+        // Sweep bound of the fused form (one call does the whole block): the reference's tql2
+        // has no limit, but here a block that never converges would hang the GPU instead of
+        // returning a bad basis.  30 sweeps per eigenvalue is far beyond anything finite input
+        // needs (2-3 observed); the uniform counter ends the loop and the caller's repair /
+        // eigen_done path deals with what is left.
+        if (FUSED && ns >= 30 * n) {
+            st.done = 1;
+            break;
+        }
         const double thr = eps * st.tst1;
 
         // implicit shift (cmaes.cpp:405-417)

@@ -3,8 +3,9 @@ restarts (ConcurrentBiPop) and CCPSO with its swarm groups sharded over the rank
 at the end of this file).
 
 Import order: with backend "nccl" the collectives run on torch CUDA tensors, and torch brings its
-own HIP runtime, which has to be loaded before libbbopt_hip.so's: `import torch` (or let torchrun's
-RANK variable make bboptpy_amd._ffi do it) before the first optimizer is created.
+own HIP runtime, which has to be loaded before libbbopt_hip.so's: the two drivers import torch
+themselves (`torch_first`) when they are given a process group or run under torchrun (RANK set),
+and raise a clear error if the HIP library got there first.
 
 Concurrent BIPOP-CMA-ES across the GPUs of one node.
 
@@ -35,6 +36,38 @@ import numpy as _np
 
 from .multivariate import ActiveCMAES, CMAES, MultivariateSolution
 from .objectives import Builtin
+
+
+
+def torch_first(why):
+    """A torch.distributed program uses torch's CUDA tensors for its collectives, and torch
+    bundles its own HIP runtime, which must be the FIRST one the process loads -- imported after
+    libbbopt_hip.so torch finds "no HIP GPUs" (measured).  Called explicitly by the two drivers
+    below whenever a process group is in play; bboptpy_amd._ffi itself never imports torch."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    from . import _ffi
+    if _ffi._lib is not None and _ffi._lib.bbo_device_count() > 0:     # (no GPU: order is moot)
+        raise RuntimeError(
+            "%s: libbbopt_hip.so was loaded before torch.  `import torch` (and initialise the "
+            "process group) before the first bboptpy_amd optimizer is created." % why)
+    import torch  # noqa: F401
+
+
+def _group_wanted(group, world_size):
+    import os
+    return world_size is None and (group is not None or os.environ.get("RANK") is not None)
+
+
+def _device_of(dist, group, device):
+    """where the collective's buffers live: the engine's own GPU under nccl (NOT torch's current
+    device -- the caller may never have called torch.cuda.set_device), host memory otherwise"""
+    import torch
+    if dist.get_backend(group) != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", int(device or 0))
+
 
 _GOLDEN = 0x9E3779B97F4A7C15
 _M64 = (1 << 64) - 1
@@ -104,6 +137,8 @@ class ConcurrentBiPop:
         # eigensolver is one workgroup), so several of them share a GPU almost for free.
         self.slots = max(1, int(slots_per_rank))
         self._algs = {}
+        if _group_wanted(group, world_size):
+            torch_first("ConcurrentBiPop")
 
     # -- topology ---------------------------------------------------------------------------
     def _topology(self):
@@ -279,11 +314,12 @@ class ConcurrentBiPop:
                 import torch
                 mine = _np.concatenate(self._run_slots(f, slots[rank * S:(rank + 1) * S], st, total,
                                                        rank * S))
-                dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+                dev = _device_of(dist, self.group, self.device)
                 mine_t = torch.from_numpy(mine).to(dev)
                 out = [torch.empty_like(mine_t) for _ in range(world)]
                 dist.all_gather(out, mine_t, group=self.group)
                 records = [r for t in out for r in t.cpu().numpy().reshape(S, reclen)]
+                self.collectives = getattr(self, "collectives", 0) + 1
             else:
                 # no process group: every rank's slots run in this process, rank after rank (the
                 # serial stand-in for the collective -- same plan, same reduction)
@@ -319,8 +355,15 @@ class ShardedCCPSO:
     (the serial stand-in for the collective: same plan, same merge)."""
 
     def __init__(self, mfev, sigmatol, np, pps, npps=None, correct=True, pcauchy=-1., seed=0,
-                 device=None, group=None, engine_factory=None, world_size=None, rank=None):
+                 device=None, group=None, engine_factory=None, world_size=None, rank=None,
+                 always_exchange=False):
         self.mfev = int(mfev)
+        # always_exchange: run the all-gather + merge even in a group of ONE rank (where the
+        # merge is the identity) -- how the RCCL path is exercised on a one-GPU machine
+        self._always = bool(always_exchange)
+        self.collectives = 0
+        if _group_wanted(group, world_size) and engine_factory is None:
+            torch_first("ShardedCCPSO")
         self._ctor = dict(mfev=mfev, sigmatol=sigmatol, np=np, pps=pps, npps=npps,
                           correct=correct, pcauchy=pcauchy)
         self.seed, self.device, self.group = int(seed) & _M64, device, group
@@ -368,7 +411,7 @@ class ShardedCCPSO:
         W = self.world
         for e in self._engines:
             e.phase(0)
-        if W == 1:
+        if W == 1 and not (self._always and self._dist is not None):
             pass                                  # one rank evaluated every swarm: nothing to merge
         elif self._dist is None:                  # serial stand-in: all ranks live in this process
             gathered = _np.stack([e.export_tables() for e in self._engines])
@@ -378,21 +421,23 @@ class ShardedCCPSO:
             import torch
             dist, e = self._dist, self._engines[0]
             reclen = e.table_record()
-            on_gpu = dist.get_backend(self.group) == "nccl"
+            dev = _device_of(dist, self.group, self.device)
+            on_gpu = dev.type == "cuda"
             if self._buf is None:
-                dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu"
                 self._buf = (torch.zeros(reclen, dtype=torch.float64, device=dev),
                              torch.zeros(W * reclen, dtype=torch.float64, device=dev))
             mine, allrec = self._buf
             if on_gpu:                            # device to device: the record never visits the host
                 e.export_tables(device_ptr=mine.data_ptr())
-                dist.all_gather_into_tensor(allrec, mine, group=self.group)
-                torch.cuda.current_stream().synchronize()
+                with torch.cuda.device(dev):      # RCCL launches on the current device's stream
+                    dist.all_gather_into_tensor(allrec, mine, group=self.group)
+                    torch.cuda.current_stream(dev).synchronize()
                 e.merge_tables(world=W, device_ptr=allrec.data_ptr())
             else:
                 e.export_tables(out=mine.numpy())
                 dist.all_gather(list(allrec.view(W, reclen).unbind(0)), mine, group=self.group)
                 e.merge_tables(allrec.numpy(), W)
+            self.collectives += 1
         for e in self._engines:
             e.phase(1)
 

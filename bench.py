@@ -490,15 +490,11 @@ def kernel_report(names, costs, prof, workload, P):
 def spawn_ranks(n_gpus):
     """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree before
     this process has touched the GPU (never exec after HIP init), pass their output through"""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks a free rendezvous port itself (no bind/close/reuse race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr",
+           "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode

@@ -245,8 +245,11 @@ int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out);
  * and a generation becomes: phase 0 (regroup + evaluate this block) on every rank, ONE
  * all-gather of the fitness records, bbo_ccpso_merge_tables, phase 1 (the rest of updateSwarm,
  * updatePosition, the stop test: replicated, identical on every rank).  A record is
- * bbo_ccpso_table_record(h) doubles (fX | fY at full capacity); `device_memory` != 0 says the
- * caller's pointer is device memory (e.g. an RCCL buffer), else host memory.  One population. */
+ * bbo_ccpso_table_record(h) doubles: only the rows of the swarms this rank evaluated, fX block
+ * | fY block, each ceil(max swarms / world) * np doubles (max swarms = n / the smallest swarm
+ * size); `device_memory` != 0 says the caller's pointer is device memory (e.g. an RCCL buffer),
+ * else host memory.  One population.  While world > 1, bbo_iterate / bbo_run / bbo_optimize
+ * return BBO_ERR_STATE: only the phase / merge protocol advances a sharded handle. */
 int bbo_ccpso_set_shard(bbo_handle h, int rank, int world);
 int bbo_ccpso_phase(bbo_handle h, int phase);
 int bbo_ccpso_table_record(bbo_handle h);

@@ -163,7 +163,12 @@ def test_c3_batched_matches_oracle(hip, oracle_lib):
 
 
 @pytest.mark.parametrize("n,lam,obj", [(128, 512, "rosenbrock"), (128, 4096, "ellipsoid"),
-                                       (64, 200, "rosenbrock")])
+                                       (64, 200, "rosenbrock"),
+                                       # n = 256 (C5): L2-streaming Householder steps, the external
+                                       # top merge, cma_eig_gemm / cma_eig_wy
+                                       (256, 40, "rosenbrock"), (256, 512, "ellipsoid"),
+                                       # n > 256: Householder with accumulation + the serial QL
+                                       (300, 40, "rosenbrock")])
 def test_eigen_to_sample_coupling_with_the_oracles_own_basis(hip, oracle_lib, n, lam, obj):
     """The phase tests above hand the device's (B, D, C^-1/2) to the oracle every generation, so
     what the NEXT generation samples through is only checked by invariants.  Here the oracle
@@ -220,3 +225,32 @@ def test_eigen_to_sample_coupling_with_the_oracles_own_basis(hip, oracle_lib, n,
                1e-10, "C gen %d" % gen)
         _close(g.get_state("D"), o.get("D"), 1e-10, "D gen %d" % gen)
     o.destroy()
+
+
+# ---- generations to the reference's own stop (the second half of BASELINE.json's metric) -------
+# BASELINE.md section 2, measured on the reference's C++ (ActiveCmaes(mfev, 1e-4, lambda),
+# Rosenbrock, [-10, 10]^n): n = 128, lambda = 4096 -> generation 2047, flag 5 (TolUpSigma,
+# cmaes.cpp:193), f = 84.4; lambda = 1024 -> generations 6228 / 6230 (seeds 1, 2), flag 2
+# (TolHistFun, cmaes.cpp:160), f = 1.2e-4 / 6.8e-5.
+@pytest.mark.parametrize("lam,ref_gens,ref_flag,f_lo,f_hi", [
+    (4096, 2047, 5, 60., 110.),          # M: stops short of the optimum, like the reference
+    (1024, 6229, 2, 0., 1e-3),           # C3
+])
+def test_generations_to_the_reference_stop(hip, lam, ref_gens, ref_flag, f_lo, f_hi):
+    """the device stops where the reference stops: 8 seeded populations under the reference's
+    whole stop rule (tol = 1e-4, cmaes.cpp:151-227) -- median generation count within 1 % of the
+    reference's, every population with the reference's stop flag and its final f range"""
+    n, pops = 128, 8
+    lo, up = -10. * np.ones(n), 10. * np.ones(n)
+    guess = np.random.default_rng(11).uniform(-10, 10, (pops, n))
+    alg = hip.ActiveCMAES(mfev=2 ** 31 - 1, tol=1e-4, np=lam, seed=11, populations=pops)
+    alg.initialize(hip.objectives.rosenbrock, lo, up, guess)
+    launched = alg.run(3 * ref_gens)
+    assert launched < 3 * ref_gens                       # every population stopped by itself
+    its = [int(alg.get_state("it", p)[0]) for p in range(pops)]
+    flags = [int(alg.get_state("flag", p)[0]) for p in range(pops)]
+    fbest = [float(alg.get_state("fit_val", p)[0]) for p in range(pops)]
+    assert flags == [ref_flag] * pops, (flags, its)
+    assert abs(np.median(its) - ref_gens) <= 0.01 * ref_gens, its
+    assert max(abs(i - ref_gens) for i in its) <= 0.03 * ref_gens, its
+    assert all(f_lo <= f <= f_hi for f in fbest), fbest

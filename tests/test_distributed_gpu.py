@@ -130,6 +130,27 @@ def test_sharded_ccpso_on_device_equals_unsharded(hip, n, npp, pps, obj):
                 np.testing.assert_array_equal(e.get_state("y"), want[g][5])
 
 
+def test_sharded_handle_refuses_the_unsharded_entry_points(hip):
+    """once the swarm groups are sharded (world > 1) only phase(0) / merge / phase(1) is a valid
+    generation: iterate / run / optimize would update from stale rows, so they report
+    BBO_ERR_STATE; and a rank's record holds its own block only (ceil(max swarms / W) np rows)"""
+    from bboptpy_amd import _ffi
+    n, npp, pps = 60, 10, [2, 3, 5]
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    e = hip.CCPSO(mfev=10 ** 6, sigmatol=1e-12, np=npp, pps=pps, seed=8)
+    e.set_shard(1, 3)
+    e.initialize(hip.objectives.rosenbrock, lo, up, np.zeros(n))
+    assert e.table_record() == 2 * ((n // 2 + 2) // 3) * npp
+    for call in (e.iterate, lambda: e.run(3)):
+        with pytest.raises(_ffi.BboError) as ei:
+            call()
+        assert ei.value.status == -2 and "sharded" in str(ei.value)
+    e.set_shard(0, 1)                      # back to one rank: the plain entry points work again
+    e.initialize(hip.objectives.rosenbrock, lo, up, np.zeros(n))
+    e.iterate()
+    assert int(e.get_state("fev")[0]) > 0
+
+
 def test_sharded_ccpso_host_objective_splits_the_calls(hip):
     """a Python objective: each of the W ranks calls it only for its own swarms' candidates
     (plus the replicated yhat re-evaluation), and the optimum found is the unsharded one's"""
