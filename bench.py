@@ -368,7 +368,17 @@ def max_over_ranks(dt):
     return float(t.item())
 
 
-def bipop_leg(bb, world, rank, local_rank, use_dist, budget_per_rank, barrier=None, slots=1):
+# The bounded C5 leg of every default line.  Sized so that ONE GPU shows the BIPOP schedule, not
+# just its first run: inner tol 0.5 ends a run when sigma has about halved (TolX, cmaes.cpp:180-191)
+# -- the first default run (lambda = 20) stops after ~1.2 s -- and 40000 evaluations per GPU then
+# cover the first run, a large-regime restart and several small-regime ones (measured on one
+# MI355X: 6 rounds, 1 large + 4 small restarts, 5.2 s).  bipop_cmaes.cpp:117-142,204-267.
+C5_LEG_TOL = 0.5
+C5_LEG_BUDGET = 40000
+
+
+def bipop_leg(bb, world, rank, local_rank, use_dist, budget_per_rank, barrier=None, slots=1,
+              tol=1e-8):
     """concurrent BIPOP-CMA-ES n = 256 Rastrigin over `world` ranks (C5): rounds of `slots`
     restarts per GPU (1 = the configuration as BASELINE.json words it), one RCCL all-gather of
     slots * (n + 7) doubles per round.  Returns on every rank (evaluations of all ranks, seconds =
@@ -378,7 +388,7 @@ def bipop_leg(bb, world, rank, local_rank, use_dist, budget_per_rank, barrier=No
     lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
     guess = np.random.default_rng(7).uniform(-5.12, 5.12, n)
     budget = budget_per_rank * world * slots
-    drv = ConcurrentBiPop(mfev=budget, tol=1e-8, sigma0=2., seed=2024, device=local_rank,
+    drv = ConcurrentBiPop(mfev=budget, tol=tol, sigma0=2., seed=2024, device=local_rank,
                           variant="active", slots_per_rank=slots)
     if barrier:
         barrier()
@@ -400,9 +410,10 @@ def c5_inner_profile(bb, device, lam=20, gens=150):
     return wl, prof
 
 
-def c5_cpu_baseline(budget_evals=3000):
-    """the reference's BiPopCmaes (or the oracle's restatement of it) on one host core: its
-    first default-lambda run at n = 256 Rastrigin, bounded to `budget_evals` evaluations"""
+def c5_cpu_baseline(budget_evals=3000, tol=1e-8):
+    """the reference's BiPopCmaes (or the oracle's restatement of it) on one host core at n = 256
+    Rastrigin, bounded to `budget_evals` evaluations (with tol = 1e-8 that is part of its first
+    default-lambda run; with the C5 leg's tol the schedule gets as far as the budget lets it)"""
     import pyoracle as po
     lib = po.reference()
     kind = "reference" if lib is not None else "port"
@@ -412,14 +423,19 @@ def c5_cpu_baseline(budget_evals=3000):
     lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
     guess = np.random.default_rng(7).uniform(-5.12, 5.12, n)
     lib.seed(1)
-    h = po.bipop(lib, po.cma(lib, "active", 1, 1e-8, 4), budget_evals)
+    h = po.bipop(lib, po.cma(lib, "active", 1, tol, 4), budget_evals)
     t0 = time.perf_counter()
     h.init("rastrigin", lo, up, guess)
+    restarts = 0
+    while h.scalar("fev") < budget_evals and h.scalar("largerestarts") < 9:
+        h.iterate()                                   # bipop_cmaes.cpp:170-189
+        restarts += 1
     dt = time.perf_counter() - t0
     fev = h.scalar("fev")
     return {"value": fev / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
-            "sample": "BiPopCmaes(ActiveCmaes) n=256 rastrigin, first run (lambda=20) capped at "
-                      "%d evaluations, 1 thread, %.1f s" % (budget_evals, dt)}
+            "sample": "BiPopCmaes(ActiveCmaes, tol=%g) n=256 rastrigin, budget %d evaluations "
+                      "(first run + %d restarts), 1 thread, %.1f s" % (tol, budget_evals, restarts,
+                                                                         dt)}
 
 
 def bench_bipop(args, world, rank, local_rank, use_dist, barrier):
@@ -566,19 +582,37 @@ def main():
     # BIPOP multi-restart scaling (north_star): a bounded C5 leg at this world size, all ranks
     bipop = None
     if args.workload == "M" and not args.no_bipop:
-        st, bdt, budget = bipop_leg(bb, world, rank, local_rank, use_dist, 20000, barrier)
-        bipop = {"workload": "BIPOP-CMA-ES (ActiveCMAES inner) n=256 rastrigin, one concurrent "
-                             "restart population per GPU, %d evaluations per GPU" % 20000,
+        st, bdt, budget = bipop_leg(bb, world, rank, local_rank, use_dist, C5_LEG_BUDGET, barrier,
+                                    tol=C5_LEG_TOL)
+        bipop = {"workload": "BIPOP-CMA-ES (ActiveCMAES inner, tol %g) n=256 rastrigin, one "
+                             "concurrent restart population per GPU, %d evaluations per GPU"
+                             % (C5_LEG_TOL, C5_LEG_BUDGET),
                  "n_gpus": world, "value": st.fev / bdt, "unit": "candidate-evals/s",
                  "wall_s": bdt, "rounds": st.round, "restarts": len(st.history),
+                 "large_restarts": st.largerestarts, "small_restarts": st.smallrestarts,
                  "evaluations": st.fev, "best_f": st.fxbest, "scaling": "weak"}
         # the same with 8 concurrent restart populations PACKED on every GPU (an inner run keeps
         # about one compute unit busy: the n = 256 eigensolver is one workgroup)
-        st8, bdt8, _ = bipop_leg(bb, world, rank, local_rank, use_dist, 20000, barrier, slots=8)
+        st8, bdt8, _ = bipop_leg(bb, world, rank, local_rank, use_dist, C5_LEG_BUDGET, barrier,
+                                 slots=8, tol=C5_LEG_TOL)
         bipop["packed_8_per_gpu"] = {"value": st8.fev / bdt8, "unit": "candidate-evals/s",
                                      "wall_s": bdt8, "rounds": st8.round,
-                                     "restarts": len(st8.history), "evaluations": st8.fev,
-                                     "best_f": st8.fxbest}
+                                     "restarts": len(st8.history),
+                                     "large_restarts": st8.largerestarts,
+                                     "small_restarts": st8.smallrestarts,
+                                     "evaluations": st8.fev, "best_f": st8.fxbest}
+        if rank == 0 and world == 1:
+            # what an inner run is made of (ActiveCMAES n = 256, lambda = lambda_def): per-kernel
+            # device time and the roofline of its dominant kernel; and the reference's own
+            # BiPopCmaes on one host core under the same tol, bounded to ~15 s
+            wl5, prof5 = c5_inner_profile(bb, local_rank)
+            k5, r5 = kernel_report(CMA_KERNELS, cma_kernel_costs(wl5["n"], wl5["np"], 1), prof5,
+                                   "C5", 1)
+            bipop["inner_run_roofline"] = r5
+            bipop["inner_run_kernels"] = {k: {"avg_us": v["avg_us"], "share": v["share"]}
+                                          for k, v in k5.items()}
+            if not args.no_cpu_baseline:
+                bipop["cpu_baseline"] = c5_cpu_baseline(10000, tol=C5_LEG_TOL)
 
     if rank == 0:
         # per-kernel device time (HIP events on the engine's stream) -> roofline
