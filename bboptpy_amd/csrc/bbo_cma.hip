@@ -914,12 +914,12 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     }
     if (k == "eig_stamps") {
         if (!stamps_.p) return 0;
-        if (out && cap >= 32) {
-            long long t[32];
-            stamps_.download(t, 32);
-            for (int i = 0; i < 32; i++) out[i] = (double) t[i];
+        if (out && cap >= 48) {
+            long long t[48];
+            stamps_.download(t, 48);
+            for (int i = 0; i < 48; i++) out[i] = (double) t[i];
         }
-        return 32;
+        return 48;
     }
     if (k == "best_hist" || k == "kth_hist") {
         if (out && cap >= c.hlen)
@@ -1043,7 +1043,7 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         return 1;
     }
     if (k == "eig_stamps") {
-        if (stamps_.count != 32) stamps_.alloc(32);
+        if (stamps_.count != 48) stamps_.alloc(48);    // [32..47]: step clocks of diagnostic builds
         d_.stamps = stamps_.p;
         return 1;
     }

@@ -47,6 +47,19 @@ constexpr int EIG_NVEC = 9;   // d, e, u, w, g, h, tdiag, uh0, uh1
 // their slabs in step would otherwise land on the same L2 / HBM channels)
 __host__ __device__ inline size_t eig_slab(int ld) { return (size_t) (ld + 32) * (ld + 32) + 72; }
 
+// doubles of the `part` area behind the nine LDS vectors: [4][vl] column partial sums of the generic
+// path; the hybrid (128 < n <= 256, D&C) keeps eight 128-column slabs of its transposed product and
+// the previous step's u / w (2 x 128) there
+__host__ __device__ inline int eig_part_doubles(int vl, bool reg_path, bool hybrid)
+{
+    if (reg_path) return 0;
+    const int generic = 4 * vl;
+    if (!hybrid) return generic;
+    // vl >= 256 (n > 224): u / w of the previous step live in the free vector uh1 instead -- at
+    // n = 256 the LDS matrix leaves no room for 256 more doubles here
+    return vl >= 256 ? (generic > 1024 ? generic : 1024) : 1280;
+}
+
 inline EigPlan eig_plan(int n, int ld)
 {
     EigPlan pl {};
@@ -56,7 +69,8 @@ inline EigPlan eig_plan(int n, int ld)
     pl.dc = n <= 256 ? 1 : 0;          // 128 < n <= 256: matrix in global memory, top merge external
     const size_t budget = 160 * 1024 - 1024;
     const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
-    const size_t vecs = (size_t) (EIG_NVEC + (pl.reg_path ? 0 : 4)) * pl.vl * sizeof(double);
+    const size_t vecs = ((size_t) EIG_NVEC * pl.vl
+            + eig_part_doubles(pl.vl, pl.reg_path != 0, pl.dc && !pl.reg_path)) * sizeof(double);
     const int lda_lds = n | 1;
     const size_t mat = (size_t) n * lda_lds * sizeof(double);
     const size_t fixed = vecs + ints;
@@ -608,6 +622,444 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// 128 < n <= 256 (BIPOP's n = 256), D&C stage: the first n - 128 Householder steps with the
+// whole ACTIVE matrix on chip, by symmetry.  Blocks of A = [L11 L21^T; L21 L22] (128 + (n - 128)):
+//   L11  LDS (row stride 130), full, as before;
+//   L22  registers, full, thread (row 128 + (tid >> 2), class tid & 3) owns 32 columns of its row
+//        (the layout of the register-resident code above);
+//   L21  registers, as 4-row x 8-column PATCHES: wavefront w, lane l owns rows 128 + 16 w +
+//        4 (l >> 4) + k (k < 4) and columns 8 (l & 15) + c (c < 8);
+//   L12  is NOT kept: round 2 streamed it (and L22) from L2 every step -- 29 k cycles per step,
+//        19 k of them the rank-2 update's loads queueing behind its own stores.
+// The product A u then needs L21 twice: rows (L21 u_top: four sums per thread, all-reduced over
+// the 16 lanes of a DPP row by rotations) and columns (L21^T u_bot: eight sums per thread, reduced
+// over the four row groups of the wavefront by two half-exchanges, v_permlane16_swap and
+// v_permlane32_swap -- after the swap of (A, B) a lane holds its own and its partner's copy of the
+// half it keeps, no select -- and over the wavefronts through an 8 x 128 LDS slab added in wave
+// order, so the result does not depend on timing).  The rank-2 update touches L11 in LDS and the
+// two register blocks; nothing streams.  Reflector i (i >= 128) goes to row i of the global work
+// matrix (read back by cma_eig_wy), the leading 128 x 128 block then finishes in
+// eig_tred_accum_reg128 exactly as before.  Sums are formed in a different order than the
+// streaming code formed them: equal to rounding.
+// ---------------------------------------------------------------------------
+__device__ inline void eig_swap_rows16(double &a, double &b)     // a: odd 16-lane rows <-> b: even rows
+{
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a);
+    unsigned blo = __double2loint(b), bhi = __double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int) r1[0], (int) r0[0]);
+    b = __hiloint2double((int) r1[1], (int) r0[1]);
+}
+
+__device__ inline void eig_swap_half32(double &a, double &b)     // a: lanes 32..63 <-> b: lanes 0..31
+{
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a);
+    unsigned blo = __double2loint(b), bhi = __double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int) r1[0], (int) r0[0]);
+    b = __hiloint2double((int) r1[1], (int) r0[1]);
+}
+
+__device__ inline double eig_row16_sum(double v)      // all 16 lanes of a DPP row get the row's sum
+{
+    v += eig_dpp<0x128>(v);   // row_ror:8
+    v += eig_dpp<0x124>(v);   // row_ror:4
+    v += eig_dpp<0x122>(v);   // row_ror:2
+    v += eig_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+
+// A REAL function (noinline): inlined into cma_eigen_body, whose register allocation already runs
+// at 256 VGPRs with ~490 spilled SGPRs, the 128 matrix registers of this loop were spilled and
+// reloaded EVERY step (1.69 ms for the 128 steps of n = 256, no better than streaming from L2).
+// It names the LDS vectors itself (same layout as cma_eigen_body, from nv): through pointer
+// arguments the compiler would lose the address space and emit flat loads.
+#ifdef BBO_EIG_STEP_CLOCKS
+#define EIG_CLK(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        clk[slot] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define EIG_CLK(slot) do { } while (0)
+#endif
+__device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C, int ld, int n,
+        double *Aglob, int lda, int nv, long long *stamps)
+{
+#ifdef BBO_EIG_STEP_CLOCKS
+    unsigned long long clk[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = EIG_THREADS, LB = 130;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nr = (n + 31) & ~31;
+    double *dv = lds + 2, *ev = dv + nv, *uv = ev + nv, *wv = uv + nv, *gv = wv + nv;
+    double *hvec = gv + nv, *td = hvec + nv, *gv2 = td + nv /* uh0 */, *uh1 = gv2 + nv;
+    double *part = uh1 + nv - 2;
+    // (hybrid plan: no chunk buffers, rc = 0 -- the LDS matrix follows the integer block)
+    double *L11 = reinterpret_cast<double*>(reinterpret_cast<int*>(part + eig_part_doubles(nv, false, true))
+            + 2 * EIG_MAXSEQ * 3 + 8);
+    // ---- load: L11 -> LDS, L22 and L21 -> registers ------------------------------------------
+    for (int q = tid; q < 128 * 64; q += T) {
+        const int r = q >> 6, c2 = (q & 63) * 2;
+        *reinterpret_cast<double2*>(&L11[r * LB + c2]) =
+                make_double2(C[(size_t) r * ld + c2], C[(size_t) r * ld + c2 + 1]);
+    }
+    for (int k = tid; k < nr; k += T) {
+        dv[k] = k < n ? C[(size_t) (n - 1) * ld + k] : 0.;
+        hvec[k] = 0.;
+        uv[k] = 0.;
+        wv[k] = 0.;
+    }
+    const int rq = tid & 3, rj0 = tid >> 2;          // L11 / L22 rows: 4 lanes per row
+    const int R22 = 128 + rj0;
+    double2 r22[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c2 = 128 + 32 * a + 8 * rq + 2 * b;
+            r22[a][b] = make_double2((R22 < n && c2 < n) ? C[(size_t) R22 * ld + c2] : 0.,
+                                     (R22 < n && c2 + 1 < n) ? C[(size_t) R22 * ld + c2 + 1] : 0.);
+        }
+    const int cg = lane & 15, rgw = lane >> 4;        // L21 patches
+    const int P0 = 128 + 16 * wave + 4 * rgw;         // first row of this thread's patch
+    double2 p21[4][4];                                // [row k][column pair b]: columns 8 cg + 2 b
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = P0 + k, c2 = 8 * cg + 2 * b;
+            p21[k][b] = r < n ? make_double2(C[(size_t) r * ld + c2], C[(size_t) r * ld + c2 + 1])
+                              : make_double2(0., 0.);
+        }
+    const int bit4 = (lane >> 4) & 1, bit5 = lane >> 5;
+    const int mycol = 8 * cg + 4 * bit4 + 2 * bit5;   // the column pair this lane ends up with
+
+    // per-thread LDS bases: everything below is base + immediate offset
+    double *uq = uv + 8 * rq, *wq = wv + 8 * rq, *dq = dv + 8 * rq;     // 4-lanes-per-row layout
+    double *uc = uv + 8 * cg, *wc = wv + 8 * cg, *dc = dv + 8 * cg;     // patch columns
+    double *uP = uv + P0, *wP = wv + P0;                                // patch rows
+    double *lrow = L11 + rj0 * LB + 8 * rq;
+    // L11 lives in LDS, so its rank-2 update is DEFERRED by one step and applied on the fly when
+    // the next product reads the block (one read + one write of the block per step instead of a
+    // read for the product and a read + write for the update): up / wp keep the previous step's
+    // u and w for rows / columns < 128 (zero before the first step)
+    double *up = nv >= 256 ? uh1 : part + 1024, *wp = up + 128;
+    double *upq = up + 8 * rq, *wpq = wp + 8 * rq;
+    if (tid < 256) up[tid] = 0.;               // (up and wp are adjacent)
+#define EIG_SEQ() __builtin_amdgcn_sched_barrier(0)   /* keeps one column group's loads in flight, not all */
+    // The steps synchronise through LDS only.  __syncthreads() would also wait for the stash row's
+    // GLOBAL stores (vmcnt(0): a round trip to L2, ~1 us, every step); nothing in this loop reads
+    // them -- the full barrier after the loop orders them before the V pass.
+#define EIG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    __syncthreads();
+    for (int i = n - 1; i >= 128; i--) {
+        EIG_CLK(7);
+        EIG_LDS_BARRIER();                             // dv = row i of A (columns < i, and A(i, i))
+        EIG_CLK(0);
+        const int ir = (i + 31) & ~31;
+        const bool wact = 128 + 16 * wave < i;         // this wavefront's bottom rows are active
+        const int GA2 = (i - 128 + 31) >> 5;           // 32-column groups of L22 still active
+        double dk[4];
+        double hs = 0.;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            // (unconditional read: lane + 64 m <= 255 stays inside the LDS vectors; masked after)
+            const double t = dv[lane + 64 * m];
+            dk[m] = lane + 64 * m < i ? t : 0.;
+            hs = __builtin_fma(dk[m], dk[m], hs);
+        }
+        const double h0 = eig_wave_sum(hs);
+        const double f = dv[i - 1];
+        const double tdi = dv[i];
+        // h0 == 0 (the row is already reduced): u = 0, w = 0 -- the step then changes nothing and
+        // publishes the next row like any other (tred2 skips the transformation, cmaes.cpp:300-305)
+        const bool live = h0 != 0.;
+        // root and reciprocal as in the register-resident steps: hardware estimates + Newton
+        double g;
+        {
+            double y = __builtin_amdgcn_rsq(live ? h0 : 1.);
+            const double hq = live ? h0 : 1.;
+            const double err = fma(-hq * y, y, 1.);
+            y = fma(y * err, fma(err, 0.375, 0.5), y);
+            g = hq * y;
+            g = fma(fma(-g, g, hq), 0.5 * y, g);
+            if (!live) g = 0.;
+        }
+        if (f > 0) g = -g;
+        const double h = h0 - f * g;
+        const double rh = live ? dc_rcp(h) : 0.;
+        // every wavefront writes the SAME u, so it may read its own copy without a barrier
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int k = lane + 64 * m;
+            if (k < ir) uv[k] = (live && k < i) ? (k == i - 1 ? f - g : dk[m]) : 0.;
+        }
+        if (tid == 0) {
+            ev[i] = live ? g : f;
+            td[i] = tdi;
+            hvec[i] = live ? h : 0.;
+        }
+        // stash: row i of the global work matrix = the Householder vector of step i (issued here so
+        // that the store drains behind the product)
+        if (tid < i) Aglob[(size_t) i * lda + tid] = (live && tid < i) ? (tid == i - 1 ? f - g : dv[tid]) : 0.;
+        EIG_CLK(1);
+        // ---- p = A u -------------------------------------------------------------------------
+        {   // top rows j = rj0 < 128: L11 u_top (the L21^T u_bot part arrives through `part`),
+            // with the previous step's update of L11 applied on the way
+            double acc0 = 0., acc1 = 0.;
+            const double ujp = up[rj0], wjp = wp[rj0];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    double2 x = *reinterpret_cast<const double2*>(lrow + 32 * a + 2 * b);
+                    const double2 u2 = *reinterpret_cast<const double2*>(uq + 32 * a + 2 * b);
+                    const double2 p2 = *reinterpret_cast<const double2*>(upq + 32 * a + 2 * b);
+                    const double2 q2 = *reinterpret_cast<const double2*>(wpq + 32 * a + 2 * b);
+                    x.x = __builtin_fma(-p2.x, wjp, __builtin_fma(-q2.x, ujp, x.x));
+                    x.y = __builtin_fma(-p2.y, wjp, __builtin_fma(-q2.y, ujp, x.y));
+                    *reinterpret_cast<double2*>(lrow + 32 * a + 2 * b) = x;
+                    acc0 = __builtin_fma(x.x, u2.x, acc0);
+                    acc1 = __builtin_fma(x.y, u2.y, acc1);
+                }
+                EIG_SEQ();
+            }
+            double acc = acc0 + acc1;
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            if (rq == 0) gv[rj0] = acc;
+        }
+        EIG_CLK(2);
+        if (wact) {
+            // bottom rows: L22 u_bot (row sums of the full symmetric block)
+            double acc0 = 0., acc1 = 0.;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (a < GA2) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const double2 u2 = *reinterpret_cast<const double2*>(uq + 128 + 32 * a + 2 * b);
+                        acc0 = __builtin_fma(r22[a][b].x, u2.x, acc0);
+                        acc1 = __builtin_fma(r22[a][b].y, u2.y, acc1);
+                    }
+                }
+                EIG_SEQ();
+            }
+            double acc = acc0 + acc1;
+            acc += __shfl_xor(acc, 1, 4);
+            acc += __shfl_xor(acc, 2, 4);
+            if (rq == 0) gv[R22] = acc;
+            // L21: rows (L21 u_top -> gv2) and columns (L21^T u_bot -> part[wave])
+            double2 ut[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) ut[b] = *reinterpret_cast<const double2*>(uc + 2 * b);
+            const double2 ub0 = *reinterpret_cast<const double2*>(uP);
+            const double2 ub1 = *reinterpret_cast<const double2*>(uP + 2);
+            const double ub[4] = { ub0.x, ub0.y, ub1.x, ub1.y };
+            double rp[4];
+            double2 cp[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) cp[b] = make_double2(0., 0.);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double a0 = 0., a1 = 0.;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    a0 = __builtin_fma(p21[k][b].x, ut[b].x, a0);
+                    a1 = __builtin_fma(p21[k][b].y, ut[b].y, a1);
+                    cp[b].x = __builtin_fma(p21[k][b].x, ub[k], cp[b].x);
+                    cp[b].y = __builtin_fma(p21[k][b].y, ub[k], cp[b].y);
+                }
+                rp[k] = eig_row16_sum(a0 + a1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (cg == k) gv2[P0 + k] = rp[k];
+            // half-exchange over lane bit 4: keep columns 0..3 (bit clear) or 4..7 (bit set)
+            eig_swap_rows16(cp[0].x, cp[2].x);
+            eig_swap_rows16(cp[0].y, cp[2].y);
+            eig_swap_rows16(cp[1].x, cp[3].x);
+            eig_swap_rows16(cp[1].y, cp[3].y);
+            double2 s0 = make_double2(cp[0].x + cp[2].x, cp[0].y + cp[2].y);
+            double2 s1 = make_double2(cp[1].x + cp[3].x, cp[1].y + cp[3].y);
+            // ... and over lane bit 5: keep the first pair (bit clear) or the second (bit set)
+            eig_swap_half32(s0.x, s1.x);
+            eig_swap_half32(s0.y, s1.y);
+            *reinterpret_cast<double2*>(&part[wave * 128 + mycol]) =
+                    make_double2(s0.x + s1.x, s0.y + s1.y);
+        } else {
+            // retired (all rows of this wavefront are reflectors by now): its slab reads as zero
+            *reinterpret_cast<double2*>(&part[wave * 128 + 2 * lane]) = make_double2(0., 0.);
+        }
+        EIG_CLK(3);
+        EIG_LDS_BARRIER();
+        EIG_CLK(4);
+        // ---- w = p / h - (u^T p / 2 h^2) u, every wavefront for itself --------------------------
+        {
+            double ek[4], uk[4];
+            double fs = 0.;
+            // the column sums of L21^T u_bot: one slab per active wavefront, added in wave order
+            // (all eight slabs, unconditionally: one LDS round trip; a retired wavefront's slab is zero)
+            double pr[16];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                pr[2 * w] = part[w * 128 + lane];
+                pr[2 * w + 1] = part[w * 128 + 64 + lane];
+            }
+            double ps0 = 0., ps1 = 0.;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                ps0 += pr[2 * w];
+                ps1 += pr[2 * w + 1];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int k = lane + 64 * m;
+                const double g0 = gv[k], g2 = m >= 2 ? gv2[k] : (m == 0 ? ps0 : ps1);
+                const double u0 = uv[k];
+                const double gk = k < i ? g0 + g2 : 0.;
+                uk[m] = k < i ? u0 : 0.;
+                ek[m] = gk * rh;
+                fs = __builtin_fma(ek[m], uk[m], fs);
+            }
+            const double hh = eig_wave_sum(fs) * (0.5 * rh);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int k = lane + 64 * m;
+                const double wk = k < i ? ek[m] - hh * uk[m] : 0.;
+                if (k < ir) wv[k] = wk;
+                if (m < 2) {            // (every wavefront writes the same values)
+                    up[k] = uk[m];
+                    wp[k] = wk;
+                }
+            }
+        }
+        EIG_CLK(5);
+        // ---- A -= u w^T + w u^T ------------------------------------------------------------------
+        if (wact) {
+            const double uj = uv[R22], wj = wv[R22];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (a < GA2) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const double2 u2 = *reinterpret_cast<const double2*>(uq + 128 + 32 * a + 2 * b);
+                        const double2 w2 = *reinterpret_cast<const double2*>(wq + 128 + 32 * a + 2 * b);
+                        r22[a][b].x = __builtin_fma(-u2.x, wj, __builtin_fma(-w2.x, uj, r22[a][b].x));
+                        r22[a][b].y = __builtin_fma(-u2.y, wj, __builtin_fma(-w2.y, uj, r22[a][b].y));
+                    }
+                }
+                EIG_SEQ();
+            }
+            if (R22 == i - 1) {                // this row is the next d: its L22 part ...
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+                    if (128 + 32 * a < nr) {
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            *reinterpret_cast<double2*>(dq + 128 + 32 * a + 2 * b) = r22[a][b];
+                    }
+            }
+            double2 ut[4], wt[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                ut[b] = *reinterpret_cast<const double2*>(uc + 2 * b);
+                wt[b] = *reinterpret_cast<const double2*>(wc + 2 * b);
+            }
+            const double2 ub0 = *reinterpret_cast<const double2*>(uP);
+            const double2 ub1 = *reinterpret_cast<const double2*>(uP + 2);
+            const double2 wb0 = *reinterpret_cast<const double2*>(wP);
+            const double2 wb1 = *reinterpret_cast<const double2*>(wP + 2);
+            const double ub[4] = { ub0.x, ub0.y, ub1.x, ub1.y };
+            const double wb[4] = { wb0.x, wb0.y, wb1.x, wb1.y };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    p21[k][b].x = __builtin_fma(-ut[b].x, wb[k], __builtin_fma(-wt[b].x, ub[k], p21[k][b].x));
+                    p21[k][b].y = __builtin_fma(-ut[b].y, wb[k], __builtin_fma(-wt[b].y, ub[k], p21[k][b].y));
+                }
+            // ... and its L21 part (columns < 128); four static blocks: a run-time index into
+            // p21 would move the whole array to scratch memory
+            const int pk = i - 1 - P0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (pk == k) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) *reinterpret_cast<double2*>(dc + 2 * b) = p21[k][b];
+                }
+        }
+    }
+#ifdef BBO_EIG_STEP_CLOCKS
+    if (stamps && tid == 0)
+        for (int q = 0; q < 8; q++) stamps[40 + q] = (long long) clk[q];
+#endif
+    // the last step's update of L11, and row 127 as the d of the register-resident steps
+    EIG_LDS_BARRIER();
+    {
+        const double ujp = up[rj0], wjp = wp[rj0];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double2 x = *reinterpret_cast<const double2*>(lrow + 32 * a + 2 * b);
+                const double2 p2 = *reinterpret_cast<const double2*>(upq + 32 * a + 2 * b);
+                const double2 q2 = *reinterpret_cast<const double2*>(wpq + 32 * a + 2 * b);
+                x.x = __builtin_fma(-p2.x, wjp, __builtin_fma(-q2.x, ujp, x.x));
+                x.y = __builtin_fma(-p2.y, wjp, __builtin_fma(-q2.y, ujp, x.y));
+                *reinterpret_cast<double2*>(lrow + 32 * a + 2 * b) = x;
+                if (rj0 == 127) *reinterpret_cast<double2*>(dq + 32 * a + 2 * b) = x;
+            }
+            EIG_SEQ();
+        }
+    }
+#undef EIG_SEQ
+#undef EIG_LDS_BARRIER
+    __syncthreads();
+}
+
+// the rest of the reduction for 128 < n <= 256: the leading block in registers, then V for cma_eig_wy
+__device__ inline void eig_tred_sym256(const double *C, int ld, int n, const EigMat &A,
+        double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
+        int nv, int tid, long long *stamps, const EigMat &As, bool accumulate)
+{
+    constexpr int T = EIG_THREADS, LB = 130;
+    const int nr = (n + 31) & ~31;
+    eig_tred_sym256_steps(C, ld, n, A.a, A.ld, nv, stamps);
+    if (stamps && tid == 0) stamps[2] = wall_clock64();
+    // the leading 128 x 128 block: reduce in registers (its reflectors stay in the LDS stash)
+    eig_tred_accum_reg128(As.a, LB, 128, As, dv, ev, uv, wv, gv, hvec, td, tid, nullptr,
+            A.a, A.ld, false, accumulate);
+    for (int k = tid; k < nr; k += T) {
+        uv[k] = 0.;
+        wv[k] = 0.;
+    }
+    __syncthreads();
+    // leave A = V for cma_eig_wy: row i = u_i in columns < i, zero from column i on; the first
+    // 128 rows come from the LDS stash, the others were stashed in place
+    const int lda = A.ld;
+    for (int q = tid; q < n * (nr >> 1); q += T) {
+        const int r = q / (nr >> 1), c2 = (q - r * (nr >> 1)) * 2;
+        double2 *cell = reinterpret_cast<double2*>(&A.a[(size_t) r * lda + c2]);
+        double2 v = make_double2(0., 0.);
+        if (r < 128) {
+            if (c2 < r) v.x = As(r, c2);
+            if (c2 + 1 < r) v.y = As(r, c2 + 1);
+        } else if (c2 < r) {
+            v = *cell;
+            if (c2 + 1 >= r) v.y = 0.;
+        }
+        *cell = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += T) dv[k] = td[k];
+    __syncthreads();
+}
+
 template<int TT>
 __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
         int force)
@@ -632,7 +1084,8 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
     double *td = hvec + nv;       // diagonal of the tridiagonal matrix
     double *uh0 = td + nv, *uh1 = uh0 + nv;
     double *part = uh1 + nv - 2;  // [4][nv] column partial sums (generic path only)
-    double2 *rot = reinterpret_cast<double2*>(part + (pl.reg_path ? 0 : 4 * nv));   // [2][rc]
+    double2 *rot = reinterpret_cast<double2*>(part
+            + eig_part_doubles(nv, pl.reg_path != 0, pl.dc && !pl.reg_path));   // [2][rc]
     int *ibuf = reinterpret_cast<int*>(rot + 2 * pl.rc);        // desc[2][MAXSEQ*3], nseq[2], done[2], misc
     int *desc = ibuf;
     int *nseq = ibuf + 2 * EIG_MAXSEQ * 3;
@@ -658,6 +1111,11 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
         // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
+        // (diagnostic bit 1024: round 2's form of the first n - 128 steps, streaming from L2)
+        if (hybrid && !(d.dbg & 2) && !(d.dbg & 1024))
+            eig_tred_sym256(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, nv, tid,
+                    (d.stamps && p == 0) ? d.stamps : nullptr, Ast, false);
+        else
         eig_tred_accum_global(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, part, nv, tid,
                 (d.stamps && p == 0) ? d.stamps : nullptr, hybrid ? &Ast : nullptr,
                 !(hybrid && !(d.dbg & 2)));

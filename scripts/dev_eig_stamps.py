@@ -27,8 +27,8 @@ for rep in range(3):
              21: "merge top", 22: "merges done", 23: "reflectors/B done", 24: "mg start",
              25: "mg deflate", 26: "mg 26", 27: "mg secular", 28: "mg 28", 29: "mg 29",
              30: "mg end"}
-    t0 = min(v for v in st if v > 0)
-    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
+    t0 = min(v for v in st[:32] if v > 0)
+    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i < 32 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
     print("rep %d" % rep)
     prev = t0
     for v, i in rows:
@@ -36,3 +36,6 @@ for rep in range(3):
                                                     (v - t0) / 100.))
         prev = v
     print("   secular iterations (top merge): %d; leaf sweeps: %s" % (st[31], st[12:16]))
+    if len(st) >= 48 and any(st[40:48]):
+        print("   step clocks (cycles, BBO_EIG_STEP_CLOCKS build): barrier1 %d, chain+u %d, L11 product %d, "
+              "L22/L21 product %d, barrier2 %d, w %d, rank-2 %d, loop end %d" % tuple(st[40:48]))

@@ -270,7 +270,8 @@ def _spd_cases(n, rng):
     yield "repeated", Q @ np.diag(np.where(np.arange(n) % 2 == 0, 1., 3.)) @ Q.T
 
 
-@pytest.mark.parametrize("n", [10, 16, 17, 37, 64, 100, 128, 129, 160, 200, 256, 300])
+@pytest.mark.parametrize("n", [10, 16, 17, 37, 64, 100, 128, 129, 144, 145, 160, 200, 224, 225, 255, 256,
+                               300])
 def test_eigendecomposition_special_matrices(hip, n):
     """the eigensolver alone (QL for n <= 16, Householder + divide and conquer above) on
     matrices that stress deflation, clustering and scaling; checked against numpy.eigh"""
