@@ -100,7 +100,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     c.bound = params_.bound ? 1 : 0;
     // (16 < ld <= 128: the samplers there always hand down ||z||^2, so without a box nothing in
     // a generation reads C^-1/2 but cma_paths, which can work from B and D)
-    c.lazy_isc = (!sep && !c.bound && c.ld > 16 && c.ld <= 128) ? 1 : 0;
+    c.lazy_isc = (!sep && !c.bound && c.ld > 16 && c.ld <= 256) ? 1 : 0;
     c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
     c.mfev = params_.mfev;
     c.mit = params_.mfev / lambda;
@@ -398,6 +398,7 @@ void CmaEngine::launch_sample_eval()
         case 4: hipLaunchKernelGGL(cma_sample_eval<4>, grid, dim3(256), lds, stream_, d_, c_); break;
         default: hipLaunchKernelGGL(cma_sample_eval<8>, grid, dim3(256), lds, stream_, d_, c_); break;
         }
+        zn_valid = true;
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());

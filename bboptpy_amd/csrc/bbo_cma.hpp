@@ -34,7 +34,7 @@ struct CmaConst {
     int variant;              // 0 plain (cmaes.cpp), 1 active (active_cmaes.cpp), 2 separable (sep_cmaes.cpp)
     int bound, obj;
     int use_zn;               // this generation's zn2 is valid and x was not clamped
-    int lazy_isc;             // C^-1/2 is not formed after a decomposition (16 < ld <= 128, no box): cma_paths
+    int lazy_isc;             // C^-1/2 is not formed after a decomposition (16 < ld <= 256, no box): cma_paths
                               // works from B and D, the whitening takes ||z||^2, readers get it on demand
     int mfev, mit, hlen, ik;
     int honor_stop;           // 1 inside run()/optimize(): stopped populations are frozen

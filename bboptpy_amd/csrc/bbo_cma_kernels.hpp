@@ -171,8 +171,10 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     const int NT = ld >> 4, KS = ld >> 2;
     const double *bdp = d.BDp + (size_t) p * ld * ld;
     const int ar = lane & 15, ak = lane >> 4;
+    double zz = 0.;
     for (int ks = 0; ks < KS; ks++) {
         const double a = lds[ar * ldz + 4 * ks + ak];
+        zz = __builtin_fma(a, a, zz);
 #pragma unroll
         for (int t = 0; t < MAXT; t++) {
             const int nt = wave + 4 * t;
@@ -182,6 +184,11 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
             }
         }
     }
+    // ||z||^2 of the 16 rows of this tile (by-product for the whitened-norm shortcut, as in
+    // sample_eval64_body: same sums in the same order)
+    zz += __shfl_xor(zz, 16, 64);
+    zz += __shfl_xor(zz, 32, 64);
+    if (wave == 0 && ak == 0) d.zn2[(size_t) p * c.lambda_pad + mt * 16 + ar] = zz;
     __syncthreads();
 
     // 3. x = m + sigma * y (clipped to the box when bound), to HBM and to LDS
@@ -1315,13 +1322,13 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
     if (LAZY && sc->basis_ok) {
         // C^-1/2 dm = B (D^-1 (B^T dm)) from the basis itself: 2 n^2 operations instead of the
         // n^3 of forming C^-1/2 after every decomposition (cma_post then only packs B D)
-        __shared__ double sv[128], cv[128], part[128];
+        __shared__ double sv[256], cv[256], part[128];
         const double *B = d.B + (size_t) p * ld * ld, *D = d.D + (size_t) p * ld;
         // (both products with the loads of a thread independent of each other: the matrix comes
         // from L2 / HBM once, latency is what there is to hide)
-        {
+        for (int jb = 0; jb < c.n; jb += 128) {     // (one pass for n <= 128, two up to 256)
             // t = B^T dm: column j by threads j and j + 128 (even / odd rows), 8 rows in flight
-            const int j = tid & 127, h = tid >> 7;
+            const int j = jb + (tid & 127), h = tid >> 7;
             double t0 = 0., t1 = 0., t2 = 0., t3 = 0.;
             if (j < c.n) {
                 int i = h;
@@ -1337,25 +1344,30 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
                 for (; i < c.n; i += 2) t0 += B[(size_t) i * ld + j] * dm[i];
             }
             const double t = (t0 + t1) + (t2 + t3);
-            if (h == 1) part[j] = t;
+            if (h == 1) part[tid & 127] = t;
             __syncthreads();
-            if (h == 0) sv[j] = j < c.n ? (t + part[j]) / D[j] : 0.;
+            if (h == 0) sv[j] = j < c.n ? (t + part[tid & 127]) / D[j] : 0.;
+            __syncthreads();
         }
-        __syncthreads();
-        {
+        for (int ib = 0; ib < c.n; ib += 128) {
             // cv = B sv: rows r, r + 16, ... by the 16 lanes of a DPP row (128-byte segments)
-            const int g = tid & 15, r = tid >> 4;
+            const int g = tid & 15, r = ib + (tid >> 4);
             double a[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = r + 16 * u;
-                double x[8];
+                double tot = 0.;
+                for (int kb = 0; kb < c.n; kb += 128) {
+                    double x[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int j = g + 16 * k;
-                    x[k] = (i < c.n && j < c.n) ? B[(size_t) i * ld + j] * sv[j] : 0.;
+                    for (int k = 0; k < 8; k++) {
+                        const int j = kb + g + 16 * k;
+                        x[k] = (i < c.n && j < c.n) ? B[(size_t) i * ld + j] * sv[j] : 0.;
+                    }
+                    const double part8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                    tot = kb == 0 ? part8 : tot + part8;
                 }
-                a[u] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                a[u] = tot;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -1468,6 +1480,11 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
     // mode 0: after cma_eigen, only if it decomposed; 1: always; 2: pack only (C^-1/2 is
     // taken as stored -- Cmaes::init sets it to I whatever B holds, cmaes.cpp:55-59)
     if (mode == 0 && !sc->eigen_done) return;
+    // mode 3: C^-1/2 on demand (bbo_get "invsqrtC" under lazy_isc) -- only from a consistent basis
+    if (mode == 3 && !sc->basis_ok) return;
+    // lazy_isc (no box, ld <= 256): C^-1/2 is not formed after a decomposition -- cma_paths works
+    // from B and D, the whitened norms come from the sampler -- this launch only packs B D
+    const bool gemm = mode == 3 || (mode != 2 && !c.lazy_isc);
     const int ld = c.ld, n = c.n;
     const int tid = threadIdx.x;
     const int i = blockIdx.y * 16 + (tid >> 4), j = blockIdx.x * 16 + (tid & 15);
@@ -1475,6 +1492,7 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
     const double *D = d.D + (size_t) p * ld;
     __shared__ double Bi[16][17], Bj[16][17], Dinv[16];
     double sum = 0.;
+    if (gemm)
     for (int k0 = 0; k0 < ld; k0 += 16) {
         const int r = tid >> 4, k = k0 + (tid & 15);
         const int ri = blockIdx.y * 16 + r, rj = blockIdx.x * 16 + r;
@@ -1487,14 +1505,16 @@ __global__ __launch_bounds__(256) void cma_post(CmaDev d, CmaConst c, int mode)
         __syncthreads();
     }
     const bool in = i < n && j < n;
-    double v = in ? sum : 0.;
-    if (mode == 2) v = in ? d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] : 0.;
-    else d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] = v;
-    if (mode != 2 && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) d.scal[p].basis_ok = 1;
     // packed B-operand element (row i -> column tile/lane, col j -> k index)
     const int KS = ld >> 2;
     const size_t pk = ((size_t) (i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15);
-    d.ISp[(size_t) p * ld * ld + pk] = v;
+    if (gemm || mode == 2) {
+        double v = in ? sum : 0.;
+        if (mode == 2) v = in ? d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] : 0.;
+        else d.isc[(size_t) p * ld * ld + (size_t) i * ld + j] = v;
+        d.ISp[(size_t) p * ld * ld + pk] = v;
+    }
+    if (mode != 2 && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) d.scal[p].basis_ok = 1;
     d.BDp[(size_t) p * ld * ld + pk] = in ? B[(size_t) i * ld + j] * D[j] : 0.;
 }
 
