@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {
-        QlState st { 0, 0, 1, 0, 0., 0. };
+        QlState st { 0, 0, 1, 0, 0., 0., 0 };
         int prev_done = 0;
         for (int epoch = 0;; epoch++) {
             const int cur = epoch & 1;
@@ -1183,11 +1183,11 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         for (int j = tid; j < n; j += T) gv[j] = dv[j];   // already ascending
     } else {
     for (int j = tid; j < n; j += T) {
-        const double dj = dv[j];
+        const double dj = dv[j], kj = dc_key(dj);
         int r = 0;
         for (int k = 0; k < n; k++) {
-            const double dk = dv[k];
-            r += (dk < dj) || (dk == dj && k < j);
+            const double dk = dc_key(dv[k]);      // (NaN ranks as +inf: perm stays a permutation)
+            r += (dk < kj) || (dk == kj && k < j);
         }
         perm[j] = r;
         gv[r] = dj;   // sorted eigenvalues
@@ -1522,11 +1522,11 @@ __device__ __forceinline__ void eigen_small_body(const CmaDev &d, const CmaConst
     }
     // ---- ascending order (cmaes.cpp:459-477), repair (:250-266), sqrt (:269-271) ----------------
     if (lane < n) {
-        const double dj = dv[lane];
+        const double dj = dv[lane], kj = dc_key(dj);
         int r = 0;
         for (int k = 0; k < n; k++) {
-            const double dk = dv[k];
-            r += (dk < dj) || (dk == dj && k < lane);
+            const double dk = dc_key(dv[k]);
+            r += (dk < kj) || (dk == kj && k < lane);
         }
         perm[lane] = r;
         gv[r] = dj;

@@ -56,6 +56,13 @@ __device__ inline double dc_rcp(double x)
     return r;
 }
 
+// Key of a ranking by counting.  The maps built from such rankings (sorted position -> source
+// column, root -> output column) are used as INDICES: a ranking must be a permutation whatever
+// the data.  With a NaN every comparison is false, all NaN entries would get the same rank and
+// some positions none (the index read back from them is then arbitrary -- a covariance with a
+// NaN entry made the eigensolver fault).  NaN ranks as +infinity; equal keys rank by position.
+__device__ inline double dc_key(double v) { return v == v ? v : __builtin_huge_val(); }
+
 // the team of wavefronts that works on one merge
 struct DcTeam {
     int active;       // has a merge at this level
@@ -160,9 +167,10 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     __syncthreads();
     if (ttid < m) {
         int r = 0;
+        const double ki = dc_key(di);
         for (int j = 0; j < m; j++) {
-            const double dj = W.lam[j];
-            r += (dj < di) || (dj == di && j < ttid);
+            const double dj = dc_key(W.lam[j]);
+            r += (dj < ki) || (dj == ki && j < ttid);
         }
         W.dS[r] = di;
         W.zS[r] = zi;
@@ -272,9 +280,10 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         const int pos = W.kp[ttid];
         const double dk = W.dS[pos];
         int r = 0;
+        const double kk = dc_key(dk);
         for (int j = 0; j < k; j++) {
-            const double dj = W.dS[W.kp[j]];
-            r += (dj < dk) || (dj == dk && j < ttid);
+            const double dj = dc_key(W.dS[W.kp[j]]);
+            r += (dj < kk) || (dj == kk && j < ttid);
         }
         const double z = W.zS[pos];
         W.dl[r] = dk;
@@ -459,10 +468,10 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     if (ttid < nd) W.lam[k + ttid] = W.dS[W.dp[ttid]];
     __syncthreads();
     if (ttid < m) {
-        const double v = W.lam[ttid];
+        const double v = dc_key(W.lam[ttid]);
         int r = 0;
         for (int j = 0; j < m; j++) {
-            const double u = W.lam[j];
+            const double u = dc_key(W.lam[j]);
             r += (u < v) || (u == v && j < ttid);
         }
         W.outpos[ttid] = r;
@@ -595,7 +604,7 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     }
     dc_wave_sync();
     EigMat blk { &Q(a, a), Q.ld };
-    QlState st { 0, 0, 1, 0, 0., 0. };
+    QlState st { 0, 0, 1, 0, 0., 0., 0 };
     // QL has no iteration limit in the reference; ql_produce_reg<true> stops after 30 sweeps per
     // eigenvalue (a uniform counter), which only bounds a run on non-finite / subnormal input
     // (a lane touches only its own row of the block: the rotations need no fence among lanes)
@@ -942,11 +951,11 @@ __device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *e
     const bool single = nblk == 1;
     if (single) {
         if (tid < n) {
-            const double v = dv[tid];
+            const double v = dv[tid], kv = dc_key(v);
             int r = 0;
             for (int j = 0; j < n; j++) {
-                const double u = dv[j];
-                r += (u < v) || (u == v && j < tid);
+                const double u = dc_key(dv[j]);
+                r += (u < kv) || (u == kv && j < tid);
             }
             W.outpos[tid] = r;
             W.lam[tid] = v;

@@ -80,6 +80,7 @@ __device__ inline double ql_hypot1(double p)       // sqrt(p^2 + 1)
 struct QlState {
     int l, m, need_m, done;
     double f, tst1;
+    int total;            // sweeps so far, over all calls (bounded: see ql_produce)
 };
 
 // Producer: advances the QL recurrence on (dv, ev), recording up to `rc` Givens pairs of
@@ -126,6 +127,12 @@ __device__ inline int ql_produce(QlState &st, int n, double *dv, double *ev, dou
         }
         const int l = st.l, m = st.m, len = m - l;
         if (count + len > rc || ns >= EIG_MAXSEQ) break;
+        // (the reference's tql2 has no sweep limit; here a matrix that never converges must not
+        // hang the GPU: 30 sweeps per eigenvalue, far beyond anything finite input needs)
+        if (++st.total > 30 * n) {
+            st.done = 1;
+            break;
+        }
         const double thr = eps * st.tst1;
 
         // implicit shift (cmaes.cpp:405-417)

@@ -57,6 +57,8 @@ WORKLOADS = {
     "C2": dict(algo="SHADE", n=128, np=4096, objective="rastrigin", box=(-5.12, 5.12), P=256),
     "JADE": dict(algo="JADE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "SEP": dict(algo="SepCMAES", n=1024, np=4096, objective="ellipsoid", box=(-5., 5.), P=64),
+    # the building block of C5 (what one restart population runs): profiling only
+    "C5I": dict(algo="ActiveCMAES", n=256, np=20, objective="rastrigin", box=(-5.12, 5.12), P=1),
     "SANSDE": dict(algo="SANSDE", n=128, np=4096, objective="rosenbrock", box=(-10., 10.), P=256),
     "CSO": dict(algo="CSO", n=512, np=65536, objective="sphere", box=(-10., 10.), P=4),
     "CCPSO": dict(algo="CCPSO", n=1000, np=30, objective="rosenbrock", box=(-10., 10.), P=16,
@@ -66,7 +68,7 @@ WORKLOADS = {
 }
 
 CMA_KERNELS = ["cma_sample_eval", "cma_rank", "cma_whiten", "cma_gram", "cma_paths", "cma_cov",
-               "cma_eigen", "cma_post", "cma_history_stop"]
+               "cma_eigen", "cma_post", "cma_history_stop", "cma_draw"]
 DE_KERNELS = ["de_generation", "de_bookkeep", "de_archive_copy", "de_rank", "de_finish",
               "de_select"]
 PSO_KERNELS = ["pso_center", "pso_ese", "pso_control", "pso_update", "pso_finish"]
@@ -117,19 +119,24 @@ def cma_kernel_costs(n, lam, P):
     """algorithmic work of ONE launch (all P populations), SURVEY.md section 8d:
     flops for the MFMA-bound kernels, bytes for the bandwidth-bound ones"""
     mu = lam // 2
-    # n <= 128, unbounded: the sampler hands down ||z||^2 and the whitening GEMM (mu 2n^2
+    # n <= 256, unbounded: the sampler hands down ||z||^2 and the whitening GEMM (mu 2n^2
     # flops) is not executed at all -- the kernel gathers mu norms through the ranking
     # (DESIGN.md "whitened norms"); beyond that it is the GEMM
-    whiten = ("hbm", P * mu * 12) if n <= 128 else ("mfma", P * mu * 2 * n * n)
+    whiten = ("hbm", P * mu * 12) if n <= 256 else ("mfma", P * mu * 2 * n * n)
     return {
+        # (the lean n = 128 sampler: the next generation's normals are drawn by a kernel of their
+        # own on a second stream, beside rank / paths / cov / eigen / stop -- it OVERLAPS them, so
+        # the shares of a profiled pass add up to more than the step.  Priced in the bytes it
+        # writes; what bounds it is the vector pipe: ~170 instructions per Philox call)
+        "cma_draw": ("hbm", P * lam * n * 8),
         "cma_sample_eval": ("mfma", P * lam * (2 * n * n + 8 * n)),
         "cma_whiten": whiten,
         "cma_gram": ("mfma", P * lam * n * (n + 1)),      # lower triangle only, like the reference
         "cma_eigen": ("mfma", P * 9 * n ** 3),
-        # 16 < n <= 128 without a box (every benchmark shape but C1): C^-1/2 is not formed per
-        # generation and the eigensolver packs B D itself -- cma_post is not launched, the timer
-        # brackets nothing (DESIGN.md section 4, "C^-1/2 on demand")
-        "cma_post": ("mfma", None if 16 < n <= 128 else P * 2 * n ** 3),
+        # 16 < n <= 256 without a box (every benchmark shape but C1): C^-1/2 is not formed per
+        # generation; n <= 128: the eigensolver packs B D itself, cma_post is not launched and
+        # the timer brackets nothing; above, cma_post only packs (DESIGN.md section 4)
+        "cma_post": ("mfma", None if 16 < n <= 256 else P * 2 * n ** 3),
         "cma_rank": ("hbm", P * lam * 16),
         "cma_paths": ("hbm", P * 8 * (n * n + 8 * n)),
         "cma_cov": ("hbm", P * 8 * 2 * (n * (n + 1) // 2)),
