@@ -1942,30 +1942,70 @@ __device__ inline void small_phase_sync()
 // (the scratch is named inside each function, not passed in: through a pointer argument the
 // compiler loses the address space and turns every ds_read into a flat load -- the serial QL chain
 // of the eigensolver ran 1.5x slower that way)
+// The view's pointers are LDS addresses, but typed generic: as they stand every access through
+// them is a FLAT load or store (and every wait a vmcnt(0) & lgkmcnt(0)).  Each phase therefore
+// takes its own copy of the view and tells the compiler where the pointers point
+// (llvm.assume(is.shared): InferAddressSpaces then rewrites their uses to ds_read / ds_write).
+__device__ __forceinline__ CmaDev small_lds_view(const CmaDev &v)
+{
+    CmaDev w = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BBO_LDS(ptr) __builtin_assume(__builtin_amdgcn_is_shared((const void*) (w.ptr)))
+#else
+#define BBO_LDS(ptr) (void) 0      /* (the host pass only parses this function) */
+#endif
+    BBO_LDS(X); BBO_LDS(f); BBO_LDS(zn2); BBO_LDS(rank); BBO_LDS(order); BBO_LDS(xmean);
+    BBO_LDS(xold); BBO_LDS(pc); BBO_LDS(ps); BBO_LDS(D); BBO_LDS(C); BBO_LDS(B); BBO_LDS(isc);
+    BBO_LDS(BDp); BBO_LDS(ISp); BBO_LDS(S); BBO_LDS(gram_part); BBO_LDS(mean_part);
+    BBO_LDS(hist_best); BBO_LDS(hist_kth); BBO_LDS(weights); BBO_LDS(lower); BBO_LDS(upper);
+    BBO_LDS(aux); BBO_LDS(scal);
+#undef BBO_LDS
+    return w;
+}
 SMALL_NOINLINE void small_sample(const CmaDev &v, const CmaConst &c, int bx, int psub, bool first)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    sample_eval64_body<1, 8>(v, c, 0, bx, lds, psub, first);
+    const CmaDev w = small_lds_view(v);
+    sample_eval64_body<1, 8>(w, c, 0, bx, lds, psub, first);
 }
-SMALL_NOINLINE void small_rank(const CmaDev &v, const CmaConst &c, int lane) { rank_wave_body(v, c, 0, lane); }
+SMALL_NOINLINE void small_rank(const CmaDev &v, const CmaConst &c, int lane)
+{
+    const CmaDev w = small_lds_view(v);
+    rank_wave_body(w, c, 0, lane);
+}
 SMALL_NOINLINE void small_whiten(const CmaDev &v, const CmaConst &c, int mt)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    whiten_body<1>(v, c, 0, mt, lds);
+    const CmaDev w = small_lds_view(v);
+    whiten_body<1>(w, c, 0, mt, lds);
 }
 SMALL_NOINLINE void small_gram(const CmaDev &v, const CmaConst &c, int s, int ldy)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    gram_body(v, c, 0, s, 0, ldy, lds);
+    const CmaDev w = small_lds_view(v);
+    gram_body(w, c, 0, s, 0, ldy, lds);
 }
-SMALL_NOINLINE void small_paths(const CmaDev &v, const CmaConst &c) { paths_body(v, c, 0); }
-SMALL_NOINLINE void small_cov(const CmaDev &v, const CmaConst &c) { cov_body(v, c, 0, 0); }
+SMALL_NOINLINE void small_paths(const CmaDev &v, const CmaConst &c)
+{
+    const CmaDev w = small_lds_view(v);
+    paths_body(w, c, 0);
+}
+SMALL_NOINLINE void small_cov(const CmaDev &v, const CmaConst &c)
+{
+    const CmaDev w = small_lds_view(v);
+    cov_body(w, c, 0, 0);
+}
 SMALL_NOINLINE void small_eigen(const CmaDev &v, const CmaConst &c, int lane)
 {
     __shared__ __attribute__((aligned(16))) double eig_lds[EIGS_DOUBLES];
-    eigen_small_body(v, c, 0, lane, eig_lds, 0, 1);
+    const CmaDev w = small_lds_view(v);
+    eigen_small_body(w, c, 0, lane, eig_lds, 0, 1);
 }
-SMALL_NOINLINE void small_stop(const CmaDev &v, const CmaConst &c, int lane) { history_stop_body(v, c, 0, lane); }
+SMALL_NOINLINE void small_stop(const CmaDev &v, const CmaConst &c, int lane)
+{
+    const CmaDev w = small_lds_view(v);
+    history_stop_body(w, c, 0, lane);
+}
 #undef SMALL_NOINLINE
 
 __device__ inline void small_copy(double *dst, const double *src, int count, int tid)

@@ -672,10 +672,10 @@ __device__ inline double eig_row16_sum(double v)      // all 16 lanes of a DPP r
     return v;
 }
 
-// A REAL function (noinline): inlined into cma_eigen_body, whose register allocation already runs
+// A REAL function (noinline): inlined into cma_eigen_impl, whose register allocation already runs
 // at 256 VGPRs with ~490 spilled SGPRs, the 128 matrix registers of this loop were spilled and
 // reloaded EVERY step (1.69 ms for the 128 steps of n = 256, no better than streaming from L2).
-// It names the LDS vectors itself (same layout as cma_eigen_body, from nv): through pointer
+// It names the LDS vectors itself (same layout as cma_eigen_impl, from nv): through pointer
 // arguments the compiler would lose the address space and emit flat loads.
 #ifdef BBO_EIG_STEP_CLOCKS
 #define EIG_CLK(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -1060,8 +1060,13 @@ __device__ inline void eig_tred_sym256(const double *C, int ld, int n, const Eig
     __syncthreads();
 }
 
-template<int TT>
-__device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
+// LDSM: the work matrix A (reflector stash, then the eigenvector blocks of the divide and conquer)
+// lives in LDS (pl.use_lds) -- a COMPILE-TIME fact here.  As the run-time choice
+// `pl.use_lds ? LDS : global` the pointer is generic and every access to A -- each rotation of a QL
+// leaf, the fragment reads of the merge products -- became a FLAT load or store, waited for with
+// vmcnt(0) & lgkmcnt(0) in the middle of the recurrences (round 3: read in the ISA).
+template<int TT, bool LDSM>
+__device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
         int force)
 {
     const int p = blockIdx.x;
@@ -1091,8 +1096,8 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
     int *nseq = ibuf + 2 * EIG_MAXSEQ * 3;
     int *sdone = nseq + 2;
     int *perm = reinterpret_cast<int*>(uv);                     // reused after QL
-    EigMat A { pl.use_lds ? reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8)
-                          : d.eig_work + (size_t) p * 4 * eig_slab(ld), pl.lda };
+    EigMat A { LDSM ? reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8)
+                    : d.eig_work + (size_t) p * 4 * eig_slab(ld), pl.lda };
     double *C = d.C + (size_t) p * ld * ld;
 
 #define EIG_STAMP(slot) do { if (d.stamps && p == 0 && tid == 0) d.stamps[slot] = wall_clock64(); } while (0)
@@ -1101,13 +1106,13 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         dv[-1 - tid] = 0.;
         ev[-1 - tid] = 0.;
     }
-    if (pl.reg_path) {
+    if (LDSM) {      // (use_lds implies the register-resident reduction: n <= 128)
         // (with the D&C stage the reflectors stay stashed in A: eig_dc_phase applies them to the
         // tridiagonal eigenvectors in blocked form on the matrix cores)
         eig_tred_accum_reg128<TT>(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, tid,
                 (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true,
                 !(pl.dc && !(d.dbg & 2)));
-    } else if (TT == EIG_THREADS) {
+    } else if (TT == EIG_THREADS && !LDSM) {
         const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
         // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
@@ -1136,7 +1141,7 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
         eig_dc_phase<TT>(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg, pl.reg_path ? 0 : 1, hvec);
+                d.dbg, LDSM ? 0 : 1, hvec);
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {
@@ -1224,7 +1229,7 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
         sc->eigenlastev = sc->fev;
         sc->eigen_done = 1;
     }
-    if (use_dc && pl.reg_path && c.lazy_isc) {
+    if (use_dc && LDSM && c.lazy_isc) {
         // the sampler's packed operand B D straight from the LDS copy of B (what cma_post would
         // re-read B for; C^-1/2 is not formed in this configuration, see CmaConst::lazy_isc):
         // element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
@@ -1249,15 +1254,16 @@ __device__ __forceinline__ void cma_eigen_body(const CmaDev &d, const CmaConst &
 // matrices share a CU (the 512-thread form owns a CU's whole register file).
 __global__ __launch_bounds__(512) void cma_eigen(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
-    cma_eigen_body<512>(d, c, pl, force);
+    if (pl.use_lds) cma_eigen_impl<512, true>(d, c, pl, force);
+    else cma_eigen_impl<512, false>(d, c, pl, force);
 }
 __global__ __launch_bounds__(256, 2) void cma_eigen_256(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
-    cma_eigen_body<256>(d, c, pl, force);       // n <= 64
+    cma_eigen_impl<256, true>(d, c, pl, force);       // n <= 64: the matrix always fits LDS
 }
 __global__ __launch_bounds__(128, 2) void cma_eigen_128(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
-    cma_eigen_body<128>(d, c, pl, force);       // n <= 32
+    cma_eigen_impl<128, true>(d, c, pl, force);       // n <= 32
 }
 
 // ---------------------------------------------------------------------------

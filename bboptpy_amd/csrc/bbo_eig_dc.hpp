@@ -798,8 +798,11 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 // ext_top != 0 (n > 128, Q in global memory): stop after the scalar part of the top merge; on
 // exit Q = blockdiag(Q_1, Q_2), F (= G + n*n, n x n) = the top merge's eigenvector factor with
 // columns in ascending eigenvalue order, and the caller forms B = Q_house (Q F).
+// (forceinline: called once with Q in LDS and once with Q in global memory from cma_eigen -- as a
+// shared out-of-line function it would see generic pointers and address everything with FLAT
+// instructions)
 template<int TT = 512>
-__device__ inline void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
+__device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
         const double *hv = nullptr)
 {
