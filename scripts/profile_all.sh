@@ -4,7 +4,7 @@
 # usage: scripts/profile_all.sh <tag>
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for spec in "M 256 pmc" "C3 256 pmc" "C2 256 pmc" "C1 4096 nopmc" "C4 1 nopmc" "SEP 64 pmc" "CSO 4 nopmc" "CCPSO 16 nopmc"; do
+for spec in "M 256 pmc" "C3 256 pmc" "C2 256 pmc" "C1 4096 nopmc" "C4 1 nopmc" "C5I 1 nopmc" "SEP 64 pmc" "CSO 4 nopmc" "CCPSO 16 nopmc"; do
   set -- $spec
   WL=$1; P=$2; PMC=$3
   OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
