@@ -53,10 +53,16 @@ def test_bench_runs_under_a_world_size_1_nccl_group(hip):
     port = s.getsockname()[1]
     s.close()
     env = dict(_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT=str(port))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C3",
-                          "--populations", "8", "--steps", "5", "--warmup", "2",
-                          "--no-cpu-baseline", "--no-single", "--no-convergence"],
+    # the DEFAULT workload (what the driver launches), small: the bounded C5 leg then runs too --
+    # ConcurrentBiPop under the nccl group, its all_gather on device tensors, max_over_ranks
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--populations", "8",
+                          "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-single",
+                          "--no-convergence"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["roofline"] is not None
+    leg = rec["bipop_scaling"]
+    assert leg["n_gpus"] == 1 and leg["rounds"] >= 3
+    assert leg["large_restarts"] >= 1 and leg["small_restarts"] >= 1
+    assert leg["packed_8_per_gpu"]["restarts"] >= 8
