@@ -267,6 +267,11 @@ void CcpsoEngine::phase(int which)
     if (which == 0) launch_regroup_eval();
     else if (which == 1) launch_rest();
     else throw Error(BBO_ERR_ARG, "unknown CCPSO phase");
+    // Phase 0 with the objective on the device returns without waiting: what follows it --
+    // bbo_ccpso_export_tables, bbo_get -- is ordered behind it on the engine's stream and
+    // synchronises itself (one host wait per exchange instead of two).  Phase 1 ends a generation
+    // and waits, like bbo_iterate.
+    if (which == 0 && obj_.on_device() && !timer_.on()) return;
     BBO_HIP(hipStreamSynchronize(stream_));
     timer_.collect();
 }
@@ -315,6 +320,7 @@ void CcpsoEngine::merge_tables(const double *gathered, int world, bool device_me
     const double *src = gathered;
     if (!device_memory) {
         const size_t cnt = (size_t) world * 2 * stride;
+        BBO_HIP(hipStreamSynchronize(stream_));  // (the upload is not stream-ordered)
         if (gather_.count != cnt) gather_.alloc(cnt);
         gather_.upload(gathered, cnt);
         src = gather_.p;
@@ -491,6 +497,7 @@ int CcpsoEngine::set(const std::string &k, int p, const double *in, int count)
     // what a host-side local search (ccpso.cpp:371-435; the Python class drives it) hands back:
     // the re-weighted context vector, its value, the evaluations it spent, the `improved` flag
     BBO_HIP(hipSetDevice(params_.device));
+    BBO_HIP(hipStreamSynchronize(stream_));      // (uploads below are not stream-ordered)
     BBO_HIP(hipStreamSynchronize(stream_));
     if (k == "yhat") {
         BBO_REQUIRE(count == c_.n, "set yhat: wrong element count");
