@@ -1025,7 +1025,7 @@ __device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C,
 // the rest of the reduction for 128 < n <= 256: the leading block in registers, then V for cma_eig_wy
 __device__ inline void eig_tred_sym256(const double *C, int ld, int n, const EigMat &A,
         double *dv, double *ev, double *uv, double *wv, double *gv, double *hvec, double *td,
-        int nv, int tid, long long *stamps, const EigMat &As, bool accumulate)
+        int nv, int tid, long long *stamps, const EigMat &As, bool accumulate, double *Vout)
 {
     constexpr int T = EIG_THREADS, LB = 130;
     const int nr = (n + 31) & ~31;
@@ -1039,21 +1039,15 @@ __device__ inline void eig_tred_sym256(const double *C, int ld, int n, const Eig
         wv[k] = 0.;
     }
     __syncthreads();
-    // leave A = V for cma_eig_wy: row i = u_i in columns < i, zero from column i on; the first
-    // 128 rows come from the LDS stash, the others were stashed in place
+    // V for cma_eig_wy, written straight to its place (Vout: n x n, dense): row i = u_i in
+    // columns < i, zero from column i on; the first 128 rows come from the LDS stash, the others
+    // from the rows of A they were stashed in
     const int lda = A.ld;
-    for (int q = tid; q < n * (nr >> 1); q += T) {
-        const int r = q / (nr >> 1), c2 = (q - r * (nr >> 1)) * 2;
-        double2 *cell = reinterpret_cast<double2*>(&A.a[(size_t) r * lda + c2]);
-        double2 v = make_double2(0., 0.);
-        if (r < 128) {
-            if (c2 < r) v.x = As(r, c2);
-            if (c2 + 1 < r) v.y = As(r, c2 + 1);
-        } else if (c2 < r) {
-            v = *cell;
-            if (c2 + 1 >= r) v.y = 0.;
-        }
-        *cell = v;
+    for (int q = tid; q < n * n; q += T) {
+        const int r = q / n, cidx = q - r * n;
+        double v = 0.;
+        if (cidx < r) v = r < 128 ? As(r, cidx) : A.a[(size_t) r * lda + cidx];
+        Vout[q] = v;
     }
     __syncthreads();
     for (int k = tid; k < n; k += T) dv[k] = td[k];
@@ -1119,7 +1113,8 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         // (diagnostic bit 1024: round 2's form of the first n - 128 steps, streaming from L2)
         if (hybrid && !(d.dbg & 2) && !(d.dbg & 1024))
             eig_tred_sym256(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, nv, tid,
-                    (d.stamps && p == 0) ? d.stamps : nullptr, Ast, false);
+                    (d.stamps && p == 0) ? d.stamps : nullptr, Ast, false,
+                    d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld));
         else
         eig_tred_accum_global(C, ld, n, A, dv, ev, uv, wv, gv, hvec, td, part, nv, tid,
                 (d.stamps && p == 0) ? d.stamps : nullptr, hybrid ? &Ast : nullptr,
@@ -1141,7 +1136,8 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
         eig_dc_phase<TT>(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
                 d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg, LDSM ? 0 : 1, hvec);
+                d.dbg, LDSM ? 0 : 1, hvec,
+                !LDSM && pl.dc && !(d.dbg & 2) && !(d.dbg & 1024));   // V already in its place
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {

@@ -804,7 +804,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 template<int TT = 512>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
-        const double *hv = nullptr)
+        const double *hv = nullptr, bool qh_ready = false)
 {
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
@@ -817,6 +817,9 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     __shared__ int maxnr_s;
     __shared__ double scale_s;
 
+    // (qh_ready: the reduction has left V in Qh itself -- at n = 256 this copy, 512 KB global to
+    // global by one workgroup, took 54 us)
+    if (!qh_ready)
     for (int q = tid; q < n * n; q += T) {
         const int r = q / n, c = q - r * n;
         Qh[q] = Q(r, c);
