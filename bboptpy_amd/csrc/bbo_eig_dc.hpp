@@ -884,8 +884,14 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         dv[i] *= scale;
         ev[i] *= scale;
     }
-    // Q becomes the eigenvector matrix of T: clear it
-    for (int q = tid; q < n * Q.ld; q += T) Q.a[q] = 0.;
+    // Q becomes the eigenvector matrix of T: clear it (16-byte stores where the rows allow: the
+    // global work matrix of n > 128 is 512 KB for this one workgroup)
+    if ((Q.ld & 1) == 0 && (reinterpret_cast<size_t>(Q.a) & 15) == 0) {
+        double2 *q2 = reinterpret_cast<double2*>(Q.a);
+        for (int q = tid; q < (n * Q.ld) >> 1; q += T) q2[q] = make_double2(0., 0.);
+    } else {
+        for (int q = tid; q < n * Q.ld; q += T) Q.a[q] = 0.;
+    }
     __syncthreads();
     // rank-one tears at the block boundaries
     if (tid >= 1 && tid < nblk) {
