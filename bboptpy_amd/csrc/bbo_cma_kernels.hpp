@@ -172,15 +172,29 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     const double *bdp = d.BDp + (size_t) p * ld * ld;
     const int ar = lane & 15, ak = lane >> 4;
     double zz = 0.;
-    for (int ks = 0; ks < KS; ks++) {
-        const double a = lds[ar * ldz + 4 * ks + ak];
-        zz = __builtin_fma(a, a, zz);
+    // four k-steps of operand fragments requested before the first of their MFMAs: with one
+    // 16-row tile per workgroup (small lambda: a handful of workgroups on the whole chip) the
+    // fragments come from L2 one dependent round trip per k-step otherwise.  (ld is a multiple
+    // of 16: KS is a multiple of 4.)  Same products in the same order.
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+        double a[4], b[4][MAXT];
 #pragma unroll
-        for (int t = 0; t < MAXT; t++) {
-            const int nt = wave + 4 * t;
-            if (nt < NT) {
-                const double b = bdp[((size_t) nt * KS + ks) * 64 + lane];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < 4; u++) {
+            a[u] = lds[ar * ldz + 4 * (ks0 + u) + ak];
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                const int nt = wave + 4 * t;
+                b[u][t] = nt < NT ? bdp[((size_t) nt * KS + ks0 + u) * 64 + lane] : 0.;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            zz = __builtin_fma(a[u], a[u], zz);
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                const int nt = wave + 4 * t;
+                if (nt < NT)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][t], acc[t], 0, 0, 0);
             }
         }
     }
