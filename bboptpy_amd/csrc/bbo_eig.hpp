@@ -1359,13 +1359,24 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
             const int row = 16 * rt + fk + 4 * r;
             q[rt][r] = (live && row < n && col < n) ? M[(size_t) row * n + col] : 0.;
         }
+    // panel b + 1 is on its way from L2 (in registers) while panel b is applied: staged straight
+    // from global memory every panel exposed a round trip, 16 times per launch
+    double pre[16];
+    auto fetch = [&](int b) {
+        const int i0 = 16 * b, reach = min(n, i0 + 16);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int k = tid;      // e = tid + 256 u: row j = u, column k = tid
+            pre[u] = (i0 + u < n && k < reach) ? V[(size_t) (i0 + u) * n + k] : 0.;
+        }
+    };
+    fetch(0);
     for (int b = 0; b < npanel; b++) {
         const int i0 = 16 * b, reach = min(n, i0 + 16);
         __syncthreads();
-        for (int e = tid; e < 16 * 256; e += 256) {
-            const int j = e >> 8, k = e & 255;
-            Vp[j * WY_LDV + k] = (i0 + j < n && k < reach) ? V[(size_t) (i0 + j) * n + k] : 0.;
-        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) Vp[u * WY_LDV + tid] = pre[u];
+        if (b + 1 < npanel) fetch(b + 1);
         double tv[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
