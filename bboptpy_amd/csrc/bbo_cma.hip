@@ -601,7 +601,13 @@ void CmaEngine::launch_eigen()
     if (pl.dc && !pl.reg_path) {
         // 128 < n <= 256: the top merge's two products as whole-GPU kernels
         dim3 grid((c.n + 63) / 64, (c.n + 63) / 64, c.npop);
-        hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
+        // few populations: 64 x 16 blocks, four times the workgroups (same sums, same order)
+        const bool narrow = (long) grid.x * grid.y * grid.z < 128;
+        dim3 grid1((c.n + 15) / 16, (c.n + 63) / 64, c.npop);
+        if (narrow)
+            hipLaunchKernelGGL(cma_eig_gemm1, grid1, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
+        else
+            hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
         // second product: the stashed reflectors applied in blocked form (the QL fallback of
         // the diagnostic switch has accumulated Q_house instead)
         if (d_.dbg & 2)

@@ -1269,7 +1269,11 @@ __global__ __launch_bounds__(128, 2) void cma_eigen_128(CmaDev d, CmaConst c, Ei
 // which = 1: eig_work[1] (Q_house) * eig_work[3] -> d.B.
 // grid (ceil(n/64), ceil(n/64), P), 256 threads: wavefront w owns rows 16w.. of a 64 x 64 block
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int lda_work, int which)
+// CT = column tiles per wavefront: 4 (a 64 x 64 block per workgroup) when many populations fill the
+// chip, 1 (64 x 16) when a handful do not -- one population at n = 256 is 16 workgroups of CT = 4,
+// each wavefront a chain of 1024 MFMAs (30 us), or 64 workgroups of CT = 1
+template<int CT>
+__device__ __forceinline__ void eig_gemm_body(const CmaDev &d, const CmaConst &c, int lda_work, int which)
 {
     const int p = blockIdx.z;
     const CmaScal *sc = d.scal + p;
@@ -1286,19 +1290,19 @@ __global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int ld
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int row = blockIdx.y * 64 + wave * 16 + fr;
-    const int col0 = blockIdx.x * 64 + fr;
-    d4_eig acc[4];
+    const int col0 = blockIdx.x * 16 * CT + fr;
+    d4_eig acc[CT];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = d4_eig { 0., 0., 0., 0. };
+    for (int t = 0; t < CT; t++) acc[t] = d4_eig { 0., 0., 0., 0. };
     const int ksteps = (n + 3) >> 2;
     for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {
-        double av[4], bv[4][4];
+        double av[4], bv[4][CT];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int kk = 4 * (ks0 + u) + fk;
             av[u] = (row < n && kk < n) ? A[(size_t) row * lda + kk] : 0.;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < CT; t++) {
                 const int col = col0 + 16 * t;
                 bv[u][t] = (kk < n && col < n) ? Bm[(size_t) kk * n + col] : 0.;
             }
@@ -1306,11 +1310,11 @@ __global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int ld
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < CT; t++)
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < CT; t++) {
         const int col = col0 + 16 * t;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1318,6 +1322,15 @@ __global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int ld
             if (orow < n && col < n) Cm[(size_t) orow * ldc + col] = acc[t][r];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cma_eig_gemm(CmaDev d, CmaConst c, int lda_work, int which)
+{
+    eig_gemm_body<4>(d, c, lda_work, which);
+}
+__global__ __launch_bounds__(256) void cma_eig_gemm1(CmaDev d, CmaConst c, int lda_work, int which)
+{
+    eig_gemm_body<1>(d, c, lda_work, which);       // grid (ceil(n/16), ceil(n/64), P)
 }
 
 // ---------------------------------------------------------------------------
