@@ -598,8 +598,8 @@ void CmaEngine::launch_eigen()
                 pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
-    if (pl.dc && !pl.reg_path) {
-        // 128 < n <= 256: the top merge's two products as whole-GPU kernels
+    if (pl.dc && !pl.reg_path && (pl.hybrid || !(d_.dbg & 2))) {
+        // n > 128: the top merge's two products as whole-GPU kernels
         dim3 grid((c.n + 63) / 64, (c.n + 63) / 64, c.npop);
         // few populations: 64 x 16 blocks, four times the workgroups (same sums, same order)
         const bool narrow = (long) grid.x * grid.y * grid.z < 128;
@@ -610,7 +610,7 @@ void CmaEngine::launch_eigen()
             hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
         // second product: the stashed reflectors applied in blocked form (the QL fallback of
         // the diagnostic switch has accumulated Q_house instead)
-        if (d_.dbg & 2)
+        if ((d_.dbg & 2) || !pl.hybrid)     // (n > 256: Q_house was accumulated by the reduction)
             hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
         else
             hipLaunchKernelGGL(cma_eig_wy, dim3((c.n + 63) / 64, c.npop), dim3(256), 0, stream_, d_,

@@ -34,6 +34,7 @@ struct EigPlan {
     int use_lds;      // matrix in LDS?
     int reg_path;     // n <= 128: tred2 + accumulation run out of registers
     int dc;           // tridiagonal stage by divide and conquer (bbo_eig_dc.hpp) instead of QL
+    int hybrid;       // 128 < n <= 256: on-chip reduction, reflectors stashed (cma_eig_wy applies them)
     int lda;          // leading dimension of the work matrix
     int rc;           // Givens pairs per chunk buffer
     int vl;           // stride of the LDS vectors (>= 128, includes a 2-element front pad)
@@ -66,16 +67,17 @@ inline EigPlan eig_plan(int n, int ld)
     pl.threads = n <= 32 ? 128 : n <= 64 ? 256 : EIG_THREADS;
     pl.vl = (((n > 128 ? n : 128) + 31) & ~31) + 2;
     pl.reg_path = n <= 128 ? 1 : 0;
-    pl.dc = n <= 256 ? 1 : 0;          // 128 < n <= 256: matrix in global memory, top merge external
+    pl.dc = 1;                         // (n <= EIG_NMAX) n > 128: matrix in global memory, top merge external
+    pl.hybrid = (n > 128 && n <= 256) ? 1 : 0;   // above 256: streaming reduction with Q_house accumulated
     const size_t budget = 160 * 1024 - 1024;
     const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
     const size_t vecs = ((size_t) EIG_NVEC * pl.vl
-            + eig_part_doubles(pl.vl, pl.reg_path != 0, pl.dc && !pl.reg_path)) * sizeof(double);
+            + eig_part_doubles(pl.vl, pl.reg_path != 0, pl.hybrid != 0)) * sizeof(double);
     const int lda_lds = n | 1;
     const size_t mat = (size_t) n * lda_lds * sizeof(double);
     const size_t fixed = vecs + ints;
     // the chunk buffers need room for at least one full QL sweep (n-1 pairs) each
-    if (fixed + mat + (size_t) 2 * n * 16 <= budget && !(pl.dc && !pl.reg_path)) {
+    if (fixed + mat + (size_t) 2 * n * 16 <= budget && pl.reg_path) {
         pl.use_lds = 1;
         pl.lda = lda_lds;
         size_t rc = (budget - fixed - mat) / (2 * 16);
@@ -89,7 +91,7 @@ inline EigPlan eig_plan(int n, int ld)
     } else {
         pl.use_lds = 0;
         pl.lda = (n + 31) & ~31;      // global work matrix: rows 256-byte aligned, unguarded 32-column groups
-        if (pl.dc) {
+        if (pl.hybrid) {
             // no QL chunk buffers; a 128 x 128 LDS matrix for the register-resident tail
             pl.rc = 0;
             pl.lds_bytes = fixed + (size_t) 128 * 130 * sizeof(double);
@@ -1084,7 +1086,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     double *uh0 = td + nv, *uh1 = uh0 + nv;
     double *part = uh1 + nv - 2;  // [4][nv] column partial sums (generic path only)
     double2 *rot = reinterpret_cast<double2*>(part
-            + eig_part_doubles(nv, pl.reg_path != 0, pl.dc && !pl.reg_path));   // [2][rc]
+            + eig_part_doubles(nv, pl.reg_path != 0, pl.hybrid != 0));   // [2][rc]
     int *ibuf = reinterpret_cast<int*>(rot + 2 * pl.rc);        // desc[2][MAXSEQ*3], nseq[2], done[2], misc
     int *desc = ibuf;
     int *nseq = ibuf + 2 * EIG_MAXSEQ * 3;
@@ -1107,7 +1109,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
                 (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true,
                 !(pl.dc && !(d.dbg & 2)));
     } else if (TT == EIG_THREADS && !LDSM) {
-        const bool hybrid = pl.dc != 0;      // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
+        const bool hybrid = pl.hybrid != 0;  // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
         // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
         // (diagnostic bit 1024: round 2's form of the first n - 128 steps, streaming from L2)
@@ -1134,10 +1136,20 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         double *scr = uv;
         DcMat Qm { A.a, A.ld };
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
-        eig_dc_phase<TT>(Qm, n, dv, ev, d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld),
-                d.B + (size_t) p * ld * ld, ld, scr, (d.stamps && p == 0) ? d.stamps : nullptr,
-                d.dbg, LDSM ? 0 : 1, hvec,
-                !LDSM && pl.dc && !(d.dbg & 2) && !(d.dbg & 1024));   // V already in its place
+        double *Gp = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
+        double *Bp_ = d.B + (size_t) p * ld * ld;
+        long long *st_ = (d.stamps && p == 0) ? d.stamps : nullptr;
+        if (LDSM || pl.hybrid || TT != EIG_THREADS) {
+            // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
+            eig_dc_phase<TT, false>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
+                    !LDSM && !(d.dbg & 2) && !(d.dbg & 1024));   // (hybrid: V already in its place)
+        } else if (TT == EIG_THREADS && !LDSM) {
+            // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
+            // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
+            // register-resident product cannot hold go through the slab the first of them fills
+            eig_dc_phase<TT, true>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, 1, nullptr, false,
+                    d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld));
+        }
     } else
     // ---- implicit QL (cmaes.cpp:388-456), producer / consumer over two chunk buffers -----
     {

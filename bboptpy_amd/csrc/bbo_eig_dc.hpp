@@ -31,7 +31,8 @@ namespace bbo {
 typedef double dc_d4 __attribute__((ext_vector_type(4)));
 
 constexpr int DC_LEAF = 16;
-constexpr int DC_MAXB = 16;          // max leaves (n <= 256)
+constexpr int DC_MAXB = 16;          // max leaves, n <= 256
+constexpr int DC_MAXB_BIG = 32;      // ... n <= 512 (the BIG instantiations)
 constexpr double DC_EPS = 0x1.0p-53;
 constexpr int DC_KSTEPS = 32;        // k-steps of a 128-deep MFMA contraction
 
@@ -131,9 +132,12 @@ __device__ inline double dc_quad_sum(double v)
 // walk through the same barriers).  Q (LDS) holds the blocks' eigenvectors on its diagonal
 // blocks (zeros elsewhere inside [a,b)^2), dv their eigenvalues, rho_in = e[mid-1].
 // Fg (global) is scratch for the eigenvector factor of this merge (m x m).
-template<int LPR, bool do_gemm>
+// BIG: instantiations for 256 < n <= 512 (two passes over a level's merges, merges the
+// register-resident product cannot hold); the n <= 256 ones compile exactly as before
+template<int LPR, bool do_gemm, bool BIG = false>
 __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
-        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps)
+        double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps,
+        int mlevel = 0, double *Tg = nullptr)     // widest merge of this level; m x m global scratch
 {
 #define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a > 64) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
@@ -520,7 +524,46 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     MG_STAMP(29);
     // (the top merge of a matrix wider than 128 leaves F in global memory: the two products
     // Q F and Q_house (Q F) are separate whole-GPU kernels, cma_eig_gemm)
-    if (do_gemm) {
+    if (BIG && do_gemm && (mlevel > 4 * DC_KSTEPS || ((mlevel + 15) >> 4) > 2 * tm.nwaves)) {
+    // ---- merges the register-resident form below cannot hold (n > 256 only): it keeps the F
+    // fragments of at most TWO 16-column tiles per wavefront of the team, 128 deep -- enough for
+    // every level of n <= 256 (m <= 32 x the team's wavefronts), not for 32 leaves on 8
+    // wavefronts (m = 35 or 64 on one, 128 on two, 256 on four).  Here every 16 x 16 tile of the
+    // product is formed by itself, operands straight from global memory (four k-steps requested
+    // ahead), into the scratch Tg, then copied back.  The same for every team of the level.
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ntl = (mlevel + 15) >> 4, ntile = (m + 15) >> 4;
+    const int ksteps = (m + 3) >> 2;
+    for (int t = tm.twave; t < ntl * ntl; t += tm.nwaves) {
+        const int rt = t / ntl, ct = t - rt * ntl;
+        if (!on || rt >= ntile || ct >= ntile) continue;
+        dc_d4 acc = { 0., 0., 0., 0. };
+        const int arow = rt * 16 + fr, col = ct * 16 + fr;
+        for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int kk = 4 * (ks0 + u) + fk;
+                av[u] = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
+                bv[u] = (kk < m && col < m) ? Fg[(size_t) kk * m + col] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rt * 16 + (lane >> 4) + 4 * r;
+            if (row < m && col < m) Tg[(size_t) row * m + col] = acc[r];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int q = ttid; q < m * m; q += TT) {
+        const int r = q / m, c = q - r * m;
+        Q(a + r, a + c) = Tg[q];
+    }
+    } else if (do_gemm) {
     // ---- Q[a:b, a:b] <- Q[a:b, a:b] F on the matrix cores, 16 rows at a time, in place.
     // A wavefront keeps the F fragments of its column tile(s) in registers for the whole
     // merge; every wavefront finishes reading the 16 old rows before any of them is stored.
@@ -801,10 +844,10 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 // (forceinline: called once with Q in LDS and once with Q in global memory from cma_eigen -- as a
 // shared out-of-line function it would see generic pointers and address everything with FLAT
 // instructions)
-template<int TT = 512>
+template<int TT = 512, bool BIG = false>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
-        const double *hv = nullptr, bool qh_ready = false)
+        const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr)
 {
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
@@ -812,7 +855,8 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     const int NW = T >> 6;
     double *Qh = G;                       // Q_house, n x n row-major
     double *F = G + (size_t) n * n;       // merge factors (one m x m slab per merge)
-    __shared__ int bounds[DC_MAXB + 1];
+    constexpr int MAXB = BIG ? DC_MAXB_BIG : DC_MAXB;
+    __shared__ int bounds[MAXB + 1];
     __shared__ int nblk_s;
     __shared__ int maxnr_s;
     __shared__ double scale_s;
@@ -865,7 +909,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
             int widest = 0;
             for (int i = 0; i < nb; i++) widest = max(widest, bounds[i + 1] - bounds[i]);
             if (widest <= DC_LEAF) break;
-            int tmp[DC_MAXB + 1];
+            int tmp[MAXB + 1];
             int c2 = 0;
             tmp[c2++] = bounds[0];
             for (int i = 0; i < nb; i++) {
@@ -914,7 +958,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
 
     DC_STAMP(18);
     // ---- merges, bottom-up; all merges of a level run at once, each by its own team --------
-    int cur[DC_MAXB + 1];
+    int cur[MAXB + 1];
     int nc = nblk;
     for (int i = 0; i <= nblk; i++) cur[i] = bounds[i];
     while (nc > 1 && !(dbg & 4)) {
@@ -922,9 +966,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         int teams = 1;
         while (teams < nm) teams <<= 1;               // 1, 2, 4, 8
         const int wpt = NW / teams > 0 ? NW / teams : 1;   // wavefronts per team
+        // lanes per secular root: as many as every team of this level can give its poles
+        // (chosen from the WIDEST merge so that all teams run the same code path)
+        int m = 0;
+        for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
+        // a level has at most NW teams at a time: 16 merges (32 leaves, n > 256) take two passes
+        const int tcount = min(teams, NW);
+        for (int pass = 0; pass * tcount < nm && (BIG || pass == 0); pass++) {
         DcTeam tm;
         tm.id = wave / wpt;
-        tm.active = tm.id < nm;
+        const int q0 = pass * tcount + tm.id;
+        tm.active = q0 < nm;
         tm.wave0 = tm.id * wpt;
         tm.nwaves = wpt;
         tm.twave = wave - tm.wave0;
@@ -932,24 +984,26 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         tm.tthreads = 64 * wpt;
         if (tid == 0) maxnr_s = 0;
         __syncthreads();
-        const int q = tm.active ? tm.id : 0;
+        const int q = tm.active ? q0 : 0;
         const int a = cur[2 * q], mid = cur[2 * q + 1], b = cur[2 * q + 2];
         double *Fg = F + (size_t) a * n;
+        double *Tbuf = Tscratch ? Tscratch + (size_t) a * n : nullptr;
         const double rho = ev[mid - 1];
-        // lanes per secular root: as many as every team of this level can give its poles
-        // (chosen from the WIDEST merge so that all teams run the same code path)
-        int m = 0;
-        for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
         if (ext_top && nc == 2) {
-            // the top merge of a matrix wider than 128 (512 threads, m <= 256): scalar part only
-            dc_merge_level<2, false>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            // the top merge of a matrix wider than 128 (512 threads): scalar part only
+            if (2 * m <= tm.tthreads)
+                dc_merge_level<2, false, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+            else
+                dc_merge_level<1, false, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         } else if (4 * m <= tm.tthreads)
-            dc_merge_level<4, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            dc_merge_level<4, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         else if (2 * m <= tm.tthreads)
-            dc_merge_level<2, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
+            dc_merge_level<2, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         else
-            dc_merge_level<1, true>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps);
-        int nxt[DC_MAXB + 1];
+            dc_merge_level<1, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+        if (BIG) __syncthreads();
+        }
+        int nxt[MAXB + 1];
         int nn = 0;
         nxt[nn++] = cur[0];
         for (int i = 0; i + 1 < nc; i += 2) nxt[nn++] = cur[i + 2];
