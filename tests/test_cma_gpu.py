@@ -271,10 +271,11 @@ def _spd_cases(n, rng):
 
 
 @pytest.mark.parametrize("n", [10, 16, 17, 37, 64, 100, 128, 129, 144, 145, 160, 200, 224, 225, 255, 256,
-                               300])
+                               257, 280, 300, 384, 512])
 def test_eigendecomposition_special_matrices(hip, n):
-    """the eigensolver alone (QL for n <= 16, Householder + divide and conquer above) on
-    matrices that stress deflation, clustering and scaling; checked against numpy.eigh"""
+    """the eigensolver alone (QL for n <= 16, Householder + divide and conquer above: register
+    path to 128, on-chip symmetric steps to 256, streaming reduction + two-pass merge levels to
+    512) on matrices that stress deflation, clustering and scaling; checked against numpy.eigh"""
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
     g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
