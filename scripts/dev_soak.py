@@ -9,8 +9,9 @@ objs = [b.objectives.sphere, b.objectives.rosenbrock, b.objectives.rastrigin, b.
 t0 = time.time(); runs = 0
 while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
     algo = rng.choice(["CMAES", "ActiveCMAES", "SepCMAES", "SHADE", "JADE", "SANSDE", "APSO", "CSO"])
-    n = int(rng.choice([1, 2, 3, 7, 10, 16, 17, 31, 32, 33, 50, 64, 65, 100, 127, 128, 129, 150, 200]))
+    n = int(rng.choice([1, 2, 3, 7, 10, 16, 17, 31, 32, 33, 50, 64, 65, 100, 127, 128, 129, 150, 200, 255, 256, 257, 300, 384, 512]))
     P = int(rng.choice([1, 2, 3, 4, 5, 9, 33, 64]))
+    if n > 200: P = min(P, 9)
     f = objs[rng.integers(len(objs))]
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     kw = dict(seed=int(rng.integers(1 << 30)), populations=P)
@@ -18,6 +19,8 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
         if algo in ("CMAES", "ActiveCMAES", "SepCMAES"):
             lam = int(rng.choice([4, 7, 16, 20, 50, 64, 65, 130, 300]))
             if algo == "SepCMAES" and n < 2: continue
+            # the reference's uncapped (n+2)/3 learning-rate adjustment: c_cov > 1 there
+            if algo == "SepCMAES" and lam > 4 * n: continue
             a = getattr(b, algo)(mfev=10**7, tol=1e-12, np=lam, **kw)
             key, per = "xmean", lam
         elif algo == "SHADE":

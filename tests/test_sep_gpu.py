@@ -81,6 +81,30 @@ def test_generation_matches_oracle(hip, oracle_lib, n, lam, obj, bound, adjustlr
         o.set("sigma", g.get_state("sigma"))
 
 
+def test_uncapped_learning_rate_matches_the_reference(hip, oracle_lib):
+    """The reference multiplies c_cov by (n + 2)/3 without a cap (sep_cmaes.cpp:56-58, on by
+    default): for lambda large against n, c_cov > 1, the diagonal covariance turns negative and the
+    reference's state is NaN within two generations.  A drop-in does the same: same c_cov, and
+    non-finite from the same generation under the same normals -- not a silent repair."""
+    n, lam = 7, 300
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.full(n, 1.5)
+    g = hip.SepCMAES(mfev=10 ** 7, tol=1e-12, np=lam, seed=5)
+    g.initialize(hip.objectives.sphere, lo, up, guess)
+    o = po.cma(oracle_lib, "sep", 10 ** 7, 1e-12, lam, adjustlr=True)
+    o.set_rng(po.RNG_PHILOX, 5)
+    o.init("sphere", lo, up, guess)
+    assert g.get_state("ccov")[0] == o.scalar("ccov") > 1.
+    first = {}
+    for gen in range(6):
+        g.iterate()
+        o.iterate()
+        for who, x in (("device", g.get_state("xmean")), ("oracle", o.get("xmean", n))):
+            if who not in first and not np.all(np.isfinite(x)):
+                first[who] = gen
+    assert "oracle" in first and first.get("device") == first["oracle"], first
+
+
 def test_sep_rejects_full_covariance_keys(hip):
     g = hip.SepCMAES(mfev=1000, tol=1e-8, np=8)
     g.initialize(hip.objectives.sphere, -np.ones(4), np.ones(4), np.zeros(4))
