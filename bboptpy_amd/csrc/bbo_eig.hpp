@@ -127,8 +127,7 @@ __device__ inline double tred_matvec(const double (&a_)[4][8], double (&ur)[4][8
             acc1 = __builtin_fma(a_[a][b + 1], ur[a][b + 1], acc1);
         }
     double acc = acc0 + acc1;
-    acc += __shfl_xor(acc, 1, 4);
-    acc += __shfl_xor(acc, 2, 4);
+    acc = eig_quad_sum(acc);
     return acc;
 }
 
@@ -167,8 +166,7 @@ __device__ inline void accum_step(double (&a_)[4][8], const EigMat &As, int row,
             acc1 = __builtin_fma(ur[a][b + 1], a_[a][b + 1], acc1);
         }
     double acc = acc0 + acc1;
-    acc += __shfl_xor(acc, 1, 4);
-    acc += __shfl_xor(acc, 2, 4);
+    acc = eig_quad_sum(acc);
     const double gq = -(acc / h);
 #pragma unroll
     for (int a = 0; a < AMAX; a++)
@@ -476,8 +474,7 @@ __device__ inline void eig_tred_accum_global(const double *C, int ld, int n, con
                     }
             }
             double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
+            acc = eig_quad_sum(acc);
             if (rq == 0) gv[j] = acc;
         }
         __syncthreads();
@@ -831,8 +828,7 @@ __device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C,
                 EIG_SEQ();
             }
             double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
+            acc = eig_quad_sum(acc);
             if (rq == 0) gv[rj0] = acc;
         }
         EIG_CLK(2);
@@ -852,8 +848,7 @@ __device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C,
                 EIG_SEQ();
             }
             double acc = acc0 + acc1;
-            acc += __shfl_xor(acc, 1, 4);
-            acc += __shfl_xor(acc, 2, 4);
+            acc = eig_quad_sum(acc);
             if (rq == 0) gv[R22] = acc;
             // L21: rows (L21 u_top -> gv2) and columns (L21^T u_bot -> part[wave])
             double2 ut[4];

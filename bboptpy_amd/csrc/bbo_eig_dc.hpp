@@ -57,6 +57,18 @@ __device__ inline double dc_rcp(double x)
     return r;
 }
 
+// sqrt(x) for x >= 0 from the reciprocal-root estimate (one third-order correction + one step on
+// the root: full fp64 to a rounding error); 0 for x = 0
+__device__ inline double dc_sqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double err = fma(-x * y, y, 1.);
+    y = fma(y * err, fma(err, 0.375, 0.5), y);
+    double r = x * y;
+    r = fma(fma(-r, r, x), 0.5 * y, r);
+    return x > 0. && x < __builtin_huge_val() ? r : x;
+}
+
 // Key of a ranking by counting.  The maps built from such rankings (sorted position -> source
 // column, root -> output column) are used as INDICES: a ranking must be a permutation whatever
 // the data.  With a NaN every comparison is false, all NaN entries would get the same rank and
@@ -123,8 +135,8 @@ __device__ inline double dc_team_max(double v, double *red, const DcTeam &tm)
 template<int LPR>
 __device__ inline double dc_quad_sum(double v)
 {
-#pragma unroll
-    for (int s = 1; s < LPR; s <<= 1) v += __shfl_xor(v, s, LPR);
+    if (LPR >= 2) v += eig_quad_xor1(v);
+    if (LPR >= 4) v += eig_quad_xor2(v);
     return v;
 }
 
@@ -139,7 +151,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps,
         int mlevel = 0, double *Tg = nullptr)     // widest merge of this level; m x m global scratch
 {
-#define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && b - a > 64) stamps[slot] = wall_clock64(); } while (0)
+#define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && a == 0) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
     const int lane = threadIdx.x & 63;
     const int ttid = tm.ttid, TT = tm.tthreads;
@@ -393,7 +405,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                     if (last) {
                         const double aa = dpsi * dlp * dlp, ss = psi - dpsi * dlp;
                         const double c0 = 1. + ss + phi;
-                        const double eta = dlp + aa / c0;
+                        const double eta = dlp + aa * dc_rcp(c0);
                         const double cand = mu + eta;
                         if (eta == eta && cand > lo && cand < hi) nmu = cand;
                     } else {
@@ -403,9 +415,11 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                         const double c0 = 1. + ss + rr;
                         const double A1 = -(c0 * (dlp + drp) + aa + bb);
                         const double A0 = c0 * dlp * drp + aa * drp + bb * dlp;
+                        // (the model only proposes the next iterate, the bracket and the residual
+                        // test decide: hardware estimates + Newton, not the IEEE sequences)
                         const double disc = fmax(A1 * A1 - 4. * c0 * A0, 0.);
-                        const double qq = -0.5 * (A1 + (A1 >= 0. ? 1. : -1.) * sqrt(disc));
-                        const double e1 = qq / c0, e2 = A0 / qq;
+                        const double qq = -0.5 * (A1 + (A1 >= 0. ? 1. : -1.) * dc_sqrt(disc));
+                        const double e1 = qq * dc_rcp(c0), e2 = A0 * dc_rcp(qq);
                         const double c1 = mu + e1, c2 = mu + e2;
                         if (e1 == e1 && c1 > lo && c1 < hi) nmu = c1;
                         else if (e2 == e2 && c2 > lo && c2 < hi) nmu = c2;
@@ -414,8 +428,11 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                     else mu = nmu;
                 }
             }
-            if (__syncthreads_count(done ? 0 : 1) == 0) {
-                if (stamps && threadIdx.x == 0 && b - a > 64) stamps[31] = it + 1;
+            // every wavefront leaves when ITS roots are done (the loop reads the merge's vectors
+            // and writes nothing shared): no workgroup barrier per iteration, and a finished
+            // wavefront leaves its SIMD's issue slots to the one still iterating
+            if (__ballot(!done) == 0ull) {
+                if (stamps && threadIdx.x == 0 && a == 0) stamps[31] = it + 1;
                 break;
             }
         }
@@ -443,8 +460,8 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 prod *= jj == i ? num : num * dc_rcp(W.dl[jj] - di2);
             }
         }
-#pragma unroll
-        for (int s = 1; s < LPR; s <<= 1) prod *= __shfl_xor(prod, s, LPR);
+        if (LPR >= 2) prod *= eig_quad_xor1(prod);
+        if (LPR >= 4) prod *= eig_quad_xor2(prod);
         if (on && k > 1 && i < k && sub == 0) {
             const double v = sqrt(fabs(prod));
             W.what[i] = W.ws[i] >= 0. ? v : -v;
@@ -490,6 +507,14 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.colroot[W.outpos[k + ttid]] = -1;
     }
     __syncthreads();
+    // The in-place product below keeps F as MFMA B fragments in registers: when no deflation
+    // rotation fired anywhere on this level (the common case) every lane forms ITS fragment
+    // entries straight from the merge's vectors -- same expression, same bits -- and F never
+    // travels through global memory (a store, a fence, two barriers and a load per merge).
+    constexpr bool FRAG_OK = do_gemm;
+    const bool generic_prod = BIG && do_gemm && (mlevel > 4 * DC_KSTEPS || ((mlevel + 15) >> 4) > 2 * tm.nwaves);
+    const bool direct = FRAG_OK && maxnr == 0 && !generic_prod;
+    if (!direct) {
     // F (rows in ORIGINAL column order), written in one pass
     for (int q = ttid; q < m * m; q += TT) {
         const int r = q / m, cidx = q - r * m;
@@ -520,11 +545,12 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     }
     __threadfence_block();
     __syncthreads();
+    }   // !direct
 
     MG_STAMP(29);
     // (the top merge of a matrix wider than 128 leaves F in global memory: the two products
     // Q F and Q_house (Q F) are separate whole-GPU kernels, cma_eig_gemm)
-    if (BIG && do_gemm && (mlevel > 4 * DC_KSTEPS || ((mlevel + 15) >> 4) > 2 * tm.nwaves)) {
+    if (generic_prod) {
     // ---- merges the register-resident form below cannot hold (n > 256 only): it keeps the F
     // fragments of at most TWO 16-column tiles per wavefront of the team, 128 deep -- enough for
     // every level of n <= 256 (m <= 32 x the team's wavefronts), not for 32 leaves on 8
@@ -571,6 +597,32 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const int ntile = (m + 15) >> 4;
     const int ksteps = (m + 3) >> 2;
     double bfrag[2][DC_KSTEPS];
+    if (direct) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int ct = tm.twave + u * tm.nwaves;
+            const int col = ct * 16 + fr;
+            const bool cok = on && ct < ntile && col < m;
+            const int j = cok ? W.colroot[col] : -1;
+            const double dorgj = j >= 0 ? W.dl[W.org[j]] : 0.;
+            const double muj = j >= 0 ? W.mu[j] : 0.;
+            const double nj = j >= 0 ? W.ninv[j] : 0.;
+#pragma unroll
+            for (int ks = 0; ks < DC_KSTEPS; ks++) {
+                const int kk = 4 * ks + fk;
+                double v = 0.;
+                if (cok && kk < m) {
+                    const int i = W.rowmap[kk];
+                    if (i >= 0) {
+                        if (j >= 0) v = k == 1 ? 1. : W.what[i] * dc_rcp((W.dl[i] - dorgj) - muj) * nj;
+                    } else if (-(1 + i) == col) {
+                        v = 1.;
+                    }
+                }
+                bfrag[u][ks] = v;
+            }
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int ct = tm.twave + u * tm.nwaves;
@@ -581,17 +633,25 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             bfrag[u][ks] = (on && ct < ntile && kk < m && col < m) ? Fg[(size_t) kk * m + col] : 0.;
         }
     }
-    // every team walks the same number of row tiles (the widest merge of the level)
-    for (int rt = 0; rt < (DC_KSTEPS * 4) / 16; rt++) {
+    }
+    // every team walks the same number of row tiles (the widest merge of the level).  Q is still
+    // BLOCK DIAGONAL here (Q_1 on [a, mid), Q_2 on [mid, b), zeros elsewhere): a row tile inside
+    // one block only has its block's columns to contract over -- half the k-steps of the merge
+    // multiply stored zeros, and skipping them leaves every sum as it was (x + 0 * f)
+    const int m1 = mid - a;
+    const int rtiles = mlevel > 0 ? min((mlevel + 15) >> 4, (DC_KSTEPS * 4) / 16) : (DC_KSTEPS * 4) / 16;
+    for (int rt = 0; rt < rtiles; rt++) {
         dc_d4 acc[2] = { { 0., 0., 0., 0. }, { 0., 0., 0., 0. } };
         const int arow = rt * 16 + fr;
+        const int klo = 16 * rt >= m1 ? m1 >> 2 : 0;
+        const int khi = 16 * rt + 16 <= m1 ? (m1 + 3) >> 2 : ksteps;
         if (rt < ntile) {
             // (a second column tile only when the merge is wider than 16 columns per wavefront
             // of its team -- uneven splits; for n = 128 every wavefront has exactly one)
             if (tm.twave + tm.nwaves < ntile) {
 #pragma unroll
                 for (int ks = 0; ks < DC_KSTEPS; ks++) {
-                    if (ks < ksteps) {
+                    if (ks >= klo && ks < khi) {
                         const int kk = 4 * ks + fk;
                         const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
                         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
@@ -601,7 +661,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             } else if (tm.twave < ntile) {
 #pragma unroll
                 for (int ks = 0; ks < DC_KSTEPS; ks++) {
-                    if (ks < ksteps) {
+                    if (ks >= klo && ks < khi) {
                         const int kk = 4 * ks + fk;
                         const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
                         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
@@ -961,7 +1021,11 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     int cur[MAXB + 1];
     int nc = nblk;
     for (int i = 0; i <= nblk; i++) cur[i] = bounds[i];
-    while (nc > 1 && !(dbg & 4)) {
+    // (diagnostic bits 8192 / 16384: stop after the first / second level, so that the phase clocks
+    // of dc_merge_level -- the first team's, every level overwrites them -- show THAT level)
+    int levels_done = 0;
+    while (nc > 1 && !(dbg & 4) && !((dbg & 8192) && levels_done >= 1) && !((dbg & 16384) && levels_done >= 2)) {
+        levels_done++;
         const int nm = nc >> 1;                       // merges at this level
         int teams = 1;
         while (teams < nm) teams <<= 1;               // 1, 2, 4, 8

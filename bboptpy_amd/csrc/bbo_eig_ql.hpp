@@ -28,6 +28,18 @@ __device__ inline double eig_dpp(double v)
     return __hiloint2double(hi, lo);
 }
 
+// partner exchange inside groups of four lanes (DPP quad_perm: a plain vector move, where
+// __shfl_xor goes through the LDS crossbar -- ds_bpermute, an address computation and a wait on
+// the critical path of every Householder step and every secular iteration)
+__device__ inline double eig_quad_xor1(double v) { return eig_dpp<0xB1>(v); }   // quad_perm:[1,0,3,2]
+__device__ inline double eig_quad_xor2(double v) { return eig_dpp<0x4E>(v); }   // quad_perm:[2,3,0,1]
+__device__ inline double eig_quad_sum(double v)     // all four lanes of a quad get the same sum
+{
+    v += eig_quad_xor1(v);
+    v += eig_quad_xor2(v);
+    return v;
+}
+
 __device__ inline double eig_readlane(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);

@@ -18,6 +18,8 @@ g.initialize(bb.objectives.rosenbrock, -10 * np.ones(n), 10 * np.ones(n),
              np.random.default_rng(1).uniform(-10, 10, (P, n)) if P > 1 else np.random.default_rng(1).uniform(-10, 10, n))
 g.run(30)                       # a covariance with some structure
 g.set_state("eig_stamps", [1.0])
+if len(sys.argv) > 3:                      # diagnostic bits (8192 / 16384: stop after merge level 1 / 2)
+    g.set_state("dbg", [float(sys.argv[3])])
 for rep in range(3):
     for ph in range(5):
         g.phase(ph)
