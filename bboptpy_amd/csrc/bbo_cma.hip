@@ -1126,6 +1126,8 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     }
     if (k == "eig_stamps") {
         if (stamps_.count != 48) stamps_.alloc(48);    // [32..47]: step clocks of diagnostic builds
+        BBO_HIP(hipStreamSynchronize(stream_));
+        BBO_HIP(hipMemset(stamps_.p, 0, 48 * sizeof(long long)));     // (set again = clear)
         d_.stamps = stamps_.p;
         return 1;
     }

@@ -348,40 +348,96 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             const double g0 = rho * wo / rest1;
             if (g0 == g0 && g0 > lo && g0 < hi) mu = g0;
         }
+        MG_STAMP(32);
         bool done = !act;
+#ifdef BBO_EIG_SECULAR_HIST
+        int hist_it = 0;
+#endif
+        // The poles of a lane, i = sub + LPR t, in REGISTERS for the whole solve when there are at
+        // most 32 of them (LPR = 4: every merge of n <= 128): delta_t = d_i - d_origin and w_t are
+        // loaded once, an evaluation is then a subtraction, a reciprocal and the sums -- no LDS
+        // read, no address, no end-of-list test per pole and iteration (the loop is bound by
+        // vector issue: 31 slots per pole from LDS, 20 from registers).  A pole beyond the list
+        // carries w = 0 and a delta no root comes near.
+        constexpr int NREG = 32;
+        const int npl = (k + LPR - 1) / LPR;
+        const int npl_s = __builtin_amdgcn_readfirstlane(npl);     // (k is the team's: uniform in a wavefront)
+        const bool inreg = LPR == 4 && npl_s <= NREG;
+        const int tsplit = j >= sub ? (j - sub) / LPR : -1;        // i <= j  <=>  t <= tsplit
+        double dreg[NREG], wreg[NREG];
+        if (inreg) {
+#pragma unroll
+            for (int t = 0; t < NREG; t++) {
+                const int i = sub + t * LPR;
+                const bool in = act && i < k;
+                const int ic = in ? i : 0;
+                const double dd = W.dl[ic], wl = W.w2[ic];
+                dreg[t] = in ? dd - dorg : 0x1p+1000;
+                wreg[t] = in ? wl : 0.;
+            }
+        }
         for (int it = 0; it < 64; it++) {
             double psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;
-            if (!done) {
-                // the poles up to j feed psi, the rest phi: two runs, four poles at a time
-                // (independent reciprocal chains; fp64 issue is what this loop costs)
-                const int isplit = sub + ((j + 1 - sub + LPR - 1) / LPR) * LPR;   // first i > j
+            if (!done && inreg) {
+                // same terms in the same order as the LDS form below: same bits
+                // (four poles per scalar branch: four independent reciprocal chains in flight; the
+                // padding poles of the last group add exact zeros)
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int ibeg = half ? isplit : sub, iend = half ? k : min(j + 1, k);
-                    double sa = 0., sb = 0.;
-                    for (int i0 = ibeg; i0 < iend; i0 += 4 * LPR) {
-                        double rr[4], ww[4];
+                for (int t0 = 0; t0 < NREG; t0 += 4) {
+                    if (t0 < npl_s) {
+                        double r[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int i = i0 + u * LPR;
-                            const bool in = i < iend;
-                            ww[u] = in ? W.w2[i] : 0.;
-                            rr[u] = dc_rcp(in ? (W.dl[i] - dorg) - mu : 1.);
-                        }
+                        for (int u = 0; u < 4; u++) r[u] = dc_rcp(dreg[t0 + u] - mu);
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            const double t = ww[u] * rr[u];
-                            fabs_ += fabs(t);
-                            sa += t;
-                            sb = __builtin_fma(t, rr[u], sb);
+                            const double tt = wreg[t0 + u] * r[u];
+                            const bool low = t0 + u <= tsplit;
+                            const double tp = low ? tt : 0., tq = low ? 0. : tt;
+                            fabs_ += fabs(tt);
+                            psi += tp;
+                            dpsi = __builtin_fma(tp, r[u], dpsi);
+                            phi += tq;
+                            dphi = __builtin_fma(tq, r[u], dphi);
                         }
                     }
-                    if (half) {
-                        phi = sa;
-                        dphi = sb;
-                    } else {
-                        psi = sa;
-                        dpsi = sb;
+                }
+            } else if (!done) {
+                // the poles up to j feed psi, the rest phi.  ONE loop with a wavefront-uniform trip
+                // count (k is the team's) over this lane's poles, four at a time: unconditional
+                // loads from a clamped index, the psi / phi split and the end of the list by
+                // selects.  (Written as two runs with per-lane bounds -- up to j, beyond j -- the
+                // loop compiled to an exec-mask loop with every load under its own branch and its
+                // own wait.)  Adding the zeros of the other run leaves each sum as it was.
+                for (int t0 = 0; t0 < npl; t0 += 4) {
+                    double rr[4], ww[4], dd[4];
+                    bool lowr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ic = min(sub + (t0 + u) * LPR, k - 1);
+                        ww[u] = W.w2[ic];
+                        dd[u] = W.dl[ic];
+                    }
+                    // (all four requests are out before the first value is waited for: left to
+                    // itself the scheduler, short of registers in this kernel, reuses one register
+                    // quad for all four loads and waits after each)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = sub + (t0 + u) * LPR;
+                        const bool in = i < k;
+                        ww[u] = in ? ww[u] : 0.;
+                        rr[u] = dc_rcp(in ? (dd[u] - dorg) - mu : 1.);
+                        lowr[u] = i <= j;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double t = ww[u] * rr[u];
+                        const double tp = lowr[u] ? t : 0., tq = lowr[u] ? 0. : t;
+                        fabs_ += fabs(t);
+                        psi += tp;
+                        dpsi = __builtin_fma(tp, rr[u], dpsi);
+                        phi += tq;
+                        dphi = __builtin_fma(tq, rr[u], dphi);
                     }
                 }
             }
@@ -396,6 +452,9 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 const double err = 8. * DC_EPS * (1. + rho * fabs_ * (1. + k));
                 if (fabs(f) <= err) {
                     done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                    hist_it = it + 1;
+#endif
                 } else {
                     if (f < 0.) lo = mu;
                     else hi = mu;
@@ -424,7 +483,12 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                         if (e1 == e1 && c1 > lo && c1 < hi) nmu = c1;
                         else if (e2 == e2 && c2 > lo && c2 < hi) nmu = c2;
                     }
-                    if (!(hi - lo > 4. * DC_EPS * fmax(fabs(lo), fabs(hi)))) done = true;
+                    if (!(hi - lo > 4. * DC_EPS * fmax(fabs(lo), fabs(hi)))) {
+                        done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                        hist_it = it + 1 + 100;      // (ended by the bracket, not the residual)
+#endif
+                    }
                     else mu = nmu;
                 }
             }
@@ -436,6 +500,15 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 break;
             }
         }
+        MG_STAMP(33);
+#ifdef BBO_EIG_SECULAR_HIST
+        // (diagnostic build: histogram of the iterations per root of the widest merge in slots
+        // 34..46, the root with the most in 47 as j * 1000 + iterations)
+        if (stamps && act && sub == 0 && b - a > 64) {
+            atomicAdd((unsigned long long*) &stamps[34 + min(hist_it, 12)], 1ull);
+            atomicMax((unsigned long long*) &stamps[47], (unsigned long long) hist_it * 1000000ull + j * 1000ull + k);
+        }
+#endif
         if (act && sub == 0) {
             W.mu[j] = mu;
             W.org[j] = o;

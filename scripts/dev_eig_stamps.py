@@ -21,6 +21,7 @@ g.set_state("eig_stamps", [1.0])
 if len(sys.argv) > 3:                      # diagnostic bits (8192 / 16384: stop after merge level 1 / 2)
     g.set_state("dbg", [float(sys.argv[3])])
 for rep in range(3):
+    g.set_state("eig_stamps", [1.0])       # clears the slots
     for ph in range(5):
         g.phase(ph)
     st = g.get_state("eig_stamps")
@@ -28,9 +29,9 @@ for rep in range(3):
              18: "leaves done", 19: "merge level(s) <top-1", 20: "merge level top-1",
              21: "merge top", 22: "merges done", 23: "reflectors/B done", 24: "mg start",
              25: "mg deflate", 26: "mg 26", 27: "mg secular", 28: "mg 28", 29: "mg 29",
-             30: "mg end"}
+             30: "mg end", 32: "mg sec prologue", 33: "mg sec loop (wave 0)"}
     t0 = min(v for v in st[:32] if v > 0)
-    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i < 32 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
+    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i < 34 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
     print("rep %d" % rep)
     prev = t0
     for v, i in rows:
@@ -38,6 +39,9 @@ for rep in range(3):
                                                     (v - t0) / 100.))
         prev = v
     print("   secular iterations (top merge): %d; leaf sweeps: %s" % (st[31], st[12:16]))
-    if len(st) >= 48 and any(st[40:48]):
+    if os.environ.get("SECULAR_HIST"):
+        print("   secular iterations per root (1, 2, ... 12, more): %s; worst: %d iterations at root %d of %d" % (
+            [int(v) for v in st[34:47]], st[47] // 1000000, (st[47] // 1000) % 1000, st[47] % 1000))
+    elif len(st) >= 48 and any(st[40:48]):
         print("   step clocks (cycles, BBO_EIG_STEP_CLOCKS build): barrier1 %d, chain+u %d, L11 product %d, "
               "L22/L21 product %d, barrier2 %d, w %d, rank-2 %d, loop end %d" % tuple(st[40:48]))
