@@ -76,6 +76,49 @@ __device__ inline double dc_sqrt(double x)
 // NaN entry made the eigensolver fault).  NaN ranks as +infinity; equal keys rank by position.
 __device__ inline double dc_key(double v) { return v == v ? v : __builtin_huge_val(); }
 
+// Rank by counting: the number of entries q < cnt of v (LDS) whose key is below `key`, or equal
+// to it with q < self.  Eight entries are requested before the first is looked at, and the trip
+// count is the wavefront's (cnt is the team's): written as a plain loop over v[q] this compiled to
+// one LDS round trip per two entries -- 64 serial waits for a 128-entry ranking, 3 us, three
+// rankings per merge.
+__device__ inline int dc_rank_of(const double *v, int cnt, double key, int self)
+{
+    const int cu = __builtin_amdgcn_readfirstlane(cnt);
+    int r = 0;
+    for (int q0 = 0; q0 < cu; q0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = v[min(q0 + u, cu - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            // (bitwise on purpose: && / || compile to a branch per entry here)
+            const double d = dc_key(x[u]);
+            const int qq = q0 + u;
+            const int lt = d < key ? 1 : 0, eq = d == key ? 1 : 0, before = qq < self ? 1 : 0;
+            r += (qq < cu ? 1 : 0) & (lt | (eq & before));
+        }
+    }
+    return r;
+}
+
+// The same rank for an entry of one of two lists that are EACH in ascending key order: its place in
+// its own list plus the number of entries of the other list that go before it -- entries with a
+// smaller key, and (for an entry of the second list, whose positions all come later) those with an
+// equal one.  A binary search: 7 dependent LDS reads instead of 128 comparisons.
+__device__ inline int dc_count_before(const double *v, int cnt, double key, bool or_equal)
+{
+    int lo = 0, hi = cnt;          // v[0 .. lo) go before, v[hi .. cnt) do not
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double d = dc_key(v[mid]);
+        const bool before = or_equal ? d <= key : d < key;
+        lo = before ? mid + 1 : lo;
+        hi = before ? hi : mid;
+    }
+    return lo;
+}
+
 // the team of wavefronts that works on one merge
 struct DcTeam {
     int active;       // has a merge at this level
@@ -83,6 +126,7 @@ struct DcTeam {
     int tthreads;     // threads of the team
     int wave0, nwaves, twave;
     int id;
+    int sorted_in;    // both blocks come out of merges: their eigenvalues are in ascending order
 };
 
 // LDS work area shared by all merges of a level: every array is indexed by the block's
@@ -108,10 +152,20 @@ struct DcWork {
     int *maxnr;           // [1]
 };
 
+// (wavefront stage on the cross-lane data path, eig_wave_sum / dc_wave_max: six ds_bpermute round
+// trips through the LDS crossbar before)
+__device__ inline double dc_wave_max(double v)
+{
+    v = fmax(v, eig_dpp<0x128>(v));   // row_ror:8
+    v = fmax(v, eig_dpp<0x124>(v));   // row_ror:4
+    v = fmax(v, eig_dpp<0x122>(v));   // row_ror:2
+    v = fmax(v, eig_dpp<0x121>(v));   // row_ror:1
+    return fmax(fmax(eig_readlane(v, 0), eig_readlane(v, 16)), fmax(eig_readlane(v, 32), eig_readlane(v, 48)));
+}
+
 __device__ inline double dc_team_sum(double v, double *red, const DcTeam &tm)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = eig_wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -122,8 +176,7 @@ __device__ inline double dc_team_sum(double v, double *red, const DcTeam &tm)
 
 __device__ inline double dc_team_max(double v, double *red, const DcTeam &tm)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = dc_wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -173,21 +226,19 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         zi = col < mid ? Q(mid - 1, col) : sgn * Q(mid, col);
     }
     const double zn2 = dc_team_sum(ttid < m ? zi * zi : 0., W.red, tm);
-    const double zn = sqrt(zn2);
+    const double zn = dc_sqrt(zn2);
     const double rho = fabs(rho_in) * zn2;
     if (ttid < m) {
-        zi /= zn;
+        zi *= dc_rcp(zn);
         W.lam[ttid] = di;          // unsorted copies for the ranking below
         W.what[ttid] = zi;
     }
     __syncthreads();
     if (ttid < m) {
-        int r = 0;
-        const double ki = dc_key(di);
-        for (int j = 0; j < m; j++) {
-            const double dj = dc_key(W.lam[j]);
-            r += (dj < ki) || (dj == ki && j < ttid);
-        }
+        const int m1 = mid - a;
+        const int r = !tm.sorted_in ? dc_rank_of(W.lam, m, dc_key(di), ttid)
+                : ttid < m1 ? ttid + dc_count_before(W.lam + m1, m - m1, dc_key(di), false)
+                            : (ttid - m1) + dc_count_before(W.lam, m1, dc_key(di), true);
         W.dS[r] = di;
         W.zS[r] = zi;
         W.srcS[r] = a + ttid;
@@ -295,11 +346,15 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     if (ttid < k) {
         const int pos = W.kp[ttid];
         const double dk = W.dS[pos];
-        int r = 0;
-        const double kk = dc_key(dk);
-        for (int j = 0; j < k; j++) {
-            const double dj = dc_key(W.dS[W.kp[j]]);
-            r += (dj < kk) || (dj == kk && j < ttid);
+        // (without a rotation the kept poles are a subsequence of the sorted ones: in order)
+        int r = ttid;
+        if (nr > 0) {
+            r = 0;
+            const double kk = dc_key(dk);
+            for (int j = 0; j < k; j++) {
+                const double dj = dc_key(W.dS[W.kp[j]]);
+                r += (dj < kk) || (dj == kk && j < ttid);
+            }
         }
         const double z = W.zS[pos];
         W.dl[r] = dk;
@@ -561,14 +616,13 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     if (ttid < k) W.lam[ttid] = W.dl[W.org[ttid]] + W.mu[ttid];
     if (ttid < nd) W.lam[k + ttid] = W.dS[W.dp[ttid]];
     __syncthreads();
+    // (the roots come in ascending order -- each lies on its side of the pole it shares with its
+    // neighbour, in floating point too -- and so do the deflated poles unless a rotation changed them)
     if (ttid < m) {
-        const double v = dc_key(W.lam[ttid]);
-        int r = 0;
-        for (int j = 0; j < m; j++) {
-            const double u = dc_key(W.lam[j]);
-            r += (u < v) || (u == v && j < ttid);
-        }
-        W.outpos[ttid] = r;
+        const double key = dc_key(W.lam[ttid]);
+        W.outpos[ttid] = nr > 0 ? dc_rank_of(W.lam, m, key, ttid)
+                : ttid < k ? ttid + dc_count_before(W.lam + k, nd, key, false)
+                           : (ttid - k) + dc_count_before(W.lam, k, key, true);
     }
     __syncthreads();
     if (ttid < k) {
@@ -1094,6 +1148,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     int cur[MAXB + 1];
     int nc = nblk;
     for (int i = 0; i <= nblk; i++) cur[i] = bounds[i];
+    unsigned srt = 0u;          // bit i: block i of this level came out of a merge (eigenvalues in order)
     // (diagnostic bits 8192 / 16384: stop after the first / second level, so that the phase clocks
     // of dc_merge_level -- the first team's, every level overwrites them -- show THAT level)
     int levels_done = 0;
@@ -1122,6 +1177,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         if (tid == 0) maxnr_s = 0;
         __syncthreads();
         const int q = tm.active ? q0 : 0;
+        tm.sorted_in = ((srt >> (2 * q)) & 3u) == 3u;
         const int a = cur[2 * q], mid = cur[2 * q + 1], b = cur[2 * q + 2];
         double *Fg = F + (size_t) a * n;
         double *Tbuf = Tscratch ? Tscratch + (size_t) a * n : nullptr;
@@ -1145,6 +1201,12 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         nxt[nn++] = cur[0];
         for (int i = 0; i + 1 < nc; i += 2) nxt[nn++] = cur[i + 2];
         if (nc & 1) nxt[nn++] = cur[nc];
+        {
+            unsigned ns = 0u;
+            for (int i = 0; i + 1 < nc; i += 2) ns |= 1u << (i >> 1);
+            if ((nc & 1) && ((srt >> (nc - 1)) & 1u)) ns |= 1u << (nc >> 1);
+            srt = ns;
+        }
         nc = nn - 1;
         for (int i = 0; i <= nc; i++) cur[i] = nxt[i];
         DC_STAMP(19 + (nc == 1 ? 2 : nc == 2 ? 1 : 0));
