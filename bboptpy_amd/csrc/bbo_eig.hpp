@@ -1136,13 +1136,13 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         long long *st_ = (d.stamps && p == 0) ? d.stamps : nullptr;
         if (LDSM || pl.hybrid || TT != EIG_THREADS) {
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
-            eig_dc_phase<TT, false>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
+            eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
                     !LDSM && !(d.dbg & 2) && !(d.dbg & 1024));   // (hybrid: V already in its place)
         } else if (TT == EIG_THREADS && !LDSM) {
             // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
             // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
             // register-resident product cannot hold go through the slab the first of them fills
-            eig_dc_phase<TT, true>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, 1, nullptr, false,
+            eig_dc_phase<TT, true, true>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, 1, nullptr, false,
                     d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld));
         }
     } else

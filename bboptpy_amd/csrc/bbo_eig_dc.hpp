@@ -199,7 +199,7 @@ __device__ inline double dc_quad_sum(double v)
 // Fg (global) is scratch for the eigenvector factor of this merge (m x m).
 // BIG: instantiations for 256 < n <= 512 (two passes over a level's merges, merges the
 // register-resident product cannot hold); the n <= 256 ones compile exactly as before
-template<int LPR, bool do_gemm, bool BIG = false>
+template<int LPR, bool do_gemm, bool BIG = false, bool WIDE = true>
 __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
         double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps,
         int mlevel = 0, double *Tg = nullptr)     // widest merge of this level; m x m global scratch
@@ -723,10 +723,12 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const int fr = lane & 15, fk = lane >> 4;
     const int ntile = (m + 15) >> 4;
     const int ksteps = (m + 3) >> 2;
-    double bfrag[2][DC_KSTEPS];
+    // (WIDE = false, the matrix in LDS, n <= 128: a team always has a wavefront per column tile)
+    constexpr int NT = WIDE ? 2 : 1;
+    double bfrag[NT][DC_KSTEPS];
     if (direct) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NT; u++) {
             const int ct = tm.twave + u * tm.nwaves;
             const int col = ct * 16 + fr;
             const bool cok = on && ct < ntile && col < m;
@@ -751,7 +753,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         }
     } else {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NT; u++) {
         const int ct = tm.twave + u * tm.nwaves;
         const int col = ct * 16 + fr;
 #pragma unroll
@@ -761,6 +763,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         }
     }
     }
+    MG_STAMP(34);
     // every team walks the same number of row tiles (the widest merge of the level).  Q is still
     // BLOCK DIAGONAL here (Q_1 on [a, mid), Q_2 on [mid, b), zeros elsewhere): a row tile inside
     // one block only has its block's columns to contract over -- half the k-steps of the merge
@@ -768,30 +771,51 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const int m1 = mid - a;
     const int rtiles = mlevel > 0 ? min((mlevel + 15) >> 4, (DC_KSTEPS * 4) / 16) : (DC_KSTEPS * 4) / 16;
     for (int rt = 0; rt < rtiles; rt++) {
-        dc_d4 acc[2] = { { 0., 0., 0., 0. }, { 0., 0., 0., 0. } };
+        dc_d4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = dc_d4 { 0., 0., 0., 0. };
         const int arow = rt * 16 + fr;
-        const int klo = 16 * rt >= m1 ? m1 >> 2 : 0;
-        const int khi = 16 * rt + 16 <= m1 ? (m1 + 3) >> 2 : ksteps;
-        if (rt < ntile) {
-            // (a second column tile only when the merge is wider than 16 columns per wavefront
-            // of its team -- uneven splits; for n = 128 every wavefront has exactly one)
-            if (tm.twave + tm.nwaves < ntile) {
+        // (the team's: scalars for the branches below)
+        const int klo = __builtin_amdgcn_readfirstlane(16 * rt >= m1 ? m1 >> 2 : 0);
+        const int khi = __builtin_amdgcn_readfirstlane(16 * rt + 16 <= m1 ? (m1 + 3) >> 2 : ksteps);
+        if (rt < ntile && tm.twave < ntile) {
+            // A batch of k-steps at a time: their 16 x 4 operand pieces are REQUESTED first, from
+            // in-bounds (clamped) addresses, and zeroed by selects where they lie outside the merge;
+            // then the products run back to back.  (With the load of a piece under the test for
+            // its position, each k-step was a branch, a load, a wait and one product: 6.6 k cycles
+            // per row tile where the products need 1 k.)
+            const int rowc = a + min(arow, m - 1);
+            const bool two = WIDE && tm.twave + tm.nwaves < ntile;
+            // (CH k-steps per batch: 16 where the registers allow it, 8 next to two tiles' F fragments)
+            constexpr int CH = WIDE ? 8 : 16;
 #pragma unroll
-                for (int ks = 0; ks < DC_KSTEPS; ks++) {
-                    if (ks >= klo && ks < khi) {
-                        const int kk = 4 * ks + fk;
-                        const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[1][ks], acc[1], 0, 0, 0);
-                    }
-                }
-            } else if (tm.twave < ntile) {
+            for (int h = 0; h < DC_KSTEPS / CH; h++) {
+                if (CH * h < khi && CH * h + CH > klo) {
+                    double av[CH];
 #pragma unroll
-                for (int ks = 0; ks < DC_KSTEPS; ks++) {
-                    if (ks >= klo && ks < khi) {
-                        const int kk = 4 * ks + fk;
-                        const double av = (arow < m && kk < m) ? Q(a + arow, a + kk) : 0.;
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bfrag[0][ks], acc[0], 0, 0, 0);
+                    for (int e = 0; e < CH; e++) av[e] = Q(rowc, a + min(4 * (CH * h + e) + fk, m - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (a second column tile only when the merge is wider than 16 columns per
+                    // wavefront of its team -- uneven splits; for n = 128 every wavefront has one)
+                    if (two) {
+#pragma unroll
+                        for (int e = 0; e < CH; e++) {
+                            const int ks = CH * h + e;
+                            if (ks >= klo && ks < khi) {
+                                const double x = (arow < m && 4 * ks + fk < m) ? av[e] : 0.;
+                                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, bfrag[0][ks], acc[0], 0, 0, 0);
+                                acc[NT - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, bfrag[NT - 1][ks], acc[NT - 1], 0, 0, 0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CH; e++) {
+                            const int ks = CH * h + e;
+                            if (ks >= klo && ks < khi) {
+                                const double x = (arow < m && 4 * ks + fk < m) ? av[e] : 0.;
+                                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, bfrag[0][ks], acc[0], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -799,7 +823,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         __syncthreads();
         if (rt < ntile) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < NT; u++) {
                 const int col = (tm.twave + u * tm.nwaves) * 16 + fr;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -809,6 +833,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             }
         }
     }
+    MG_STAMP(35);
     }   // do_gemm
     __syncthreads();
     if (ttid < m) dv[a + W.outpos[ttid]] = W.lam[ttid];
@@ -1031,7 +1056,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 // (forceinline: called once with Q in LDS and once with Q in global memory from cma_eigen -- as a
 // shared out-of-line function it would see generic pointers and address everything with FLAT
 // instructions)
-template<int TT = 512, bool BIG = false>
+template<int TT = 512, bool BIG = false, bool WIDE = true>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
         const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr)
@@ -1185,15 +1210,15 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         if (ext_top && nc == 2) {
             // the top merge of a matrix wider than 128 (512 threads): scalar part only
             if (2 * m <= tm.tthreads)
-                dc_merge_level<2, false, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+                dc_merge_level<2, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
             else
-                dc_merge_level<1, false, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+                dc_merge_level<1, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         } else if (4 * m <= tm.tthreads)
-            dc_merge_level<4, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+            dc_merge_level<4, true, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         else if (2 * m <= tm.tthreads)
-            dc_merge_level<2, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+            dc_merge_level<2, true, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         else
-            dc_merge_level<1, true, BIG>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+            dc_merge_level<1, true, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         if (BIG) __syncthreads();
         }
         int nxt[MAXB + 1];
