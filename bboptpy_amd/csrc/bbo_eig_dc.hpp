@@ -942,12 +942,12 @@ template<int TT>
 __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
         double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
 {
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int npanel = (n + 15) >> 4;
     constexpr int LDV = 132;
     // (outpos, if any, lives in the work area this stage reuses: n <= 16 then, one entry each)
-    const int ocol = (outpos && tid < n * n) ? outpos[tid % n] : -1;
+    const int outpos_col = (outpos && 16 * wave + fr < n) ? outpos[16 * wave + fr] : -1;
     __syncthreads();      // the merge work area is free; tau and V are visible
     dc_build_T(n, V, tau, Tg, scratch);
     // (T is written and read by THIS workgroup: workgroup scope.  A device-scope fence here
@@ -979,6 +979,24 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
             tpre[ks] = kk <= fr ? Tg[(size_t) b * 256 + kk * 16 + fr] : 0.;
         }
     };
+    // The wavefront's 16-column tile of Q stays in REGISTERS for all panels: lane (fr, fk) holds
+    // Q(16 rt + 4 r + fk, col) in qreg[rt][r] -- the accumulator layout of the update
+    // Q -= V_b W for row tile rt AND the B-operand layout of k-step 4 rt + r of W = V_b^T Q, so the
+    // same registers feed both products and Q is read from LDS once and written to B once.
+    // (Until round 3 every product re-read its pieces of Q from LDS under position tests: a
+    // branch, a load and a wait per k-step, 50 us for the eight panels of n = 128.)
+    dc_d4 qreg[DC_KSTEPS / 4];
+    {
+        const int colc = min(col, n - 1);
+#pragma unroll
+        for (int rt = 0; rt < DC_KSTEPS / 4; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * rt + fk + 4 * r;
+                const double x = Q(min(row, n - 1), colc);
+                qreg[rt][r] = (row < n && col < n) ? x : 0.;
+            }
+    }
     prefetch(0);
     for (int b = 0; b < npanel; b++) {
         const int reach = min(n, 16 * b + 16);
@@ -996,17 +1014,18 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
         __syncthreads();
         if (b + 1 < npanel) prefetch(b + 1);
         if (16 * ctile < n) {
-            // W = V_b^T Q[:, tile]
+            // W = V_b^T Q[:, tile]: A(m = fr, k = 16 rt + 4 r + fk) = reflector fr of the panel at
+            // that row (zero beyond the panel's reach, like the rows of Q beyond n)
             dc_d4 w = { 0., 0., 0., 0. };
 #pragma unroll
-            for (int q = 0; q < DC_KSTEPS / 2; q++) {
-                if (8 * q < reach) {
-                    const int k0 = 8 * q + 2 * fk;
-                    const double2 a2 = *reinterpret_cast<const double2*>(&Vp[fr * LDV + k0]);
-                    const double b0 = (k0 < n && col < n) ? Q(k0, col) : 0.;
-                    const double b1 = (k0 + 1 < n && col < n) ? Q(k0 + 1, col) : 0.;
-                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b0, w, 0, 0, 0);
-                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b1, w, 0, 0, 0);
+            for (int rt = 0; rt < DC_KSTEPS / 4; rt++) {
+                if (16 * rt < reach) {
+                    double a4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) a4[r] = Vp[fr * LDV + 16 * rt + 4 * r + fk];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        w = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[r], qreg[rt][r], w, 0, 0, 0);
                 }
             }
             // W <- T_b^T W: A(m = fr, k = 4 ks + fk) = T(4 ks + fk, fr); B operand of k-step ks =
@@ -1015,33 +1034,33 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
                 w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[ks], w[ks], w2, 0, 0, 0);
-            // Q[:, tile] -= V_b W, 16 rows at a time
+            // Q[:, tile] -= V_b W, 16 rows at a time, in the registers
 #pragma unroll
             for (int rt = 0; rt < DC_KSTEPS / 4; rt++) {
                 if (16 * rt < reach) {
-                    dc_d4 cacc;
+                    double a4[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = 16 * rt + fk + 4 * r;
-                        cacc[r] = (row < n && col < n) ? Q(row, col) : 0.;
-                    }
+                    for (int ks = 0; ks < 4; ks++) a4[ks] = -Vp[(4 * ks + fk) * LDV + 16 * rt + fr];
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++)
-                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                -Vp[(4 * ks + fk) * LDV + 16 * rt + fr], w2[ks], cacc, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = 16 * rt + fk + 4 * r;
-                        if (row < n && col < n) Q(row, col) = cacc[r];
-                    }
+                        qreg[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ks], w2[ks], qreg[rt], 0, 0, 0);
                 }
             }
         }
     }
-    __syncthreads();
-    for (int q = tid; q < n * n; q += T) {
-        const int r = q / n, c = q - r * n;
-        Bout[(size_t) r * ldb + (outpos ? ocol : c)] = Q(r, c);
+    // B straight from the registers (rows of 16 consecutive columns)
+    if (col < n) {
+        const int oc = outpos ? outpos_col : col;
+#pragma unroll
+        for (int rt = 0; rt < DC_KSTEPS / 4; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * rt + fk + 4 * r;
+                if (row < n) {
+                    Bout[(size_t) row * ldb + oc] = qreg[rt][r];
+                    Q(row, col) = qreg[rt][r];      // (the caller packs the sampler's operand from the LDS copy)
+                }
+            }
     }
     __syncthreads();
 }
