@@ -874,8 +874,9 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
 // u_i, zero from column i on), tau[i] = 1 / h_i or 0.  scratch (LDS): 16 x 17 doubles per
 // wavefront.  All threads of the workgroup call it.
 __device__ __forceinline__ void dc_build_T(int n, const double *V, const double *tau, double *Tg,
-        double *scratch)
+        double *scratch, int ldv = 0)      // ldv: row stride of V (0: dense, n)
 {
+    if (ldv == 0) ldv = n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     const int npanel = (n + 15) >> 4;
@@ -884,15 +885,24 @@ __device__ __forceinline__ void dc_build_T(int n, const double *V, const double 
         double *Sb = scratch + (size_t) wave * 16 * LS;
         const int i0 = 16 * b, reach = min(n, i0 + 16);       // rows < reach can be non-zero
         const int refl = i0 + fr;
-        const double *vrow = V + (size_t) min(refl, n - 1) * n;
+        const double *vrow = V + (size_t) min(refl, n - 1) * ldv;
         dc_d4 acc = { 0., 0., 0., 0. };
         for (int r0 = 0; r0 < reach; r0 += 4 * DC_KSTEPS) {
+            // (all requests first, from clamped addresses; zeros by selects: a load under its
+            // position test is a branch, a load and a wait of an L2 round trip -- each)
             double va[DC_KSTEPS];
 #pragma unroll
             for (int q = 0; q < DC_KSTEPS / 2; q++) {
                 const int k0 = r0 + 8 * q + 2 * fk;
-                va[2 * q] = (refl < n && k0 < reach) ? vrow[k0] : 0.;
-                va[2 * q + 1] = (refl < n && k0 + 1 < reach) ? vrow[k0 + 1] : 0.;
+                va[2 * q] = vrow[min(k0, n - 1)];
+                va[2 * q + 1] = vrow[min(k0 + 1, n - 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < DC_KSTEPS / 2; q++) {
+                const int k0 = r0 + 8 * q + 2 * fk;
+                va[2 * q] = (refl < n && k0 < reach) ? va[2 * q] : 0.;
+                va[2 * q + 1] = (refl < n && k0 + 1 < reach) ? va[2 * q + 1] : 0.;
             }
 #pragma unroll
             for (int q = 0; q < DC_KSTEPS / 2; q++) {
@@ -940,7 +950,8 @@ __device__ __forceinline__ void dc_build_T(int n, const double *V, const double 
 // scratch (LDS): 16 * 132 doubles; Tg (global): 16 * 256 doubles.
 template<int TT>
 __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *V, const double *tau,
-        double *Tg, double *scratch, double *Bout, int ldb, const int *outpos)
+        double *Tg, double *scratch, double *Bout, int ldb, const int *outpos,
+        long long *stamps = nullptr, bool t_ready = false)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = lane >> 4;
@@ -949,12 +960,13 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
     // (outpos, if any, lives in the work area this stage reuses: n <= 16 then, one entry each)
     const int outpos_col = (outpos && 16 * wave + fr < n) ? outpos[16 * wave + fr] : -1;
     __syncthreads();      // the merge work area is free; tau and V are visible
-    dc_build_T(n, V, tau, Tg, scratch);
+    if (!t_ready) dc_build_T(n, V, tau, Tg, scratch);
     // (T is written and read by THIS workgroup: workgroup scope.  A device-scope fence here
     // waits for the whole chip's write traffic when 256 workgroups reach it together -- it was
     // 70 us of the 127 this stage took in a 256-population batch, against 55 for one population)
     __threadfence_block();
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[36] = wall_clock64();
     // ---- 2. panels ---------------------------------------------------------------------------------
     double *Vp = scratch;
     const int ctile = wave, col = 16 * ctile + fr;
@@ -963,21 +975,20 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
     constexpr int NPIECE = 512 / TT;
     double pre[NPIECE][4], tpre[4];
     auto prefetch = [&](int b) {
-        const int i0 = 16 * b, reach = min(n, i0 + 16);
+        const int i0 = 16 * b;
 #pragma unroll
         for (int h = 0; h < NPIECE; h++) {
             const int e = tid + h * TT;
             const int pj = e >> 5, pc = (e & 31) * 4;
             const int rf = i0 + pj;
+            const double *vr = V + (size_t) min(rf, n - 1) * n;
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                pre[h][u] = (rf < n && pc + u < reach) ? V[(size_t) rf * n + pc + u] : 0.;
+            for (int u = 0; u < 4; u++) pre[h][u] = vr[min(pc + u, n - 1)];
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int kk = 4 * ks + fk;
-            tpre[ks] = kk <= fr ? Tg[(size_t) b * 256 + kk * 16 + fr] : 0.;
-        }
+        for (int ks = 0; ks < 4; ks++) tpre[ks] = Tg[(size_t) b * 256 + (4 * ks + fk) * 16 + fr];
+        // (raw values: what lies outside the panel is zeroed where the panel is staged, so that
+        // nothing waits for these loads before the products of the panel in hand)
     };
     // The wavefront's 16-column tile of Q stays in REGISTERS for all panels: lane (fr, fk) holds
     // Q(16 rt + 4 r + fk, col) in qreg[rt][r] -- the accumulator layout of the update
@@ -1005,17 +1016,20 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
         for (int h = 0; h < NPIECE; h++) {
             const int e = tid + h * TT;
             const int pj = e >> 5, pc = (e & 31) * 4;
+            const bool rok = 16 * b + pj < n;
 #pragma unroll
-            for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = pre[h][u];
+            for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = (rok && pc + u < reach) ? pre[h][u] : 0.;
         }
         double tv[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) tv[ks] = tpre[ks];
+        for (int ks = 0; ks < 4; ks++) tv[ks] = 4 * ks + fk <= fr ? tpre[ks] : 0.;
         __syncthreads();
         if (b + 1 < npanel) prefetch(b + 1);
         if (16 * ctile < n) {
             // W = V_b^T Q[:, tile]: A(m = fr, k = 16 rt + 4 r + fk) = reflector fr of the panel at
-            // that row (zero beyond the panel's reach, like the rows of Q beyond n)
+            // that row (zero beyond the panel's reach, like the rows of Q beyond n).
+            // (Requesting the operand pieces of all eight row groups of both products up front --
+            // 128 more registers -- was slower: 37 us for the panels against 27.)
             dc_d4 w = { 0., 0., 0., 0. };
 #pragma unroll
             for (int rt = 0; rt < DC_KSTEPS / 4; rt++) {
@@ -1048,6 +1062,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
             }
         }
     }
+    if (stamps && threadIdx.x == 0) stamps[37] = wall_clock64();
     // B straight from the registers (rows of 16 consecutive columns)
     if (col < n) {
         const int oc = outpos ? outpos_col : col;
@@ -1105,6 +1120,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     double *taug = G + (size_t) 2 * n * n;
     if (hv)
         for (int i = tid; i < n; i += T) taug[i] = hv[i] != 0. ? 1. / hv[i] : 0.;
+    // The T factors of the reflector panels (dc_apply_reflectors) while the reflectors still sit
+    // in the LDS matrix: built at the end, from their global copy, the Gram products waited for L2
+    // round trips (11 us of the stage at n = 128).  The work area is free here; hv lives in it and
+    // has just been read.
+    const bool t_early = hv && !ext_top && !qh_ready;
+    if (t_early) {
+        __threadfence_block();
+        __syncthreads();
+        dc_build_T(n, Q.a, taug, taug + n, scratch, Q.ld);
+        __syncthreads();
+    }
     DcWork W;
     {
         double *p = scratch;
@@ -1289,7 +1315,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     }
     if (hv) {
         dc_apply_reflectors<TT>(Q, n, Qh, taug, taug + n, scratch, Bout, ldb,
-                single ? W.outpos : nullptr);
+                single ? W.outpos : nullptr, stamps, t_early);
         DC_STAMP(23);
         return;
     }

@@ -29,9 +29,9 @@ for rep in range(3):
              18: "leaves done", 19: "merge level(s) <top-1", 20: "merge level top-1",
              21: "merge top", 22: "merges done", 23: "reflectors/B done", 24: "mg start",
              25: "mg deflate", 26: "mg 26", 27: "mg secular", 28: "mg 28", 29: "mg 29",
-             30: "mg end", 32: "mg sec prologue", 33: "mg sec loop (wave 0)", 34: "mg F fragments", 35: "mg product (wave 0)"}
+             30: "mg end", 32: "mg sec prologue", 33: "mg sec loop (wave 0)", 34: "mg F fragments", 35: "mg product (wave 0)", 36: "refl T factors", 37: "refl panels"}
     t0 = min(v for v in st[:32] if v > 0)
-    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i < 36 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
+    rows = sorted((v, i) for i, v in enumerate(st) if v > 0 and i < 38 and i not in (8, 9, 10, 12, 13, 14, 15, 31))
     print("rep %d" % rep)
     prev = t0
     for v, i in rows:
