@@ -135,14 +135,31 @@ template<int AMAX>
 __device__ inline void tred_rank2(double (&a_)[4][8], const double (&ur)[4][8], const double *wv,
         double uj, double wj, int q)
 {
+    // The pieces of w for two 32-column groups are requested together (eight 16-byte reads in
+    // flight): short of registers here, the scheduler otherwise asks for two or four pieces at a
+    // time and waits for each lot -- six LDS round trips on the serial path of a step.
 #pragma unroll
-    for (int a = 0; a < AMAX; a++)
+    for (int a0 = 0; a0 < AMAX; a0 += 2) {
+        double2 w2[2][4];
 #pragma unroll
-        for (int b = 0; b < 8; b += 2) {
-            const double2 w2 = *reinterpret_cast<const double2*>(&wv[32 * a + 8 * q + b]);
-            a_[a][b] = __builtin_fma(-ur[a][b], wj, __builtin_fma(-w2.x, uj, a_[a][b]));
-            a_[a][b + 1] = __builtin_fma(-ur[a][b + 1], wj, __builtin_fma(-w2.y, uj, a_[a][b + 1]));
-        }
+        for (int da = 0; da < 2; da++)
+#pragma unroll
+            for (int b = 0; b < 8; b += 2)
+                if (a0 + da < AMAX)
+                    w2[da][b >> 1] = *reinterpret_cast<const double2*>(&wv[32 * (a0 + da) + 8 * q + b]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int da = 0; da < 2; da++)
+#pragma unroll
+            for (int b = 0; b < 8; b += 2)
+                if (a0 + da < AMAX) {
+                    const int a = a0 + da;
+                    a_[a][b] = __builtin_fma(-ur[a][b], wj, __builtin_fma(-w2[da][b >> 1].x, uj, a_[a][b]));
+                    a_[a][b + 1] = __builtin_fma(-ur[a][b + 1], wj,
+                            __builtin_fma(-w2[da][b >> 1].y, uj, a_[a][b + 1]));
+                }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template<int AMAX>
@@ -221,10 +238,11 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
             return;
         }
         __syncthreads();
-        const double d0 = lane < i ? dv[lane] : 0.;
-        const double d1 = lane + 64 < i ? dv[lane + 64] : 0.;
-        const double h0 = eig_wave_sum(d0 * d0 + d1 * d1);
-        const double f = dv[i - 1];
+        // (three reads, one wait: a read under its position test is a branch and a wait of its own)
+        const double dl0 = dv[lane], dl1 = dv[lane + 64], f = dv[i - 1];
+        const double d0 = lane < i ? dl0 : 0.;
+        const double d1 = lane + 64 < i ? dl1 : 0.;
+        const double h0 = eig_wave_sum_bf(d0 * d0 + d1 * d1);
         if (h0 == 0.) {
             __syncthreads();
             if (tid == 0) {
@@ -263,21 +281,22 @@ __device__ inline void eig_tred_accum_reg128(const double *C, int ld, int n, con
         double ur[4][8];
         {
             const double acc = tred_matvec<AMAX>(a_, ur, uv, q);
-            if (q == 0 && j < i) {
-                gv[j] = acc;
-                As(i, j) = uv[j];          // stash: row i = the Householder vector of step i
-            }
+            if (q == 0 && j < i) gv[j] = acc;
         }
         __syncthreads();
-        const double e0 = lane < i ? gv[lane] * rh : 0.;
-        const double e1 = lane + 64 < i ? gv[lane + 64] * rh : 0.;
+        const double gl0 = gv[lane], gl1 = gv[lane + 64];
         const double uu0 = uv[lane], uu1 = uv[lane + 64];
-        const double hh = eig_wave_sum(e0 * uu0 + e1 * uu1) * (0.5 * rh);
+        const double e0 = lane < i ? gl0 * rh : 0.;
+        const double e1 = lane + 64 < i ? gl1 * rh : 0.;
+        const double hh = eig_wave_sum_bf(e0 * uu0 + e1 * uu1) * (0.5 * rh);
         wv[lane] = lane < i ? e0 - hh * uu0 : 0.;
         wv[lane + 64] = lane + 64 < i ? e1 - hh * uu1 : 0.;
         // A -= u w^T + w u^T; rows >= i and columns >= i see zeros and do not move
         {
             const double uj = uv[j], wj = wv[j];
+            // stash: row i = the Householder vector of step i (here, with the read of u_j the
+            // update needs anyway, not as a round trip of its own before the barrier)
+            if (q == 0 && j < i) As(i, j) = uj;
             tred_rank2<AMAX>(a_, ur, wv, uj, wj, q);
             if (j == i - 1) {
 #pragma unroll
@@ -771,7 +790,7 @@ __device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C,
             dk[m] = lane + 64 * m < i ? t : 0.;
             hs = __builtin_fma(dk[m], dk[m], hs);
         }
-        const double h0 = eig_wave_sum(hs);
+        const double h0 = eig_wave_sum_bf(hs);
         const double f = dv[i - 1];
         const double tdi = dv[i];
         // h0 == 0 (the row is already reduced): u = 0, w = 0 -- the step then changes nothing and
@@ -923,7 +942,7 @@ __device__ __attribute__((noinline)) void eig_tred_sym256_steps(const double *C,
                 ek[m] = gk * rh;
                 fs = __builtin_fma(ek[m], uk[m], fs);
             }
-            const double hh = eig_wave_sum(fs) * (0.5 * rh);
+            const double hh = eig_wave_sum_bf(fs) * (0.5 * rh);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int k = lane + 64 * m;

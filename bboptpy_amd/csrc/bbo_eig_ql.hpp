@@ -57,6 +57,32 @@ __device__ inline double eig_wave_sum(double v)
             + eig_readlane(v, 48);
 }
 
+// The same sum as a butterfly that ends with the total in every lane: two half-exchanges
+// (v_permlane32_swap / v_permlane16_swap of a value with its own copy: each lane then holds its
+// own and its partner's), then the four rotations inside a 16-lane row.  Six dependent steps and
+// no detour through scalar registers (eig_wave_sum: four rotations, four readlanes, three adds);
+// another order of additions, so another rounding -- but the same in every lane and wavefront.
+__device__ inline double eig_wave_sum_bf(double v)
+{
+    {
+        unsigned alo = __double2loint(v), ahi = __double2hiint(v);
+        auto r0 = __builtin_amdgcn_permlane32_swap(alo, alo, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(ahi, ahi, false, false);
+        v = __hiloint2double((int) r1[0], (int) r0[0]) + __hiloint2double((int) r1[1], (int) r0[1]);
+    }
+    {
+        unsigned alo = __double2loint(v), ahi = __double2hiint(v);
+        auto r0 = __builtin_amdgcn_permlane16_swap(alo, alo, false, false);
+        auto r1 = __builtin_amdgcn_permlane16_swap(ahi, ahi, false, false);
+        v = __hiloint2double((int) r1[0], (int) r0[0]) + __hiloint2double((int) r1[1], (int) r0[1]);
+    }
+    v += eig_dpp<0x128>(v);   // row_ror:8
+    v += eig_dpp<0x124>(v);   // row_ror:4
+    v += eig_dpp<0x122>(v);   // row_ror:2
+    v += eig_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+
 // Lanes of one wavefront talk through LDS here (lane 0 walks the recurrence, the others shift
 // the diagonal and search for the split).  The hardware keeps a wavefront's LDS operations in
 // order, but the COMPILER reasons per thread: on the path that skips the `if (lane == 0)` block
