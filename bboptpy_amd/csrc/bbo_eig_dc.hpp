@@ -1158,19 +1158,23 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         int ex = 0;
         if (am > 0.) frexp(am, &ex);
         scale_s = am > 0. ? ldexp(1., 1 - ex) : 1.;
-        // bounds: halve until every block has <= DC_LEAF rows
+        // bounds: halve until every block has <= leaf_rows rows.  With the matrix in LDS
+        // (16 < n <= 128) the leaves are 8 x 8: a QL leaf is a serial chain of ~2 (s^2 / 2)
+        // rotations, the extra level of merges -- 16-pole merges, one wavefront each -- costs a
+        // third of what the smaller leaves save (round 3, once the merges had become cheap)
+        const int leaf_rows = (!ext_top && n > 16 && n <= 128 && !(dbg & 32768)) ? 8 : DC_LEAF;
         int nb = 1;
         bounds[0] = 0;
         bounds[1] = n;
         while (true) {
             int widest = 0;
             for (int i = 0; i < nb; i++) widest = max(widest, bounds[i + 1] - bounds[i]);
-            if (widest <= DC_LEAF) break;
+            if (widest <= leaf_rows) break;
             int tmp[MAXB + 1];
             int c2 = 0;
             tmp[c2++] = bounds[0];
             for (int i = 0; i < nb; i++) {
-                if (bounds[i + 1] - bounds[i] > DC_LEAF) tmp[c2++] = (bounds[i] + bounds[i + 1]) / 2;
+                if (bounds[i + 1] - bounds[i] > leaf_rows) tmp[c2++] = (bounds[i] + bounds[i + 1]) / 2;
                 tmp[c2++] = bounds[i + 1];
             }
             nb = c2 - 1;
@@ -1215,14 +1219,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
 
     DC_STAMP(18);
     // ---- merges, bottom-up; all merges of a level run at once, each by its own team --------
-    int cur[MAXB + 1];
+    // Block i of level L is the run of leaves [i 2^L, min((i + 1) 2^L, nblk)): merges pair
+    // neighbours and an odd block at the end is carried, so the edges of every level are entries
+    // of `bounds` -- read where they are needed.  (Kept in per-thread arrays indexed at run time,
+    // the edges lived in scratch memory: 5 us of bookkeeping per level.)
+    auto edge = [&](int i, int L) { return bounds[min(i << L, nblk)]; };
     int nc = nblk;
-    for (int i = 0; i <= nblk; i++) cur[i] = bounds[i];
-    unsigned srt = 0u;          // bit i: block i of this level came out of a merge (eigenvalues in order)
     // (diagnostic bits 8192 / 16384: stop after the first / second level, so that the phase clocks
     // of dc_merge_level -- the first team's, every level overwrites them -- show THAT level)
     int levels_done = 0;
     while (nc > 1 && !(dbg & 4) && !((dbg & 8192) && levels_done >= 1) && !((dbg & 16384) && levels_done >= 2)) {
+        const int L = levels_done;
         levels_done++;
         const int nm = nc >> 1;                       // merges at this level
         int teams = 1;
@@ -1231,7 +1238,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         // lanes per secular root: as many as every team of this level can give its poles
         // (chosen from the WIDEST merge so that all teams run the same code path)
         int m = 0;
-        for (int i = 0; i < nm; i++) m = max(m, cur[2 * i + 2] - cur[2 * i]);
+        for (int i = 0; i < nm; i++) m = max(m, edge(2 * i + 2, L) - edge(2 * i, L));
         // a level has at most NW teams at a time: 16 merges (32 leaves, n > 256) take two passes
         const int tcount = min(teams, NW);
         for (int pass = 0; pass * tcount < nm && (BIG || pass == 0); pass++) {
@@ -1247,8 +1254,9 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         if (tid == 0) maxnr_s = 0;
         __syncthreads();
         const int q = tm.active ? q0 : 0;
-        tm.sorted_in = ((srt >> (2 * q)) & 3u) == 3u;
-        const int a = cur[2 * q], mid = cur[2 * q + 1], b = cur[2 * q + 2];
+        // (a block that came out of a merge -- two leaves or more -- has its eigenvalues in order)
+        tm.sorted_in = L >= 1 && min((2 * q + 2) << L, nblk) - ((2 * q + 1) << L) >= 2;
+        const int a = edge(2 * q, L), mid = edge(2 * q + 1, L), b = edge(2 * q + 2, L);
         double *Fg = F + (size_t) a * n;
         double *Tbuf = Tscratch ? Tscratch + (size_t) a * n : nullptr;
         const double rho = ev[mid - 1];
@@ -1266,19 +1274,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
             dc_merge_level<1, true, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         if (BIG) __syncthreads();
         }
-        int nxt[MAXB + 1];
-        int nn = 0;
-        nxt[nn++] = cur[0];
-        for (int i = 0; i + 1 < nc; i += 2) nxt[nn++] = cur[i + 2];
-        if (nc & 1) nxt[nn++] = cur[nc];
-        {
-            unsigned ns = 0u;
-            for (int i = 0; i + 1 < nc; i += 2) ns |= 1u << (i >> 1);
-            if ((nc & 1) && ((srt >> (nc - 1)) & 1u)) ns |= 1u << (nc >> 1);
-            srt = ns;
-        }
-        nc = nn - 1;
-        for (int i = 0; i <= nc; i++) cur[i] = nxt[i];
+        nc = (nc + 1) >> 1;
         DC_STAMP(19 + (nc == 1 ? 2 : nc == 2 ? 1 : 0));
     }
     __syncthreads();
