@@ -1110,10 +1110,8 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     // (qh_ready: the reduction has left V in Qh itself -- at n = 256 this copy, 512 KB global to
     // global by one workgroup, took 54 us)
     if (!qh_ready)
-    for (int q = tid; q < n * n; q += T) {
-        const int r = q / n, c = q - r * n;
-        Qh[q] = Q(r, c);
-    }
+    for (int r = wave; r < n; r += NW)
+        for (int c = lane; c < n; c += 64) Qh[(size_t) r * n + c] = Q(r, c);
     // hv != null: Q holds the STASHED REFLECTORS of the Householder stage (row i = u_i, zero from
     // column i on; H(i) = I - u_i u_i^T / hv[i]), not the accumulated Q_house: Qh is V then, and
     // the scalars 1 / h move out of the way of the work area (hv lives inside `scratch`)
@@ -1158,30 +1156,20 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         int ex = 0;
         if (am > 0.) frexp(am, &ex);
         scale_s = am > 0. ? ldexp(1., 1 - ex) : 1.;
-        // bounds: halve until every block has <= leaf_rows rows.  With the matrix in LDS
+        // blocks of <= leaf_rows rows.  With the matrix in LDS
         // (16 < n <= 128) the leaves are 8 x 8: a QL leaf is a serial chain of ~2 (s^2 / 2)
         // rotations, the extra level of merges -- 16-pole merges, one wavefront each -- costs a
         // third of what the smaller leaves save (round 3, once the merges had become cheap)
         const int leaf_rows = (!ext_top && n > 16 && n <= 128 && !(dbg & 32768)) ? 8 : DC_LEAF;
+        // (a power-of-two number of blocks whose sizes differ by at most one, edges floor(i n / nb):
+        // every level pairs all of its blocks.  Until round 3 thread 0 halved the blocks one level
+        // at a time through a per-thread array -- scratch memory: most of the 15 us this set-up took)
         int nb = 1;
-        bounds[0] = 0;
-        bounds[1] = n;
-        while (true) {
-            int widest = 0;
-            for (int i = 0; i < nb; i++) widest = max(widest, bounds[i + 1] - bounds[i]);
-            if (widest <= leaf_rows) break;
-            int tmp[MAXB + 1];
-            int c2 = 0;
-            tmp[c2++] = bounds[0];
-            for (int i = 0; i < nb; i++) {
-                if (bounds[i + 1] - bounds[i] > leaf_rows) tmp[c2++] = (bounds[i] + bounds[i + 1]) / 2;
-                tmp[c2++] = bounds[i + 1];
-            }
-            nb = c2 - 1;
-            for (int i = 0; i <= nb; i++) bounds[i] = tmp[i];
-        }
+        while ((n + nb - 1) / nb > leaf_rows && nb < MAXB) nb <<= 1;
         nblk_s = nb;
     }
+    __syncthreads();
+    if (tid <= nblk_s) bounds[tid] = (int) (((long long) tid * n) / nblk_s);
     __syncthreads();
     const double scale = scale_s;
     const int nblk = nblk_s;
