@@ -567,6 +567,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         if (act && sub == 0) {
             W.mu[j] = mu;
             W.org[j] = o;
+            W.lam[j] = dorg;       // (the origin pole itself, for the Loewner products below)
         }
         if (on && k == 1 && ttid == 0) {
             W.mu[0] = rho * W.w2[0];
@@ -581,12 +582,33 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         const int i = ttid / LPR, sub = ttid % LPR;
         double prod = 1.;
         if (on && k > 1 && i < k) {
+            // lam_jj - d_i = (d_org - d_i) + mu, paired with a denominator d_jj - d_i.  Four roots at
+            // a time, their three values each requested together (the origin poles were left in
+            // W.lam by the secular stage: no index chain), four partial products; the trip count
+            // is the wavefront's.  (A plain loop over jj was a chain of four dependent LDS reads
+            // and one product per root.)
             const double di2 = W.dl[i];
-            for (int jj = sub; jj < k; jj += LPR) {
-                // lam_jj - d_i = (d_org - d_i) + mu, paired with a denominator d_jj - d_i
-                const double num = (W.dl[W.org[jj]] - di2) + W.mu[jj];
-                prod *= jj == i ? num : num * dc_rcp(W.dl[jj] - di2);
+            const int npl_l = __builtin_amdgcn_readfirstlane((k + LPR - 1) / LPR);
+            double p4[4] = { 1., 1., 1., 1. };
+            for (int t0 = 0; t0 < npl_l; t0 += 4) {
+                double lo_[4], mu_[4], dj_[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jc = min(sub + (t0 + u) * LPR, k - 1);
+                    lo_[u] = W.lam[jc];
+                    mu_[u] = W.mu[jc];
+                    dj_[u] = W.dl[jc];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jj = sub + (t0 + u) * LPR;
+                    const double num = (lo_[u] - di2) + mu_[u];
+                    const double f = num * dc_rcp(jj == i ? 1. : dj_[u] - di2);
+                    p4[u] *= jj < k ? f : 1.;
+                }
             }
+            prod = (p4[0] * p4[1]) * (p4[2] * p4[3]);
         }
         if (LPR >= 2) prod *= eig_quad_xor1(prod);
         if (LPR >= 4) prod *= eig_quad_xor2(prod);
@@ -601,11 +623,26 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         __syncthreads();
         const int j = i;
         double ss = 0.;
-        if (on && k > 1 && j < k)
-            for (int ii = sub; ii < k; ii += LPR) {
-                const double s = W.what[ii] * dc_rcp((W.dl[ii] - W.dl[W.org[j]]) - W.mu[j]);
-                ss += s * s;
+        if (on && k > 1 && j < k) {
+            const double dorgj = W.lam[j], muj = W.mu[j];
+            const int npl_l = __builtin_amdgcn_readfirstlane((k + LPR - 1) / LPR);
+            for (int t0 = 0; t0 < npl_l; t0 += 4) {
+                double wh[4], dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ic = min(sub + (t0 + u) * LPR, k - 1);
+                    wh[u] = W.what[ic];
+                    dd[u] = W.dl[ic];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ii = sub + (t0 + u) * LPR;
+                    const double s = wh[u] * dc_rcp((dd[u] - dorgj) - muj);
+                    ss += ii < k ? s * s : 0.;
+                }
             }
+        }
         ss = dc_quad_sum<LPR>(ss);
         if (on && k > 1 && j < k && sub == 0) W.ninv[j] = 1. / sqrt(ss);
     }
