@@ -679,19 +679,45 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const bool generic_prod = BIG && do_gemm && (mlevel > 4 * DC_KSTEPS || ((mlevel + 15) >> 4) > 2 * tm.nwaves);
     const bool direct = FRAG_OK && maxnr == 0 && !generic_prod;
     if (!direct) {
-    // F (rows in ORIGINAL column order), written in one pass
-    for (int q = ttid; q < m * m; q += TT) {
-        const int r = q / m, cidx = q - r * m;
-        const int i = W.rowmap[r], j = W.colroot[cidx];
-        double v = 0.;
-        if (i >= 0) {
-            if (j >= 0)
-                v = k == 1 ? 1.
-                           : W.what[i] * dc_rcp((W.dl[i] - W.dl[W.org[j]]) - W.mu[j]) * W.ninv[j];
-        } else if (-(1 + i) == cidx) {
-            v = 1.;
+    // F (rows in ORIGINAL column order), written in one pass.  A thread keeps ONE column (its
+    // root's origin pole, offset and norm in registers) and walks down the rows, four at a time
+    // (the row map and the poles are broadcast reads, the stores of a wavefront are consecutive).
+    // (Element by element -- an integer division and a chain of five dependent LDS reads each --
+    // this pass took 44 us of the n = 256 top merge.)
+    if (m > 0) {
+        const int ncg = TT >= m ? TT / m : 1;              // row groups of the team
+        for (int c0 = 0; c0 < m; c0 += TT) {
+            const int cidx = c0 + (TT >= m ? ttid % m : ttid);
+            const int rg = TT >= m ? ttid / m : 0;
+            if (cidx < m && rg < ncg) {
+                const int j = W.colroot[cidx];
+                const double dorgj = j >= 0 ? W.dl[W.org[j]] : 0.;
+                const double muj = j >= 0 ? W.mu[j] : 0.;
+                const double nj = j >= 0 ? W.ninv[j] : 0.;
+                for (int r0 = rg; r0 < m; r0 += 4 * ncg) {
+                    int iv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) iv[u] = W.rowmap[min(r0 + u * ncg, m - 1)];
+                    __builtin_amdgcn_sched_barrier(0);
+                    double wh[4], dd[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int ic = iv[u] >= 0 ? iv[u] : 0;
+                        wh[u] = W.what[ic];
+                        dd[u] = W.dl[ic];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int r = r0 + u * ncg;
+                        const int i = iv[u];
+                        const double root = k == 1 ? 1. : wh[u] * dc_rcp((dd[u] - dorgj) - muj) * nj;
+                        const double v = i >= 0 ? (j >= 0 ? root : 0.) : (-(1 + i) == cidx ? 1. : 0.);
+                        if (r < m) Fg[(size_t) r * m + cidx] = v;
+                    }
+                }
+            }
         }
-        Fg[q] = v;
     }
     __syncthreads();
     // deflation rotations, in reverse: Q G with G = [[c, -s], [s, c]] on sorted columns (p, j)
