@@ -579,6 +579,8 @@ void CmaEngine::launch_eigen()
     if (c.variant == 2) return;        // diagonal covariance: d = sqrt(c) is part of sep_paths
     const EigPlan pl = eig_plan(c.n, c.ld);
     allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
+    allow_lds((const void*) cma_eigen_g, 160 * 1024 - 768);
+    allow_lds((const void*) cma_eigen_b, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_256, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_128, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
@@ -593,8 +595,14 @@ void CmaEngine::launch_eigen()
     else if (pl.threads == 256)
         hipLaunchKernelGGL(cma_eigen_256, dim3(c.npop), dim3(256), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
-    else
+    else if (pl.use_lds)
         hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
+                pl, 0);
+    else if (pl.hybrid)
+        hipLaunchKernelGGL(cma_eigen_g, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
+                pl, 0);
+    else
+        hipLaunchKernelGGL(cma_eigen_b, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());

@@ -1075,7 +1075,8 @@ __device__ inline void eig_tred_sym256(const double *C, int ld, int n, const Eig
 // `pl.use_lds ? LDS : global` the pointer is generic and every access to A -- each rotation of a QL
 // leaf, the fragment reads of the merge products -- became a FLAT load or store, waited for with
 // vmcnt(0) & lgkmcnt(0) in the middle of the recurrences (round 3: read in the ISA).
-template<int TT, bool LDSM>
+// HYB (matrix in global memory only): 1 = 128 < n <= 256, 0 = 256 < n <= 512 -- a kernel each
+template<int TT, bool LDSM, int HYB = 1>
 __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
         int force)
 {
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
                 (d.stamps && p == 0) ? d.stamps : nullptr, A.a, A.ld, true,
                 !(pl.dc && !(d.dbg & 2)));
     } else if (TT == EIG_THREADS && !LDSM) {
-        const bool hybrid = pl.hybrid != 0;  // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
+        const bool hybrid = HYB != 0;        // 128 < n <= 256: LDS holds a 128 x 128 stash matrix
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), 128 };
         // (with the D&C stage the reflectors stay stashed: cma_eig_wy applies them in blocked form)
         // (diagnostic bit 1024: round 2's form of the first n - 128 steps, streaming from L2)
@@ -1153,7 +1154,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         double *Gp = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
         double *Bp_ = d.B + (size_t) p * ld * ld;
         long long *st_ = (d.stamps && p == 0) ? d.stamps : nullptr;
-        if (LDSM || pl.hybrid || TT != EIG_THREADS) {
+        if (LDSM || HYB || TT != EIG_THREADS) {
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
             eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
                     !LDSM && !(d.dbg & 2) && !(d.dbg & 1024));   // (hybrid: V already in its place)
@@ -1274,10 +1275,19 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
 
 // The kernels proper: four lanes per matrix row, so the workgroup shrinks with n and several small
 // matrices share a CU (the 512-thread form owns a CU's whole register file).
+// (two kernels for the 512-thread form -- matrix in LDS, n <= 128, and matrix in global memory --
+// so that each gets a register allocation of its own)
 __global__ __launch_bounds__(512) void cma_eigen(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
-    if (pl.use_lds) cma_eigen_impl<512, true>(d, c, pl, force);
-    else cma_eigen_impl<512, false>(d, c, pl, force);
+    cma_eigen_impl<512, true>(d, c, pl, force);
+}
+__global__ __launch_bounds__(512) void cma_eigen_g(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, false, 1>(d, c, pl, force);
+}
+__global__ __launch_bounds__(512) void cma_eigen_b(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, false, 0>(d, c, pl, force);
 }
 __global__ __launch_bounds__(256, 2) void cma_eigen_256(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
