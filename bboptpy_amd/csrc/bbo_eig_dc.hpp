@@ -1033,6 +1033,12 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
     // ---- 2. panels ---------------------------------------------------------------------------------
     double *Vp = scratch;
     const int ctile = wave, col = 16 * ctile + fr;
+    // Reflector j of a panel is staged in LDS row vrow(j) = 4 (j & 3) + (j >> 2): the update's
+    // operand A(row, k = 4 ks + fk) = V[4 ks + fk][row] then comes from LDS row 4 fk + ks, and the
+    // four fk groups of a wavefront's read start 32 banks apart instead of 8 -- two passes per
+    // read, the minimum for 64 x 8 bytes, instead of four; W = V^T Q reads row vrow(fr), the same
+    // set of rows as before.
+    auto vrow = [](int j) { return 4 * (j & 3) + (j >> 2); };
     // this thread's pieces of a staged panel (16 reflectors x 32 pieces of 4 columns: one piece
     // per thread of a 512-thread workgroup, two / four of a 256- / 128-thread one)
     constexpr int NPIECE = 512 / TT;
@@ -1081,7 +1087,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
             const int pj = e >> 5, pc = (e & 31) * 4;
             const bool rok = 16 * b + pj < n;
 #pragma unroll
-            for (int u = 0; u < 4; u++) Vp[pj * LDV + pc + u] = (rok && pc + u < reach) ? pre[h][u] : 0.;
+            for (int u = 0; u < 4; u++) Vp[vrow(pj) * LDV + pc + u] = (rok && pc + u < reach) ? pre[h][u] : 0.;
         }
         double tv[4];
 #pragma unroll
@@ -1099,7 +1105,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
                 if (16 * rt < reach) {
                     double a4[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) a4[r] = Vp[fr * LDV + 16 * rt + 4 * r + fk];
+                    for (int r = 0; r < 4; r++) a4[r] = Vp[vrow(fr) * LDV + 16 * rt + 4 * r + fk];
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         w = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[r], qreg[rt][r], w, 0, 0, 0);
@@ -1117,7 +1123,7 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
                 if (16 * rt < reach) {
                     double a4[4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++) a4[ks] = -Vp[(4 * ks + fk) * LDV + 16 * rt + fr];
+                    for (int ks = 0; ks < 4; ks++) a4[ks] = -Vp[(4 * fk + ks) * LDV + 16 * rt + fr];   // = vrow(4 ks + fk)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++)
                         qreg[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[ks], w2[ks], qreg[rt], 0, 0, 0);
