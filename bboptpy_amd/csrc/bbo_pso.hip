@@ -48,6 +48,8 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     c.n = n;
     c.ld = round_up(n, 2);
     c.np = params_.np;
+    c.ldc = round_up(n, 16);
+    c.npad = round_up(params_.np, 128);
     c.correct = params_.correct ? 1 : 0;
     c.obj = obj.on_device() ? obj.builtin : OBJ_HOST;
     c.mfev = params_.mfev;
@@ -66,6 +68,7 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     ws_.alloc(rows);
     mean_.alloc(P * ld);
     nrm_.alloc(rows);
+    Xc_.alloc((size_t) P * c.npad * c.ldc);     // zeroed: the padding is never written
     pvec_.alloc(P * ld);
     radius_.alloc(rows);
     colpart_.alloc((size_t) P * parts_ * ld);
@@ -97,7 +100,7 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     PsoDev &d = d_;
     d = PsoDev {};
     d.X = X_.p; d.V = V_.p; d.XB = XB_.p; d.f = f_.p; d.fb = fb_.p; d.xbest = xbest_.p;
-    d.ws = ws_.p; d.mean = mean_.p; d.nrm = nrm_.p; d.pvec = pvec_.p; d.radius = radius_.p;
+    d.ws = ws_.p; d.mean = mean_.p; d.nrm = nrm_.p; d.Xc = Xc_.p; d.pvec = pvec_.p; d.radius = radius_.p;
     d.colpart = colpart_.p; d.colpart2 = colpart2_.p; d.rowpart2 = rowpart2_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.scal = scal_.p;
     c.honor_stop = 0;
@@ -171,7 +174,7 @@ void PsoEngine::generation(bool honor_stop)
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_ESE);
     {
-        const size_t lds = (size_t) (4 * ESE2_TILE + 256) * sizeof(double);
+        const size_t lds = (size_t) ESE2_LDS_DOUBLES * sizeof(double);
         allow_lds((const void*) pso_ese_sym, (int) lds);
         hipLaunchKernelGGL(pso_ese_sym, dim3((c.np + 127) / 128, P), dim3(256), lds, stream_, d_,
                 c_);

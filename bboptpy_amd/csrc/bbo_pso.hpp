@@ -32,6 +32,7 @@ struct PsoScal {
 
 struct PsoConst {
     int n, ld, np, correct, obj, mfev, honor_stop, npop;
+    int ldc, npad;           // Xc: row stride (n rounded up to 16), rows per population (np to 128)
     double tol;
     uint64_t seed;
 };
@@ -43,6 +44,7 @@ struct PsoDev {
     double *ws;              // [P][np] mean distance to the others
     double *mean;            // [P][ld] swarm centroid
     double *nrm;             // [P][np] squared norm of the centred particle
+    double *Xc;              // [P][npad][ldc] centred swarm, zero padded (operands of pso_ese_sym)
     double *pvec;            // [P][ld] elitist candidate
     double *radius;          // [P][np]
     double *colpart;         // [P][parts][ld] centroid partial sums
@@ -81,7 +83,7 @@ private:
     bool inited_ = false;
     int parts_ = 1;
     std::vector<double> aux_h_;
-    DevBuf<double> colpart2_, rowpart2_;
+    DevBuf<double> colpart2_, rowpart2_, Xc_;
     DevBuf<double> X_, V_, XB_, f_, fb_, xbest_, ws_, mean_, nrm_, pvec_, radius_, colpart_,
             lower_, upper_, aux_;
     DevBuf<PsoScal> scal_;

@@ -204,11 +204,17 @@ __global__ __launch_bounds__(256) void pso_nrm(PsoDev d, PsoConst c)
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
     const int i = blockIdx.x * 16 + r;
     double s = 0.;
-    if (i < c.np)
+    if (i < c.np) {
+        // the centred particle also goes to Xc (row stride ldc, a multiple of 16; rows up to the
+        // next multiple of 128 and columns n..ldc-1 stay zero from the allocation): pso_ese_sym
+        // then stages its operands without arithmetic, clamps or masks
+        double *xc = d.Xc + ((size_t) p * c.npad + i) * c.ldc;
         for (int j = g; j < c.n; j += 16) {
             const double v = d.X[((size_t) p * c.np + i) * c.ld + j] - d.mean[(size_t) p * c.ld + j];
+            xc[j] = v;
             s += v * v;
         }
+    }
     s = pso_group_sum<16>(s);
     if (g == 0 && i < c.np) d.nrm[(size_t) p * c.np + i] = s;
 }
@@ -220,13 +226,29 @@ __global__ __launch_bounds__(256) void pso_nrm(PsoDev d, PsoConst c)
 // blocks J >= I only.  A 128 x 128 tile of the Gram matrix lives in the accumulators of four
 // wavefronts (2 x 2, 64 x 64 each: 8 LDS fragment reads feed 16 MFMAs), the operands stream
 // through LDS in 16-column chunks, double buffered, the next chunk's global loads in flight
-// during the sweep.  Row sums stay in registers for the whole sweep; for J > I the tile's COLUMN
-// sums are the contribution of block I to the particles of block J and go to
-// colpart2[I][j] (no atomics: pso_ese_finish adds the slabs in a fixed order, so the result is
-// reproducible).
-// grid (ceil(np/128), P), 256 threads, dynamic LDS 2*2*128*18+512 doubles
+// during the sweep.  The operands come from Xc, the centred and zero-padded copy pso_nrm wrote:
+// staging a chunk is eight 16-byte loads and eight 16-byte LDS stores per thread and NO vector
+// arithmetic (the fp64 matrix instruction shares the vector pipe; round 2
+// centred while staging: four dependent loads of the mean, 16 subtractions and 32 selects per
+// chunk, paid once per PAIR of blocks).  Row sums stay in registers for the whole sweep; for
+// J > I the tile's COLUMN sums are the contribution of block I to the particles of block J and
+// go to colpart2[I][j] (no atomics: pso_ese_finish adds the slabs in a fixed order, so the
+// result is reproducible).
+// grid (npad/128, P), 256 threads, dynamic LDS 2*2*128*18+640 doubles
 // ---------------------------------------------------------------------------
 constexpr int ESE2_KC = 16, ESE2_LT = ESE2_KC + 2, ESE2_TILE = 128 * ESE2_LT;
+constexpr int ESE2_LDS_DOUBLES = 4 * ESE2_TILE + 640;
+
+__device__ __forceinline__ double ese_root(double t2)
+{
+    // sqrt from the hardware reciprocal-root estimate + one third-order correction (full fp64
+    // to a rounding error; 2.1e9 roots per generation at np = 65536 make the IEEE sequence 5 %
+    // of the kernel)
+    double y = __builtin_amdgcn_rsq(t2);
+    const double err = fma(-t2 * y, y, 1.);
+    y = fma(y * err, fma(err, 0.375, 0.5), y);
+    return t2 > 0. ? t2 * y : 0.;
+}
 
 __global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
 {
@@ -235,53 +257,37 @@ __global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
     if (pso_frozen(c, sc)) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cs = lds + 4 * ESE2_TILE;        // [2][128] column sums / [2][128] row sums
+    double *nI = cs + 256;                   // [128] squared norms of block I
+    double *rs = nI + 128;                   // [2][128] row sums so far (a lane owns its slots)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int np = c.np, n = c.n, ld = c.ld;
-    const int NB = (np + 127) >> 7, NCH = (ld + ESE2_KC - 1) / ESE2_KC;   // ld is even, not padded to 16
-    const double *X = d.X + (size_t) p * np * ld;
-    const double *mean = d.mean + (size_t) p * ld;
+    const int np = c.np, ldc = c.ldc;
+    const int NB = c.npad >> 7, NCH = ldc / ESE2_KC;
+    const double *Xc = d.Xc + (size_t) p * c.npad * ldc;
     const double *nrm = d.nrm + (size_t) p * np;
     const int fr = lane & 15, fk = lane >> 4;
     const int sr = tid >> 1, sh = (tid & 1) * 8;     // staging: row, first of 8 columns
+    const double *ra = Xc + (size_t) (I * 128 + sr) * ldc + sh;
 
-    double2 pa[4], pb[4];
+    // (eight named registers, not arrays: a plain copy loop from a private array to LDS is
+    // turned into a memcpy from scratch memory)
+    double2 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
     auto fetch = [&](int J, int ch) {
-        const int k0 = ch * ESE2_KC + sh;
-        const int gi = I * 128 + sr, gj = J * 128 + sr;
-        const double *ra = X + (size_t) min(gi, np - 1) * ld;
-        const double *rb = X + (size_t) min(gj, np - 1) * ld;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int kk = min(k0 + 2 * u, ld - 2);    // past the row: any in-row address, masked below
-            pa[u] = *reinterpret_cast<const double2*>(ra + kk);
-            pb[u] = *reinterpret_cast<const double2*>(rb + kk);
-        }
+        const double2 *a = reinterpret_cast<const double2*>(ra + ch * ESE2_KC);
+        const double2 *b = reinterpret_cast<const double2*>(Xc + (size_t) (J * 128 + sr) * ldc + sh
+                + ch * ESE2_KC);
+        pa0 = a[0]; pa1 = a[1]; pa2 = a[2]; pa3 = a[3];
+        pb0 = b[0]; pb1 = b[1]; pb2 = b[2]; pb3 = b[3];
     };
-    auto stash = [&](int J, int ch, int buf) {
-        const int k0 = ch * ESE2_KC + sh;
-        const bool ia = I * 128 + sr < np, ib = J * 128 + sr < np;
-        double *A = lds + buf * 2 * ESE2_TILE + sr * ESE2_LT + sh;
-        double *B = A + ESE2_TILE;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int kk = k0 + 2 * u;
-            const double2 m = *reinterpret_cast<const double2*>(mean + min(kk, ld - 2));
-            double2 va, vb;
-            va.x = (ia && kk < n) ? pa[u].x - m.x : 0.;
-            va.y = (ia && kk + 1 < n) ? pa[u].y - m.y : 0.;
-            vb.x = (ib && kk < n) ? pb[u].x - m.x : 0.;
-            vb.y = (ib && kk + 1 < n) ? pb[u].y - m.y : 0.;
-            *reinterpret_cast<double2*>(A + 2 * u) = va;
-            *reinterpret_cast<double2*>(B + 2 * u) = vb;
-        }
+    auto stash = [&](int buf) {
+        double2 *A = reinterpret_cast<double2*>(lds + buf * 2 * ESE2_TILE + sr * ESE2_LT + sh);
+        double2 *B = reinterpret_cast<double2*>(lds + buf * 2 * ESE2_TILE + ESE2_TILE + sr * ESE2_LT + sh);
+        A[0] = pa0; A[1] = pa1; A[2] = pa2; A[3] = pa3;
+        B[0] = pb0; B[1] = pb1; B[2] = pb2; B[3] = pb3;
     };
 
-    double rowacc[4][4];
-#pragma unroll
-    for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) rowacc[rt][r] = 0.;
+    // (row sums: per tile in registers, then folded over the 16 column lanes and added to the
+    // lane's own LDS slot -- 32 registers the sweep needs for its operand fragments)
     pso_d4 acc[4][4];
 #pragma unroll
     for (int rt = 0; rt < 4; rt++)
@@ -294,25 +300,39 @@ __global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
     const int half = NB >> 1;
     const int cnt = 1 + ((NB & 1) || I < half ? half : half - 1);
     const int total = cnt * NCH;
+    if (tid < 128) nI[tid] = I * 128 + tid < np ? nrm[I * 128 + tid] : 0.;
+    rs[tid] = 0.;
     fetch(I, 0);
-    stash(I, 0, 0);
+    stash(0);
     __syncthreads();
+    int t = 0, ch = 0, J = I;
     for (int it = 0; it < total; it++) {
-        const int t = it / NCH, ch = it - t * NCH;
-        const int J = I + t < NB ? I + t : I + t - NB;
         const int buf = it & 1;
-        const int nit = it + 1, nt = nit / NCH, nch = nit - nt * NCH;
-        const int nJ = I + nt < NB ? I + nt : I + nt - NB;
-        if (nit < total) fetch(nJ, nch);
+        int nt = t, nch = ch + 1, nJ = J;
+        if (nch == NCH) {
+            nch = 0;
+            nt = t + 1;
+            nJ = I + nt < NB ? I + nt : I + nt - NB;
+        }
+        // (unconditional: past the last chunk this fetches chunk 0 of the last block again and
+        // stores it where nobody reads it -- with the pair under a test the compiler cannot tell
+        // that the loads of one iteration are consumed in the same one, and waits for them
+        // before the sweep instead of after it)
+        if (nt == cnt) {
+            nt = t;
+            nJ = J;
+        }
+        fetch(nJ, nch);
+        const bool last = ch == NCH - 1;
         const double *A = lds + buf * 2 * ESE2_TILE + (64 * wr + fr) * ESE2_LT + fk;
         const double *B = lds + buf * 2 * ESE2_TILE + ESE2_TILE + (64 * wc + fr) * ESE2_LT + fk;
 #pragma unroll
         for (int ks = 0; ks < ESE2_KC / 4; ks++) {
             double a[4], b[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                a[t] = A[16 * t * ESE2_LT + 4 * ks];
-                b[t] = B[16 * t * ESE2_LT + 4 * ks];
+            for (int q = 0; q < 4; q++) {
+                a[q] = A[16 * q * ESE2_LT + 4 * ks];
+                b[q] = B[16 * q * ESE2_LT + 4 * ks];
             }
 #pragma unroll
             for (int rt = 0; rt < 4; rt++)
@@ -321,39 +341,63 @@ __global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt], b[ct], acc[rt][ct],
                             0, 0, 0);
         }
-        if (ch == NCH - 1) {
+        if (last) {
             // tile (I, J) complete: distances, row sums, and (J != I) column sums
             double colsum[4] = { 0., 0., 0., 0. };
+            double rowacc[4][4];
+#pragma unroll
+            for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) rowacc[rt][r] = 0.;
             double nj[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ct++) {
                 const int gj = J * 128 + 64 * wc + 16 * ct + fr;
                 nj[ct] = gj < np ? nrm[gj] : 0.;
             }
+            const bool full = J != I && I * 128 + 128 <= np && J * 128 + 128 <= np;
+            if (full) {
+                // no particle of the tile is past the swarm or on the diagonal: no tests
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double ni = nI[64 * wr + 16 * rt + fk + 4 * r];
+#pragma unroll
+                        for (int ct = 0; ct < 4; ct++) {
+                            const double dist = ese_root(fmax(ni + nj[ct] - 2. * acc[rt][ct][r], 0.));
+                            rowacc[rt][r] += dist;
+                            colsum[ct] += dist;
+                        }
+                    }
+            } else {
+                // (the bases pass through an empty asm: the 32 row / column indices are then
+                // formed here and not hoisted out of the sweep into 32 registers it has not got)
+                int gi0 = I * 128 + 64 * wr + fk, gj0 = J * 128 + 64 * wc + fr;
+                asm volatile("" : "+v"(gi0), "+v"(gj0));
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int gi = gi0 + 16 * rt + 4 * r;
+                        const double ni = nI[64 * wr + 16 * rt + fk + 4 * r];
+#pragma unroll
+                        for (int ct = 0; ct < 4; ct++) {
+                            const int gj = gj0 + 16 * ct;
+                            double dist = 0.;
+                            if (gi < np && gj < np && gi != gj)
+                                dist = ese_root(fmax(ni + nj[ct] - 2. * acc[rt][ct][r], 0.));
+                            rowacc[rt][r] += dist;
+                            colsum[ct] += dist;
+                        }
+                    }
+            }
 #pragma unroll
             for (int rt = 0; rt < 4; rt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int gi = I * 128 + 64 * wr + 16 * rt + fk + 4 * r;
-                    const double ni = gi < np ? nrm[gi] : 0.;   // (re-read per tile: registers are
-                                                                //  spent on the 16 accumulator tiles)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ct++) {
-                        const int gj = J * 128 + 64 * wc + 16 * ct + fr;
-                        // sqrt from the hardware reciprocal-root estimate + one third-order
-                        // correction (full fp64 to a rounding error; 2.1e9 roots per generation at
-                        // np = 65536 make the IEEE sequence 5 % of the kernel)
-                        double dist = 0.;
-                        if (gi < np && gj < np && gi != gj) {
-                            const double t2 = fmax(ni + nj[ct] - 2. * acc[rt][ct][r], 0.);
-                            double y = __builtin_amdgcn_rsq(t2);
-                            const double err = fma(-t2 * y, y, 1.);
-                            y = fma(y * err, fma(err, 0.375, 0.5), y);
-                            dist = t2 > 0. ? t2 * y : 0.;
-                        }
-                        rowacc[rt][r] += dist;
-                        colsum[ct] += dist;
-                    }
+                    const double s = pso_group_sum<16>(rowacc[rt][r]);
+                    if (fr == 0) rs[wc * 128 + 64 * wr + 16 * rt + fk + 4 * r] += s;
                 }
 #pragma unroll
             for (int ct = 0; ct < 4; ct++) {
@@ -373,20 +417,16 @@ __global__ __launch_bounds__(256, 2) void pso_ese_sym(PsoDev d, PsoConst c)
                     d.colpart2[((size_t) p * NB + I) * np + J * 128 + tid] = cs[tid] + cs[128 + tid];
             }
         }
-        if (nit < total) stash(nJ, nch, buf ^ 1);
+        stash(buf ^ 1);
         __syncthreads();
+        t = nt;
+        ch = nch;
+        J = nJ;
     }
-    // row sums of block I over all J >= I: 16 lanes, then the two column-half wavefronts
-#pragma unroll
-    for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double s = pso_group_sum<16>(rowacc[rt][r]);
-            if (fr == 0) cs[wc * 128 + 64 * wr + 16 * rt + fk + 4 * r] = s;
-        }
-    __syncthreads();
+    // row sums of block I over all J >= I: the two column-half wavefronts' slots (the loop's
+    // last barrier is behind their last update)
     if (tid < 128 && I * 128 + tid < np)
-        d.rowpart2[(size_t) p * np + I * 128 + tid] = cs[tid] + cs[128 + tid];
+        d.rowpart2[(size_t) p * np + I * 128 + tid] = rs[tid] + rs[128 + tid];
 }
 
 // ws_i = (row sums of i's own block + the column contributions of every earlier block) / (np-1)

@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
     (void) hipMemcpy(d.nrm, nrm.data(), np * 8, hipMemcpyHostToDevice);
     (void) hipMemcpy(d.scal, &sc, sizeof(sc), hipMemcpyHostToDevice);
     (void) hipMemset(d.ws, 0, np * 8);
-    const size_t lds = (size_t) (4 * ESE2_TILE + 256) * sizeof(double);
+    const size_t lds = (size_t) ESE2_LDS_DOUBLES * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*) pso_ese_sym, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     printf("attr: %s\n", hipGetErrorString(e));
     hipLaunchKernelGGL(pso_ese_sym, dim3(NB, 1), dim3(256), lds, 0, d, c);
