@@ -64,6 +64,37 @@ def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
         assert len(set(states)) >= 2   # the fuzzy state machine actually moved
 
 
+@pytest.mark.parametrize("n,np_", [
+    (8, 12),          # one block, mostly padding
+    (40, 300),        # NB = 3 (odd): every block sweeps one partner, the last block is partial
+    (130, 700),       # NB = 6 (even): the opposite pairs belong to the smaller index; n % 16 != 0
+    (20, 1024),       # NB = 8, all blocks full: the test-free epilogue of pso_ese_sym
+    (16, 1152),       # NB = 9, all blocks full
+    (515, 260),       # rows longer than 512 doubles (33 staged chunks), NB = 3
+])
+def test_mean_distance_matches_numpy(hip, n, np_):
+    """getf's d_i = mean_j ||x_i - x_j|| (apso.cpp:300-339) from pso_nrm + pso_ese_sym +
+    pso_ese_finish against the plain double loop, at block counts that exercise the cyclic pair
+    cover (odd / even NB), partial blocks and the unguarded tile path."""
+    alg = hip.APSO(mfev=10 ** 9, tol=0., np=np_, seed=5)
+    alg.initialize(hip.objectives.sphere, -5. * np.ones(n), 5. * np.ones(n), np.zeros(n))
+    X0 = alg.get_state("x").reshape(np_, n).copy()
+    alg.iterate()
+    ws = alg.get_state("ws")
+    Xc = X0 - X0.mean(0)
+    Gc = Xc @ Xc.T
+    sqc = np.diag(Gc)
+    D = np.sqrt(np.maximum(sqc[:, None] + sqc[None, :] - 2. * Gc, 0.))
+    np.fill_diagonal(D, 0.)
+    # (the centred Gram form loses ~1e-13 relative next to the direct differences; hold the
+    # device against the direct form on a sample of rows and against the Gram form on all)
+    want = D.sum(1) / (np_ - 1.)
+    assert np.abs(ws - want).max() <= 1e-11 * want.max()
+    rows = np.random.default_rng(1).choice(np_, size=min(np_, 16), replace=False)
+    direct = np.array([np.sqrt(((X0[i] - X0) ** 2).sum(1)).sum() / (np_ - 1.) for i in rows])
+    assert np.abs(ws[rows] - direct).max() <= 1e-11 * direct.max()
+
+
 def test_apso_solves_sphere(hip):
     n = 8
     alg = hip.APSO(mfev=200000, tol=1e-6, np=40, seed=3)
