@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
 // grid (splits, P), 256 threads, 2 workgroups per CU
 // ---------------------------------------------------------------------------
 constexpr int G128_CH = 32;          // rows per chunk
+constexpr int G128_PACE = 4;         // cma_gram128s: chunks between two pacing barriers
 constexpr int G128_LDY = 128 + 16;
 constexpr int G128_TI[4][9] = { { 5, 5, 5, 6, 6, 6, 7, 7, 7 }, { 2, 2, 2, 3, 3, 3, 4, 4, 4 },
         { 5, 5, 6, 6, 7, 7, 3, 4, 4 }, { 0, 1, 1, 5, 6, 6, 7, 7, 7 } };
@@ -1261,6 +1262,7 @@ __device__ __forceinline__ void gram128_stream(const CmaDev &d, const CmaConst &
     const int nrows = min(c.rps, c.lambda_pad - row0);
     const int nch = (nrows + G128_CH - 1) / G128_CH;
     const int fr = lane & 15, fk = lane >> 4;
+    const bool pace = !(d.dbg & 65536);
 
     double xo[8];
 #pragma unroll
@@ -1380,6 +1382,11 @@ __device__ __forceinline__ void gram128_stream(const CmaDev &d, const CmaConst &
         coef_link2();                     // chunk ch + 2, from the rank loaded a chunk ago
         coef_link1(ch + 3);
         cma_wave_sync();
+        // Pacing, not synchronisation: the four wavefronts share no data, but they read the same
+        // rows, and left alone they drift apart until a row one of them fetched has left L1 / L2
+        // when the next one asks for it (1.49 x the algorithmic bytes from HBM, round-3 counters).
+        // A bare s_barrier every PACE chunks (no memory wait attached) bounds the drift.
+        if (pace && (ch & (G128_PACE - 1)) == G128_PACE - 1) __builtin_amdgcn_s_barrier();
     }
     double *G = d.gram_part + ((size_t) p * c.splits + s) * 128 * 128;
     double *mp = d.mean_part + ((size_t) p * c.splits + s) * 128;
