@@ -557,7 +557,10 @@ void CmaEngine::launch_update()
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_PATHS);
-    if (c.lazy_isc)
+    if (c.lazy_isc && c.n >= 64 && !(d_.dbg & 131072))
+        // (1024 threads: a quarter of the dependent round trips of the two passes over B)
+        hipLaunchKernelGGL(cma_paths_lazy1k, dim3(c.npop), dim3(1024), 0, stream_, d_, c_);
+    else if (c.lazy_isc)
         hipLaunchKernelGGL(cma_paths_lazy, dim3(c.npop), dim3(256), 0, stream_, d_, c_);
     else
         hipLaunchKernelGGL(cma_paths, dim3(c.npop), dim3(256), 0, stream_, d_, c_);

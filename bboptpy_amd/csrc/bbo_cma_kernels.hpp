@@ -1408,22 +1408,24 @@ __global__ __launch_bounds__(256, 2) void cma_gram128s(CmaDev d, CmaConst c)
 }
 
 // ---------------------------------------------------------------------------
-// paths: mean, ps, hsig, pc, sigma -- one workgroup of 256 threads per population
+// paths: mean, ps, hsig, pc, sigma -- one workgroup of T threads per population (256; the lazy
+// form of a big batch 1024: its two passes over B are a handful of dependent round trips to L2 /
+// HBM per thread, and four times the threads make a quarter of the trips)
 // ---------------------------------------------------------------------------
-template<bool LAZY = false>     // LAZY: c.lazy_isc configurations (C^-1/2 dm from B and D)
+template<bool LAZY = false, int T = 256>   // LAZY: c.lazy_isc configurations (C^-1/2 dm from B and D)
 __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, int p)
 {
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     __shared__ double dm[512];
-    __shared__ double red[4];
+    __shared__ double red[T / 64];
     const int tid = threadIdx.x, ld = c.ld;
     double *xmean = d.xmean + (size_t) p * ld, *xold = d.xold + (size_t) p * ld;
     double *ps = d.ps + (size_t) p * ld, *pc = d.pc + (size_t) p * ld;
     const double sigma = sc->sigma;
 
     // weighted mean (active_cmaes.cpp:75-85 / cmaes.cpp:85-96)
-    for (int j = tid; j < ld; j += 256) {
+    for (int j = tid; j < ld; j += T) {
         double sum = 0.;
         for (int s = 0; s < c.splits; s++)
             sum += d.mean_part[((size_t) p * c.splits + s) * ld + j];
@@ -1448,40 +1450,47 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
     if (LAZY && sc->basis_ok) {
         // C^-1/2 dm = B (D^-1 (B^T dm)) from the basis itself: 2 n^2 operations instead of the
         // n^3 of forming C^-1/2 after every decomposition (cma_post then only packs B D)
-        __shared__ double sv[256], cv[256], part[128];
+        constexpr int HN = T / 128;         // row groups of a column in the first pass
+        constexpr int RS = T / 16, NU = 128 / RS;   // rows per sweep / sweeps of the second
+        __shared__ double sv[256], cv[256], part[HN - 1][128];
         const double *B = d.B + (size_t) p * ld * ld, *D = d.D + (size_t) p * ld;
         // (both products with the loads of a thread independent of each other: the matrix comes
         // from L2 / HBM once, latency is what there is to hide)
         for (int jb = 0; jb < c.n; jb += 128) {     // (one pass for n <= 128, two up to 256)
-            // t = B^T dm: column j by threads j and j + 128 (even / odd rows), 8 rows in flight
+            // t = B^T dm: column j by threads j, j + 128, ... (rows h, h + HN, ...), 8 rows in flight
             const int j = jb + (tid & 127), h = tid >> 7;
             double t0 = 0., t1 = 0., t2 = 0., t3 = 0.;
             if (j < c.n) {
                 int i = h;
-                for (; i + 14 < c.n; i += 16) {
+                for (; i + 7 * HN < c.n; i += 8 * HN) {
                     double b[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) b[u] = B[(size_t) (i + 2 * u) * ld + j];
-                    t0 += b[0] * dm[i] + b[4] * dm[i + 8];
-                    t1 += b[1] * dm[i + 2] + b[5] * dm[i + 10];
-                    t2 += b[2] * dm[i + 4] + b[6] * dm[i + 12];
-                    t3 += b[3] * dm[i + 6] + b[7] * dm[i + 14];
+                    for (int u = 0; u < 8; u++) b[u] = B[(size_t) (i + HN * u) * ld + j];
+                    t0 += b[0] * dm[i] + b[4] * dm[i + 4 * HN];
+                    t1 += b[1] * dm[i + HN] + b[5] * dm[i + 5 * HN];
+                    t2 += b[2] * dm[i + 2 * HN] + b[6] * dm[i + 6 * HN];
+                    t3 += b[3] * dm[i + 3 * HN] + b[7] * dm[i + 7 * HN];
                 }
-                for (; i < c.n; i += 2) t0 += B[(size_t) i * ld + j] * dm[i];
+                for (; i < c.n; i += HN) t0 += B[(size_t) i * ld + j] * dm[i];
             }
             const double t = (t0 + t1) + (t2 + t3);
-            if (h == 1) part[tid & 127] = t;
+            if (h > 0) part[h - 1][tid & 127] = t;
             __syncthreads();
-            if (h == 0) sv[j] = j < c.n ? (t + part[tid & 127]) / D[j] : 0.;
+            if (h == 0) {
+                double tt = t;
+#pragma unroll
+                for (int q = 0; q < HN - 1; q++) tt += part[q][tid & 127];
+                sv[j] = j < c.n ? tt / D[j] : 0.;
+            }
             __syncthreads();
         }
         for (int ib = 0; ib < c.n; ib += 128) {
-            // cv = B sv: rows r, r + 16, ... by the 16 lanes of a DPP row (128-byte segments)
+            // cv = B sv: rows r, r + RS, ... by the 16 lanes of a DPP row (128-byte segments)
             const int g = tid & 15, r = ib + (tid >> 4);
-            double a[8];
+            double a[NU];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = r + 16 * u;
+            for (int u = 0; u < NU; u++) {
+                const int i = r + RS * u;
                 double tot = 0.;
                 for (int kb = 0; kb < c.n; kb += 128) {
                     double x[8];
@@ -1496,19 +1505,19 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
                 a[u] = tot;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < NU; u++) {
                 const double v = group_sum<16>(a[u]);
-                if (g == 0 && r + 16 * u < c.n) cv[r + 16 * u] = v;
+                if (g == 0 && r + RS * u < c.n) cv[r + RS * u] = v;
             }
         }
         __syncthreads();
-        for (int i = tid; i < ld; i += 256) {
+        for (int i = tid; i < ld; i += T) {
             const double v = i < c.n ? (1. - c.cs) * ps[i] + csc * cv[i] / den : 0.;
             ps[i] = v;
             ssq += v * v;
         }
     } else {
-        for (int i = tid; i < ld; i += 256) {
+        for (int i = tid; i < ld; i += T) {
             double v = 0.;
             if (i < c.n) {
                 double acc = 0.;
@@ -1522,7 +1531,10 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
     ssq = wave_sum(ssq);
     if ((tid & 63) == 0) red[tid >> 6] = ssq;
     __syncthreads();
-    const double pslen = sqrt(red[0] + red[1] + red[2] + red[3]);
+    double rsum = 0.;
+#pragma unroll
+    for (int q = 0; q < T / 64; q++) rsum += red[q];
+    const double pslen = sqrt(rsum);
 
     // hsig (active_cmaes.cpp:98-105); fev already counts this generation
     const double denom = 1. - pow(1. - c.cs, 2. * sc->fev / c.lambda);
@@ -1530,7 +1542,7 @@ __device__ __forceinline__ void paths_body(const CmaDev &d, const CmaConst &c, i
 
     // pc (active_cmaes.cpp:108-112)
     const double ccc = sqrt(c.cc * (2. - c.cc) * c.mueff);
-    for (int i = tid; i < ld; i += 256) {
+    for (int i = tid; i < ld; i += T) {
         double v = 0.;
         if (i < c.n) v = (1. - c.cc) * pc[i] + hsig * ccc * dm[i] / den;
         pc[i] = v;
@@ -1556,6 +1568,10 @@ __global__ __launch_bounds__(256) void cma_paths(CmaDev d, CmaConst c)
 __global__ __launch_bounds__(256) void cma_paths_lazy(CmaDev d, CmaConst c)
 {
     paths_body<true>(d, c, blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void cma_paths_lazy1k(CmaDev d, CmaConst c)
+{
+    paths_body<true, 1024>(d, c, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
