@@ -4,6 +4,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bboptpy_amd as b
+from bboptpy_amd import _ffi
+if os.environ.get("BBO_LIB"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["BBO_LIB"])   # a variant build (scripts/_variants)
 P, n, lam = 256, 128, 4096
 bits = [int(a) for a in sys.argv[1:]] or [0, 65536]
 for dbg in bits:
