@@ -16,6 +16,9 @@ int main(int argc, char **argv) {
     for (int i = 0; i < np; i++) { double s = 0; for (int k = 0; k < np; k++) if (k != i) { double d2 = 0; for (int j = 0; j < n; j++) { double v = X[(size_t) i * ld + j] - X[(size_t) k * ld + j]; d2 += v * v; } s += sqrt(d2); } want[i] = s / (np - 1.); }
     PsoDev d {}; PsoConst c {};
     c.n = n; c.ld = ld; c.np = np; c.npop = 1; c.honor_stop = 0;
+    c.ldc = (n + 15) / 16 * 16; c.npad = (np + 127) / 128 * 128;
+    (void) hipMalloc(&d.Xc, (size_t) c.npad * c.ldc * 8);
+    (void) hipMemset(d.Xc, 0, (size_t) c.npad * c.ldc * 8);
     PsoScal sc {}; 
     (void) hipMalloc(&d.X, X.size() * 8); (void) hipMalloc(&d.mean, ld * 8); (void) hipMalloc(&d.nrm, np * 8);
     (void) hipMalloc(&d.ws, np * 8); (void) hipMalloc(&d.colpart2, (size_t) NB * np * 8); (void) hipMalloc(&d.rowpart2, np * 8);
@@ -25,6 +28,7 @@ int main(int argc, char **argv) {
     (void) hipMemcpy(d.nrm, nrm.data(), np * 8, hipMemcpyHostToDevice);
     (void) hipMemcpy(d.scal, &sc, sizeof(sc), hipMemcpyHostToDevice);
     (void) hipMemset(d.ws, 0, np * 8);
+    hipLaunchKernelGGL(pso_nrm, dim3((np + 15) / 16, 1), dim3(256), 0, 0, d, c);   // writes Xc (and nrm again)
     const size_t lds = (size_t) ESE2_LDS_DOUBLES * sizeof(double);
     hipError_t e = hipFuncSetAttribute((const void*) pso_ese_sym, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     printf("attr: %s\n", hipGetErrorString(e));
