@@ -205,8 +205,11 @@ void DeEngine::generation(bool honor_stop)
     timer_.begin(stream_, K_GEN);
     if (c.variant == 2)
         hipLaunchKernelGGL(sansde_generation, gR, dim3(16 * R), lds, stream_, d_, c_);
-    else
-        hipLaunchKernelGGL(de_generation, gR, dim3(16 * R), lds, stream_, d_, c_);
+    else {
+        const size_t lds_box = lds + (size_t) 2 * c.ld * sizeof(double);   // + lower, upper
+        allow_lds((const void*) de_generation, 128 * 1024);
+        hipLaunchKernelGGL(de_generation, gR, dim3(16 * R), lds_box, stream_, d_, c_);
+    }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     if (!obj_.on_device()) {

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void de_rank_wave(DeDev d, DeConst c, int whic
 }
 
 // ---------------------------------------------------------------------------
-// the fused generation.  grid (ceil(np_launch/16), P), 256 threads; LDS 16 * ld doubles
+// the fused generation.  grid (ceil(np_launch/16), P), 256 threads; LDS (16 + 2) * ld doubles
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
 {
@@ -157,12 +157,37 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     const int ld = c.ld, n = c.n, np = sc->np, larch = sc->larch, gen = sc->gen, cur = sc->cur;
     const bool live = i < np;
     double *trial = lds + r * ld;
+    // The box, once per workgroup, behind the rows (the host sizes the stage for two more): read
+    // from global memory inside the crossover loop -- where the scheduler puts a load next to its
+    // use -- it was a round trip to L2 per group of column pairs, on the critical path of a
+    // workgroup that lives for about ten such round trips (round 3, read in the ISA).
+    // (requested here, stored to LDS after the draws: the loads then cost no wait of their own;
+    // rows of more than two columns per thread take the plain loop)
+    double *lob = lds + (size_t) (blockDim.x >> 4) * ld, *upb = lob + ld;
+    const bool box_regs = ld <= 2 * (int) blockDim.x;
+    double blo[2] = { 0., 0. }, bup[2] = { 0., 0. };
+    if (box_regs) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = min(tid + u * (int) blockDim.x, ld - 1);
+            blo[u] = d.lower[j];
+            bup[u] = d.upper[j];
+        }
+    } else {
+        for (int j = tid; j < ld; j += blockDim.x) {
+            lob[j] = d.lower[j];
+            upb[j] = d.upper[j];
+        }
+    }
     const size_t pbase = (size_t) p * c.npinit;
     const double *Xc = d.X[cur] + pbase * ld;
     double *Xn = d.X[cur ^ 1] + pbase * ld;
     const double *fc = d.f[cur] + pbase;
     const int *order = d.order + pbase;
     const uint32_t sub = (uint32_t) p;
+    // (the parent's row index: requested before the draws, used after them -- unsigned and
+    // unconditional, so that nothing has to wait for it here, not even a sign extension)
+    const unsigned oi = (unsigned) order[live ? i : 0];
 
     // ---- per-individual draws, shade.cpp:105-131 / jade.cpp:107-133.  The draws of one
     // individual are independent Philox calls, so the 16 lanes of its group make one each
@@ -260,14 +285,27 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     // ---- mutation + binomial crossover + midpoint bound repair, into LDS.  Four column pairs
     // per lane at a time: all sixteen row loads of the four partners go out before the first
     // Philox call (the gathers are what this kernel waits for), the arithmetic is select-only ---
+    if (box_regs) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = tid + u * (int) blockDim.x;
+            if (j < ld) {
+                lob[j] = blo[u];
+                upb[j] = bup[u];
+            }
+        }
+    }
+    __syncthreads();           // lob / upb are staged
     double cnt = 0.;
     const double *xi = nullptr;
+    double fold = 0.;          // the parent's fitness: requested with the partner rows
     const int npair = ld >> 1;
     double2 akeep[4];          // the parent's columns of the first pass (all of them if ld <= 128)
 #pragma unroll
     for (int u = 0; u < 4; u++) akeep[u] = make_double2(0., 0.);
     if (live) {
-        xi = Xc + (size_t) order[i] * ld;
+        xi = Xc + (size_t) oi * ld;
+        fold = fc[oi];
         const double *xb = Xc + (size_t) order[ibest] * ld;
         const double *x1 = Xc + (size_t) order[r1] * ld;
         const double *x2 = r2 >= np ? d.arch + (pbase + (r2 - np)) * ld
@@ -290,8 +328,8 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
                 if (pj < npair) {
                     const int j = 2 * pj;
                     if (pj0 == g) akeep[u] = a[u];
-                    const double2 lo = *reinterpret_cast<const double2*>(&d.lower[j]);
-                    const double2 up = *reinterpret_cast<const double2*>(&d.upper[j]);
+                    const double2 lo = *reinterpret_cast<const double2*>(&lob[j]);
+                    const double2 up = *reinterpret_cast<const double2*>(&upb[j]);
                     const u32x4 w = philox4x32_10(c.seed, (uint32_t) i, (uint32_t) pj,
                             (uint32_t) gen, swc);
                     const bool cx = j < n && (j == jrand || u01(w.x, w.y) < CR);
@@ -334,9 +372,7 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
     }
     double ssq = 0.;
     bool accept = false;
-    double fold = 0.;
     if (live) {
-        fold = fc[order[i]];
         accept = ft <= fold;
         // (the parent's first 128 columns are still in registers)
 #pragma unroll
