@@ -203,10 +203,11 @@ void DeEngine::generation(bool honor_stop)
     dim3 gR((np_host_ + R - 1) / R, P);
     const size_t lds = (size_t) R * c.ld * sizeof(double);
     timer_.begin(stream_, K_GEN);
-    if (c.variant == 2)
-        hipLaunchKernelGGL(sansde_generation, gR, dim3(16 * R), lds, stream_, d_, c_);
-    else {
-        const size_t lds_box = lds + (size_t) 2 * c.ld * sizeof(double);   // + lower, upper
+    const size_t lds_box = lds + (size_t) 2 * c.ld * sizeof(double);   // + lower, upper
+    if (c.variant == 2) {
+        allow_lds((const void*) sansde_generation, 128 * 1024);
+        hipLaunchKernelGGL(sansde_generation, gR, dim3(16 * R), lds_box, stream_, d_, c_);
+    } else {
         allow_lds((const void*) de_generation, 128 * 1024);
         hipLaunchKernelGGL(de_generation, gR, dim3(16 * R), lds_box, stream_, d_, c_);
     }

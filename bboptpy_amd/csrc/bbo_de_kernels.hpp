@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void de_generation(DeDev d, DeConst c)
 // three distinct partners, DE/rand/1 or DE/current-to-best/2 by probability p, binomial
 // crossover (`<=`), midpoint repair, evaluation, replacement on strict improvement.
 // Generation-synchronous like de_generation (oracle: Sansde::iterate_sync).
-// grid (ceil(np/16), P), 256 threads; LDS 16 * ld doubles
+// grid (ceil(np/16), P), 256 threads; LDS (16 + 2) * ld doubles
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
 {
@@ -429,11 +429,30 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
     const double *fc = d.f[cur] + pbase;
     const int *order = d.order + pbase;
     const uint32_t sw = stream_word(STREAM_DE_PARAM, (uint32_t) p);
+    // as in de_generation: the box requested here and stored to LDS after the draws, the parent's
+    // index requested first (unsigned, unconditional), its fitness with the partner rows
+    double *lob = lds + (size_t) (blockDim.x >> 4) * ld, *upb = lob + ld;
+    const bool box_regs = ld <= 2 * (int) blockDim.x;
+    double blo[2] = { 0., 0. }, bup[2] = { 0., 0. };
+    if (box_regs) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = min(tid + u * (int) blockDim.x, ld - 1);
+            blo[u] = d.lower[j];
+            bup[u] = d.upper[j];
+        }
+    } else {
+        for (int j = tid; j < ld; j += blockDim.x) {
+            lob[j] = d.lower[j];
+            upb[j] = d.upper[j];
+        }
+    }
+    const unsigned oi = (unsigned) order[live ? i : 0];
 
     double CR = 0., F = 0.5;
     int strat = 0, r1 = 0, r2 = 0, r3 = 0, jrand = 0;
     if (live && g == 0) {
-        CR = d.crow[cur][pbase + order[i]];
+        CR = d.crow[cur][pbase + oi];
         if (gen % c.ncrref == 0) {
             double z0, z1;
             normal_pair(c.seed, (uint32_t) i, 0, (uint32_t) gen, sw, z0, z1);
@@ -483,14 +502,27 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
     r3 = __shfl(r3, 0, 16);
     jrand = __shfl(jrand, 0, 16);
 
+    if (box_regs) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = tid + u * (int) blockDim.x;
+            if (j < ld) {
+                lob[j] = blo[u];
+                upb[j] = bup[u];
+            }
+        }
+    }
+    __syncthreads();           // lob / upb are staged
     // (same shape as de_generation: four column pairs per lane, the sixteen gathers first)
     double cnt = 0.;
+    double fold = 0.;
     const int npair = ld >> 1;
     double2 akeep[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) akeep[u] = make_double2(0., 0.);
     if (live) {
-        const double *xi = Xc + (size_t) order[i] * ld;
+        const double *xi = Xc + (size_t) oi * ld;
+        fold = fc[oi];
         const double *x1 = Xc + (size_t) order[r1] * ld;
         const double *x2 = Xc + (size_t) order[r2] * ld;
         const bool rand1 = (strat & 1) == 0;
@@ -514,8 +546,8 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
                 if (pj < npair) {
                     const int j = 2 * pj;
                     if (pj0 == g) akeep[u] = a[u];
-                    const double2 lo = *reinterpret_cast<const double2*>(&d.lower[j]);
-                    const double2 up = *reinterpret_cast<const double2*>(&d.upper[j]);
+                    const double2 lo = *reinterpret_cast<const double2*>(&lob[j]);
+                    const double2 up = *reinterpret_cast<const double2*>(&upb[j]);
                     double2 m;
                     if (rand1) {
                         m.x = q1[u].x + F * (q2[u].x - q4[u].x);
@@ -561,10 +593,8 @@ __global__ __launch_bounds__(256) void sansde_generation(DeDev d, DeConst c)
     if (ft != ft) ft = BBO_INF_D;
     double ssq = 0.;
     bool accept = false;
-    double fold = 0.;
     if (live) {
-        const double *xi = Xc + (size_t) order[i] * ld;
-        fold = fc[order[i]];
+        const double *xi = Xc + (size_t) oi * ld;
         accept = ft < fold;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
