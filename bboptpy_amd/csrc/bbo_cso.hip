@@ -134,7 +134,7 @@ void CsoEngine::init(int n, const double *lower, const double *upper, const doub
     hipLaunchKernelGGL(cso_finish_part, dim3(c_.fparts, P), dim3(256), 0, stream_, d_, c_);
     hipLaunchKernelGGL(cso_finish, dim3(P), dim3(64), 0, stream_, d_, c_, 1);
     if (fuse_g_) {      // the sums cso_compete maintains from now on, of the initial swarm
-        const size_t lds = (size_t) (256 / fuse_g_) * c.ld * sizeof(double);
+        const size_t lds = (size_t) (256 / fuse_g_ + 2) * c.ld * sizeof(double);   // rows + the box
         const dim3 grid(c.nwg, P);
         if (fuse_g_ == 16) hipLaunchKernelGGL(cso_team_colsum<16>, grid, dim3(256), lds, stream_, d_, c_);
         else if (fuse_g_ == 32) hipLaunchKernelGGL(cso_team_colsum<32>, grid, dim3(256), lds, stream_, d_, c_);
@@ -205,7 +205,7 @@ void CsoEngine::generation(bool honor_stop)
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_COMPETE);
     if (fuse_g_) {
-        const size_t lds = (size_t) (256 / fuse_g_) * c.ld * sizeof(double);
+        const size_t lds = (size_t) (256 / fuse_g_ + 2) * c.ld * sizeof(double);   // rows + the box
         const dim3 grid(c.nwg, P);
         if (fuse_g_ == 16)
             hipLaunchKernelGGL((cso_compete<16, true>), grid, dim3(256), lds, stream_, d_, c_);
@@ -215,8 +215,9 @@ void CsoEngine::generation(bool honor_stop)
             hipLaunchKernelGGL((cso_compete<64, true>), grid, dim3(256), lds, stream_, d_, c_);
     } else {
         const int R = rows_per_wg16(c.ld);     // groups staged in LDS per workgroup
+        allow_lds((const void*) cso_compete<16, false>, 128 * 1024);
         hipLaunchKernelGGL((cso_compete<16, false>), dim3((c.ngroup + R - 1) / R, P), dim3(16 * R),
-                (size_t) R * c.ld * sizeof(double), stream_, d_, c_);
+                (size_t) (R + 2) * c.ld * sizeof(double), stream_, d_, c_);
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());

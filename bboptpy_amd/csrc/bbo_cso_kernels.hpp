@@ -245,6 +245,15 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
     const int gI = blockIdx.x * (blockDim.x / G) + r, ld = c.ld, n = c.n, gen = sc->gen;
     const bool live = gI < c.ngroup;
     double *trial = lds + r * ld;
+    // The box in LDS, once per workgroup, behind the teams' rows: read from global memory under
+    // `if (j < n)` inside the update loop, each column pair waited for its own loads -- and, the
+    // memory counter being in order, for the STORES of the pair before it (round 3, from the ISA).
+    double *lob = lds + (size_t) (blockDim.x / G) * ld, *upb = lob + ld;
+    for (int j = tid; j < ld; j += blockDim.x) {
+        lob[j] = d.lower[j];
+        upb[j] = d.upper[j];
+    }
+    __syncthreads();
     const size_t pb = (size_t) p * c.np;
     const int *occ = d.occ + pb + (size_t) (live ? gI : 0) * c.pc;
     const double *gmean = d.mean + (size_t) p * ld, *wmean = d.meanw + (size_t) p * ld;
@@ -292,20 +301,20 @@ __global__ __launch_bounds__(256) void cso_compete(CsoDev d, CsoConst c)
                     if (j < n) {
                         double vv = u01(wa.x, wa.y) * vi.x + u01(wa.z, wa.w) * (pa.x - xi.x)
                                 + phi * u01(wc.x, wc.y) * (me.x - xi.x);
-                        const double maxv = c.vmax * (d.upper[j] - d.lower[j]);
+                        const double maxv = c.vmax * (upb[j] - lob[j]);
                         vv = fmax(-maxv, fmin(vv, maxv));
                         double xx = xi.x + vv;
-                        if (c.correct) xx = fmax(d.lower[j], fmin(xx, d.upper[j]));
+                        if (c.correct) xx = fmax(lob[j], fmin(xx, upb[j]));
                         vn.x = vv;
                         xn.x = xx;
                     }
                     if (j + 1 < n) {
                         double vv = u01(wb.x, wb.y) * vi.y + u01(wb.z, wb.w) * (pa.y - xi.y)
                                 + phi * u01(wc.z, wc.w) * (me.y - xi.y);
-                        const double maxv = c.vmax * (d.upper[j + 1] - d.lower[j + 1]);
+                        const double maxv = c.vmax * (upb[j + 1] - lob[j + 1]);
                         vv = fmax(-maxv, fmin(vv, maxv));
                         double xx = xi.y + vv;
-                        if (c.correct) xx = fmax(d.lower[j + 1], fmin(xx, d.upper[j + 1]));
+                        if (c.correct) xx = fmax(lob[j + 1], fmin(xx, upb[j + 1]));
                         vn.y = vv;
                         xn.y = xx;
                     }
