@@ -385,11 +385,14 @@ __global__ __launch_bounds__(256) void cma_sample_eval64(CmaDev d, CmaConst c)
 // to its 256 MFMAs, all on the same pipe.  Same arithmetic, same bits.
 template<bool FULL>
 __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, int p, int rowbase,
-        double sigma, const d4_t (&acc)[8], int lane)
+        double sigma, const d4_t (&acc)[8], int lane, const double *xm)
 {
+    // xm: the mean, from the workgroup's LDS copy.  Read from global memory here -- eight loads,
+    // each next to its use between two groups of four row stores -- every one of them was waited
+    // for with vmcnt(0), i.e. together with the stores in front of it (one in-order counter): eight
+    // store acknowledgements per tile on the wavefront's critical path (round 3, from the ISA).
     const int fr = lane & 15, fk = lane >> 4;
     const int n = FULL ? 128 : c.n;
-    const double *xm = d.xmean + (size_t) p * 128;
     double *Xp = d.X + (size_t) p * c.lambda_pad * 128 + ((size_t) rowbase + fk) * 128 + fr;
     double x[8][4];
 #pragma unroll
@@ -431,7 +434,7 @@ __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, in
 // the registers they land in have been issued: loads do not occupy the vector pipe.
 template<bool FULL, bool ZBUF = false>
 __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaConst &c,
-        int rows_per_wg, double *bd, const double2 *ntab, const double *ftab)
+        int rows_per_wg, double *bd, const double2 *ntab, const double *ftab, const double *xms)
 {
     const int p = blockIdx.y, row0 = blockIdx.x * rows_per_wg;
     const CmaScal *sc = d.scal + p;
@@ -546,7 +549,7 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
         zz += __shfl_xor(zz, 16, 64);
         zz += __shfl_xor(zz, 32, 64);
         if (fk == 0) d.zn2[(size_t) p * c.lambda_pad + row] = zz;
-        sample128_epilogue<FULL>(d, c, p, rowbase, sigma, acc, lane);
+        sample128_epilogue<FULL>(d, c, p, rowbase, sigma, acc, lane, xms);
     }
 }
 
@@ -567,11 +570,13 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
     }
     __shared__ double2 ntab[NORMAL_TABLE_N];
     __shared__ double ftab[NORMAL_FTABLE_N];
+    __shared__ double xms[128];
     normal_table_fill(ntab, tid, 512);
     normal_ftable_fill(ftab, tid, 512);
+    if (tid < 128) xms[tid] = d.xmean[(size_t) p * 128 + tid];
     __syncthreads();
-    if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab, ftab);
-    else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab, ftab);
+    if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab, ftab, xms);
+    else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab, ftab, xms);
 }
 
 // The lean build with the normals PRE-DRAWN (d.zbuf, written by cma_draw128 for exactly this
@@ -591,8 +596,10 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128z(CmaDev d, CmaConst
 #pragma unroll
         for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
     }
+    __shared__ double xms[128];
+    if (tid < 128) xms[tid] = d.xmean[(size_t) p * 128 + tid];
     __syncthreads();
-    sample_eval128_body<true, true>(d, c, rows_per_wg, bd, nullptr, nullptr);
+    sample_eval128_body<true, true>(d, c, rows_per_wg, bd, nullptr, nullptr, xms);
 }
 
 // The draw of generation sc->zreq for the lean n = 128 sampler, as a kernel of its own: lane
