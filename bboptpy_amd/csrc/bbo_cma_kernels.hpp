@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     const double sigma = sc->sigma;
     const double *xm = d.xmean + (size_t) p * ld;
     double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+    // (the lane's columns of the mean and of the box first, all of them: read next to their use
+    // they sit between the row stores, and each is then waited for together with the stores in
+    // front of it -- one in-order memory counter)
+    double xmc[MAXT], loc[MAXT], upc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int col = min((wave + 4 * t) * 16 + (lane & 15), ld - 1);
+        xmc[t] = xm[col];
+        loc[t] = c.bound ? d.lower[col] : 0.;
+        upc[t] = c.bound ? d.upper[col] : 0.;
+    }
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         const int nt = wave + 4 * t;
@@ -219,8 +230,8 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
                 const int rl = (lane >> 4) + 4 * r;
                 double v = 0.;
                 if (col < c.n) {
-                    v = xm[col] + sigma * acc[t][r];
-                    if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+                    v = xmc[t] + sigma * acc[t][r];
+                    if (c.bound) v = fmax(loc[t], fmin(v, upc[t]));
                 }
                 lds[rl * ldz + col] = v;
                 Xp[((size_t) mt * 16 + rl) * ld + col] = v;
@@ -325,6 +336,15 @@ __device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaCon
     const double sigma = sc->sigma;
     const double *xm = d.xmean + (size_t) p * ld;
     double *Xp = d.X + (size_t) p * c.lambda_pad * ld;
+    // (the lane's columns of the mean and of the box first: see sample_eval_body)
+    double xmc[MAXT], loc[MAXT], upc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        const int col = min((wave + 4 * t) * 16 + (lane & 15), ld - 1);
+        xmc[t] = xm[col];
+        loc[t] = c.bound ? d.lower[col] : 0.;
+        upc[t] = c.bound ? d.upper[col] : 0.;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) {
 #pragma unroll
@@ -337,8 +357,8 @@ __device__ __forceinline__ void sample_eval64_body(const CmaDev &d, const CmaCon
                     const int rl = mt * 16 + (lane >> 4) + 4 * r;
                     double v = 0.;
                     if (col < c.n) {
-                        v = xm[col] + sigma * acc[mt][t][r];
-                        if (c.bound) v = fmax(d.lower[col], fmin(v, d.upper[col]));
+                        v = xmc[t] + sigma * acc[mt][t][r];
+                        if (c.bound) v = fmax(loc[t], fmin(v, upc[t]));
                     }
                     lds[rl * ldz + col] = v;
                     if (row0 + rl < c.lambda_pad) Xp[((size_t) row0 + rl) * ld + col] = v;
