@@ -507,12 +507,8 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
             // elements of k-steps 4 q .. 4 q + 3; candidates first, the unsettled draws of all
             // eight calls together afterwards (normal_quad_fast)
             double z[32];
-            uint32_t pend = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                pend |= normal_quad_fast(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk),
-                        (uint32_t) gen, sw, ntab, z[4 * q], z[4 * q + 1], z[4 * q + 2],
-                        z[4 * q + 3]) << (4 * q);
+            uint32_t pend = normal_quads_fast<8>(c.seed, (uint32_t) row, (uint32_t) fk, 4u,
+                    (uint32_t) gen, sw, ntab, z);
             while (pend) {
                 const int b = __ffs(pend) - 1;
                 pend &= pend - 1;

@@ -253,9 +253,10 @@ __device__ inline double zig_slow(uint64_t seed, uint32_t c0, uint32_t c1, uint3
 }
 
 // the fast path of one word: the candidate +/- t W[i] and whether it stands
-__device__ inline double zig_candidate(uint32_t w, const double2 *tab, bool &settled)
+__device__ inline double zig_candidate(uint32_t w, const double2 e, bool &settled)
 {
-    const double2 e = tab[w & 1023u];
+    // e = tab[w & 1023]: the caller reads the strips of all its words first (four LDS reads in
+    // flight instead of read, wait, use four times in a row)
     const uint32_t t = (w >> 10) | 1u;
     const double x = (double) t * e.x;
     settled = t < (uint32_t) __double_as_longlong(e.y);
@@ -273,11 +274,42 @@ __device__ inline uint32_t normal_quad_fast(uint64_t seed, uint32_t c0, uint32_t
 {
     const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
     bool s0, s1, s2, s3;
-    z0 = zig_candidate(w.x, tab, s0);
-    z1 = zig_candidate(w.y, tab, s1);
-    z2 = zig_candidate(w.z, tab, s2);
-    z3 = zig_candidate(w.w, tab, s3);
+    const double2 e0 = tab[w.x & 1023u], e1 = tab[w.y & 1023u], e2 = tab[w.z & 1023u],
+            e3 = tab[w.w & 1023u];
+    z0 = zig_candidate(w.x, e0, s0);
+    z1 = zig_candidate(w.y, e1, s1);
+    z2 = zig_candidate(w.z, e2, s2);
+    z3 = zig_candidate(w.w, e3, s3);
     return (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
+}
+
+// NQ calls in a row (call q at counter c1 = c1_0 + q c1_step), software-pipelined by hand: the
+// four strip reads of call q are issued, THEN the Philox rounds of call q + 1 run (some 60 vector
+// instructions: longer than an LDS round trip), then call q's candidates are formed.  Written as
+// NQ calls of normal_quad_fast the compiler emits `ds_read, s_waitcnt lgkmcnt(0), use` per word:
+// 32 exposed LDS round trips per 16-row tile of the n = 128 sampler.  Same draws, same bits.
+template<int NQ>
+__device__ __forceinline__ uint32_t normal_quads_fast(uint64_t seed, uint32_t c0, uint32_t c1_0,
+        uint32_t c1_step, uint32_t c2, uint32_t c3, const double2 *tab, double (&z)[4 * NQ])
+{
+    uint32_t pend = 0;
+    u32x4 wn = philox4x32_10(seed, c0, c1_0, c2, c3);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const u32x4 w = wn;
+        const double2 e0 = tab[w.x & 1023u], e1 = tab[w.y & 1023u], e2 = tab[w.z & 1023u],
+                e3 = tab[w.w & 1023u];
+        __builtin_amdgcn_sched_barrier(0);       // the reads go out before the next call's rounds
+        if (q + 1 < NQ) wn = philox4x32_10(seed, c0, c1_0 + (uint32_t) (q + 1) * c1_step, c2, c3);
+        __builtin_amdgcn_sched_barrier(0);
+        bool s0, s1, s2, s3;
+        z[4 * q] = zig_candidate(w.x, e0, s0);
+        z[4 * q + 1] = zig_candidate(w.y, e1, s1);
+        z[4 * q + 2] = zig_candidate(w.z, e2, s2);
+        z[4 * q + 3] = zig_candidate(w.w, e3, s3);
+        pend |= ((s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u)) << (4 * q);
+    }
+    return pend;
 }
 
 // draw `slot` of call c1, which normal_quad_fast reported unsettled (the call is recomputed)
@@ -295,10 +327,12 @@ __device__ inline void normal_quad(uint64_t seed, uint32_t c0, uint32_t c1, uint
 {
     const u32x4 w = philox4x32_10(seed, c0, c1, c2, c3);
     bool s0, s1, s2, s3;
-    z0 = zig_candidate(w.x, tab, s0);
-    z1 = zig_candidate(w.y, tab, s1);
-    z2 = zig_candidate(w.z, tab, s2);
-    z3 = zig_candidate(w.w, tab, s3);
+    const double2 e0 = tab[w.x & 1023u], e1 = tab[w.y & 1023u], e2 = tab[w.z & 1023u],
+            e3 = tab[w.w & 1023u];
+    z0 = zig_candidate(w.x, e0, s0);
+    z1 = zig_candidate(w.y, e1, s1);
+    z2 = zig_candidate(w.z, e2, s2);
+    z3 = zig_candidate(w.w, e3, s3);
     if (!(s0 && s1 && s2 && s3)) {
         if (!s0) z0 = zig_slow(seed, c0, c1, 0, c2, c3, w.x & 1023u, (w.x >> 10) | 1u, (w.x >> 10) & 1u, tab, zig_global_f());
         if (!s1) z1 = zig_slow(seed, c0, c1, 1, c2, c3, w.y & 1023u, (w.y >> 10) | 1u, (w.y >> 10) & 1u, tab, zig_global_f());
