@@ -524,16 +524,31 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
             // one base the upper half costs a vector add per read)
             int hi = lane + 8192;
             asm volatile("" : "+v"(hi));          // (opaque: keeps the second base in its register)
+            auto frag = [&](int i, int t) {
+                const int idx = (i >> 3) * 8 + t * 32 + (i & 7);          // fragment number
+                return idx < 128 ? bd[lane + idx * 64] : bd[hi + (idx - 128) * 64];
+            };
+            // The scheduling barrier every four k-steps (it keeps the scheduler from hoisting the
+            // operand reads of all 32 k-steps at once) also makes every group START with its reads:
+            // its first MFMA waited for a fresh LDS round trip, eight times per tile.  The eight
+            // fragments of a group's first k-step are therefore read at the end of the group before.
+            double pre[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) pre[t] = frag(0, t);
 #pragma unroll
             for (int i = 0; i < 32; i++) {
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    const int idx = (i >> 3) * 8 + t * 32 + (i & 7);      // fragment number
-                    const double bv = idx < 128 ? bd[lane + idx * 64] : bd[hi + (idx - 128) * 64];
+                    const double bv = (i & 3) == 0 ? pre[t] : frag(i, t);
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[i], bv, acc[t], 0, 0, 0);
                 }
-                // (keeps the scheduler from hoisting the operand loads of all 32 k-steps at once)
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if ((i & 3) == 3) {
+                    if (i + 1 < 32) {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) pre[t] = frag(i + 1, t);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
             // eight k-steps at a time: draw a[i] = z[row][4 (8 kc + i) + fk] (two Philox calls),
