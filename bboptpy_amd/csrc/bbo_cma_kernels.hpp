@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(256) void cma_gram(CmaDev d, CmaConst c, int ldy)
 // grid (splits, P), 256 threads, 2 workgroups per CU
 // ---------------------------------------------------------------------------
 constexpr int G128_CH = 32;          // rows per chunk
-constexpr int G128_PACE = 4;         // cma_gram128s: chunks between two pacing barriers
+constexpr int G128_PACE = 2;         // cma_gram128s: chunks between two pacing barriers (1, 2: 366 us; 4: 370; 8: 371; none: 374)
 constexpr int G128_LDY = 128 + 16;
 constexpr int G128_TI[4][9] = { { 5, 5, 5, 6, 6, 6, 7, 7, 7 }, { 2, 2, 2, 3, 3, 3, 4, 4, 4 },
         { 5, 5, 6, 6, 7, 7, 3, 4, 4 }, { 0, 1, 1, 5, 6, 6, 7, 7, 7 } };
