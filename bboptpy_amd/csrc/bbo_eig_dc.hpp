@@ -174,6 +174,27 @@ __device__ inline double dc_team_sum(double v, double *red, const DcTeam &tm)
     return s;
 }
 
+// the same sum (same order, same bits) + "some thread of the team raised its flag", on the same two
+// barriers: the flags travel in the upper half of red (a workgroup has at most 8 wavefronts)
+__device__ inline double dc_team_sum_flag(double v, bool flag, bool &any, double *red, const DcTeam &tm)
+{
+    v = eig_wave_sum(v);
+    const bool wf = __ballot(flag) != 0ull;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = v;
+        red[8 + (threadIdx.x >> 6)] = wf ? 1. : 0.;
+    }
+    __syncthreads();
+    double s = 0., f = 0.;
+    for (int w = 0; w < tm.nwaves; w++) {
+        s += red[tm.wave0 + w];
+        f += red[8 + tm.wave0 + w];
+    }
+    any = f != 0.;
+    return s;
+}
+
 __device__ inline double dc_team_max(double v, double *red, const DcTeam &tm)
 {
     v = dc_wave_max(v);
@@ -220,12 +241,23 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
 
     // ---- poles and z, ascending -------------------------------------------------------
     double zi = 0., di = 0.;
+    // The binary-search ranking below is a permutation only if EACH input list ascends in dc_key.
+    // Finite output of a merge does (rankings by key); a block contaminated by NaN / Inf need not
+    // (keys [inf, 1] against [2] would rank 1, 1, 0 and leave a slot of the index maps unwritten:
+    // the fault class of DESIGN.md section 4).  Every entry tests its own predecessor; a violation
+    // rides on the reduction of |z|^2 (no extra barrier) and selects ranking by counting.
+    bool unsorted = false;
     if (ttid < m) {
         const int col = a + ttid;
         di = dv[col];
         zi = col < mid ? Q(mid - 1, col) : sgn * Q(mid, col);
+        if (tm.sorted_in) {
+            const double dprev = dv[max(col - 1, a)];
+            unsorted = ttid > 0 && col != mid && dc_key(dprev) > dc_key(di);
+        }
     }
-    const double zn2 = dc_team_sum(ttid < m ? zi * zi : 0., W.red, tm);
+    bool any_unsorted;
+    const double zn2 = dc_team_sum_flag(ttid < m ? zi * zi : 0., unsorted, any_unsorted, W.red, tm);
     const double zn = dc_sqrt(zn2);
     const double rho = fabs(rho_in) * zn2;
     if (ttid < m) {
@@ -236,7 +268,8 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     __syncthreads();
     if (ttid < m) {
         const int m1 = mid - a;
-        const int r = !tm.sorted_in ? dc_rank_of(W.lam, m, dc_key(di), ttid)
+        const bool by_search = tm.sorted_in && !any_unsorted;
+        const int r = !by_search ? dc_rank_of(W.lam, m, dc_key(di), ttid)
                 : ttid < m1 ? ttid + dc_count_before(W.lam + m1, m - m1, dc_key(di), false)
                             : (ttid - m1) + dc_count_before(W.lam, m1, dc_key(di), true);
         W.dS[r] = di;
@@ -568,6 +601,12 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             W.mu[j] = mu;
             W.org[j] = o;
             W.lam[j] = dorg;       // (the origin pole itself, for the Loewner products below)
+            // root j lies in [d_j, d_j+1] -- in floating point too, for finite input -- which is what
+            // puts the roots in ascending order for the output ranking below.  Where it does not
+            // hold (NaN / Inf in the merge) the flag of the sequential deflation scan, consumed
+            // by now, sends that ranking to the form that is a permutation whatever the data.
+            const double lj = dorg + mu;
+            if (!(lj >= dj && lj <= dn)) W.cnt[3] = 1;
         }
         if (on && k == 1 && ttid == 0) {
             W.mu[0] = rho * W.w2[0];
@@ -657,7 +696,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     // neighbour, in floating point too -- and so do the deflated poles unless a rotation changed them)
     if (ttid < m) {
         const double key = dc_key(W.lam[ttid]);
-        W.outpos[ttid] = nr > 0 ? dc_rank_of(W.lam, m, key, ttid)
+        W.outpos[ttid] = (nr > 0 || W.cnt[3] != 0) ? dc_rank_of(W.lam, m, key, ttid)
                 : ttid < k ? ttid + dc_count_before(W.lam + k, nd, key, false)
                            : (ttid - k) + dc_count_before(W.lam, k, key, true);
     }

@@ -300,13 +300,18 @@ def test_eigendecomposition_special_matrices(hip, n):
         assert np.linalg.norm(isc @ Cm @ isc - np.eye(n)) <= 1e-13 * cond * n + 1e-10 * n, name
 
 
-@pytest.mark.parametrize("n", [10, 16, 40, 128, 200])
+@pytest.mark.parametrize("n", [10, 16, 40, 128, 200, 256, 300, 512])
 def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     """The QL leaves stop after 30 sweeps per eigenvalue (ql_produce_reg), so a covariance with
     NaN, Inf or subnormal entries cannot hang the GPU: the phase returns, marks the decomposition
     done, and a later well-formed C decomposes correctly again.  (The reference's tql2 has no
     sweep limit, cmaes.cpp:383-456; what it returns for such input is unspecified, so nothing
-    about the VALUES is asserted here.)"""
+    about the VALUES is asserted here.)  Every eigensolver kernel is covered: cma_eigen_small
+    (n <= 16), cma_eigen (LDS matrix), cma_eigen_g below and AT its full size 256 (on-chip
+    symmetric steps + external top merge) and cma_eigen_b (n > 256: merges in global memory, index
+    maps from rankings); the contaminated entries sit at the head, in the middle and at the tail so
+    that merges at every level meet non-finite poles on either side (the sorted-list ranking falls
+    back to ranking by counting there, bbo_eig_dc.hpp)."""
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
     g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
@@ -320,6 +325,9 @@ def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     bad.append(good * 1e-300)                       # products of entries underflow
     bad.append(good * 1e-310)                       # subnormal entries
     m = good * 1e-300; m[n - 1, n - 1] = 1e300; bad.append(m)
+    m = good.copy(); m[n // 2, n // 2] = np.inf; m[n - 1, n - 1] = -np.inf; bad.append(m)
+    m = good.copy(); m[n - 1, :] = m[:, n - 1] = np.nan; m[n // 4, n // 4] = np.inf; bad.append(m)
+    m = np.diag(np.arange(1., n + 1)); m[(2 * n) // 3, (2 * n) // 3] = np.nan; bad.append(m)
     for Cm in bad + [good]:
         g.set_state("C", 0.5 * (Cm + Cm.T))
         g.set_state("fev", [10 ** 6])
