@@ -498,7 +498,6 @@ int CcpsoEngine::set(const std::string &k, int p, const double *in, int count)
     // the re-weighted context vector, its value, the evaluations it spent, the `improved` flag
     BBO_HIP(hipSetDevice(params_.device));
     BBO_HIP(hipStreamSynchronize(stream_));      // (uploads below are not stream-ordered)
-    BBO_HIP(hipStreamSynchronize(stream_));
     if (k == "yhat") {
         BBO_REQUIRE(count == c_.n, "set yhat: wrong element count");
         std::vector<double> v(c_.ld, 0.);

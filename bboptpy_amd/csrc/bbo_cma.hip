@@ -16,7 +16,7 @@ namespace bbo {
 namespace {
 
 // kernel slots of the profile report (bbo_get "profile"), in launch order
-enum { K_SAMPLE = 0, K_RANK, K_WHITEN, K_GRAM, K_PATHS, K_COV, K_EIGEN, K_POST, K_STOP, K_DRAW, K_COUNT };
+enum { K_SAMPLE = 0, K_RANK, K_WHITEN, K_GRAM, K_PATHS, K_COV, K_EIGEN, K_POST, K_STOP, K_COUNT };
 
 int pick_maxt(int ld)
 {
@@ -61,19 +61,12 @@ CmaEngine::CmaEngine(const bbo_params &p) :
 
 CmaEngine::~CmaEngine()
 {
-    if (draw_stream_) {
-        (void) hipStreamSynchronize(draw_stream_);
-        (void) hipStreamDestroy(draw_stream_);
-    }
-    if (ev_sampled_) (void) hipEventDestroy(ev_sampled_);
-    if (ev_drawn_) (void) hipEventDestroy(ev_drawn_);
     if (stream_) (void) hipStreamDestroy(stream_);
     if (stop_host_) (void) hipHostFree(stop_host_);
 }
 
 void CmaEngine::set_params(int np, double sigma, int mfev)
 {
-    drop_draw();
     params_.np = np;
     params_.sigma0 = sigma;
     params_.mfev = mfev;
@@ -86,9 +79,6 @@ void CmaEngine::set_params(int np, double sigma, int mfev)
 void CmaEngine::init(int n, const double *lower, const double *upper, const double *guess,
         const ObjectiveSpec &obj)
 {
-    // (normals drawn ahead belong to the run that is being replaced)
-    if (draw_stream_) BBO_HIP(hipStreamSynchronize(draw_stream_));
-    drop_draw();
     const bool sep = params_.algo == BBO_ALGO_SEP_CMAES;
     if (sep)
         BBO_REQUIRE(n >= 1 && n <= 4096, "SepCMAES: dimension must be in [1, 4096]");
@@ -382,17 +372,8 @@ void CmaEngine::launch_sample_eval()
         // the lean build of the tile loop where nothing needs guarding (M, C3)
         const int full = (c.n == 128 && !c.bound && c.lambda == c.lambda_pad && !d_.zinject
                 && !d_.zrecord && !(d_.dbg & 256)) ? 1 : 0;
-        if (pending_draw_ && full && async_draw_ok()) {
-            // this generation's normals were drawn while the last one updated (enqueue_draw)
-            BBO_HIP(hipStreamWaitEvent(stream_, ev_drawn_, 0));
-            allow_lds((const void*) cma_sample_eval128z, 128 * 1024);
-            hipLaunchKernelGGL(cma_sample_eval128z, grid, dim3(512), 128 * 1024, stream_, d_, c_,
-                    rw);
-        } else {
-            hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_,
-                    rw, full);
-        }
-        pending_draw_ = false;
+        hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw,
+                full);
         zn_valid = true;
     } else if (c.ld <= 128) {
         // 64 candidates per workgroup, packed operand held in registers
@@ -423,56 +404,6 @@ void CmaEngine::launch_sample_eval()
     BBO_HIP(hipGetLastError());
     // ||z||^2 stands in for the whitened norm only if this launch wrote it and no x was clamped
     c_.use_zn = (zn_valid && !c.bound) ? 1 : 0;
-}
-
-// The lean n = 128 sampler's normals depend on (seed, population, candidate, column, generation)
-// only: the NEXT generation's can be drawn while this one is ranked, updated and decomposed
-// (cma_draw128 on a second stream, cma_sample_eval128z reads them).  OFF by default, diagnostic
-// bit 2048 turns it on -- measured at M (256 x 4096, round 3): the sampler drops from 756 to 631 us
-// (0.71 of the fp64 peak with the draw gone), but the draw as a kernel of its own takes 218 us of
-// the whole chip's vector pipes, the kernels it could hide behind (rank, paths, cov, stop: ~130 us,
-// and cma_gram / cma_eigen fill the register file: nothing co-resides with them) are shorter than
-// that, and its resident workgroups keep cma_whiten128 / cma_eigen workgroups waiting for a free
-// CU: the STEP went from 1.846 to 1.993 ms.  Inside the sampler the same instructions cost 125 us
-// (they fill issue gaps of the sweep).  Kept because it is bit-identical by construction and
-// tested, and because it is the measurement DESIGN.md section 6 quotes.
-bool CmaEngine::async_draw_ok() const
-{
-    const CmaConst &c = c_;
-    return (d_.dbg & 2048) && c.variant != 2 && c.ld == 128 && c.n == 128 && !c.bound
-            && c.lambda == c.lambda_pad && (long) c.npop * c.lambda_pad >= 256 * 128
-            && obj_.on_device() && (c.obj < 0 || frag_objective_ok(c.obj)) && !d_.zinject
-            && !d_.zrecord && !(d_.dbg & 256);
-}
-
-void CmaEngine::enqueue_draw()
-{
-    const CmaConst &c = c_;
-    if (!draw_stream_) {
-        int lo = 0, hi = 0;
-        BBO_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // (lo = the LEAST urgent)
-        BBO_HIP(hipStreamCreateWithPriority(&draw_stream_, hipStreamNonBlocking, lo));
-        BBO_HIP(hipEventCreateWithFlags(&ev_sampled_, hipEventDisableTiming));
-        BBO_HIP(hipEventCreateWithFlags(&ev_drawn_, hipEventDisableTiming));
-    }
-    const size_t need = (size_t) c.npop * c.lambda_pad * 128;
-    if (zbuf_.count != need) {
-        BBO_HIP(hipStreamSynchronize(draw_stream_));
-        zbuf_.alloc(need);
-    }
-    d_.zbuf = zbuf_.p;       // (init() rebuilds d_)
-    // behind the sampler just launched (it reads the buffer this draw overwrites, and it tells
-    // the draw which generation is next: CmaScal::zreq)
-    BBO_HIP(hipEventRecord(ev_sampled_, stream_));
-    BBO_HIP(hipStreamWaitEvent(draw_stream_, ev_sampled_, 0));
-    const int tiles = c.lambda_pad >> 4;
-    timer_.begin(draw_stream_, K_DRAW);
-    hipLaunchKernelGGL(cma_draw128, dim3((tiles + 4 * DRAW_TPW - 1) / (4 * DRAW_TPW), c.npop),
-            dim3(256), 0, draw_stream_, d_, c_);
-    timer_.end(draw_stream_);
-    BBO_HIP(hipGetLastError());
-    BBO_HIP(hipEventRecord(ev_drawn_, draw_stream_));
-    pending_draw_ = true;
 }
 
 void CmaEngine::launch_rank()
@@ -699,7 +630,6 @@ void CmaEngine::generation(bool honor_stop)
     }
     c_.honor_stop = honor_stop ? 1 : 0;
     launch_sample_eval();
-    if (async_draw_ok()) enqueue_draw();     // generation g + 1's normals, beside what follows
     if (!obj_.on_device()) host_evaluate();
     launch_rank();
     launch_update();
@@ -724,14 +654,12 @@ void CmaEngine::phase(int which)
     default: throw Error(BBO_ERR_ARG, "unknown CMA phase");
     }
     BBO_HIP(hipStreamSynchronize(stream_));
-    if (draw_stream_) BBO_HIP(hipStreamSynchronize(draw_stream_));
     timer_.collect();
 }
 
 void CmaEngine::inject_normals(const double *z, int count)
 {
     BBO_REQUIRE(inited_, "inject_normals before init");
-    drop_draw();
     if (!z) {
         d_.zinject = nullptr;
         return;
@@ -749,7 +677,6 @@ void CmaEngine::iterate()
     BBO_HIP(hipSetDevice(params_.device));
     generation(false);
     BBO_HIP(hipStreamSynchronize(stream_));
-    if (draw_stream_) BBO_HIP(hipStreamSynchronize(draw_stream_));
     timer_.collect();
 }
 
@@ -797,8 +724,7 @@ int CmaEngine::run(int max_generations)
         else
             for (int g = 0; g < chunk; g++) generation(true);
         BBO_HIP(hipStreamSynchronize(stream_));
-        if (draw_stream_) BBO_HIP(hipStreamSynchronize(draw_stream_));
-        timer_.collect();
+            timer_.collect();
         done += chunk;
     }
     return done;
@@ -1062,7 +988,6 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     if (!inited_) throw Error(BBO_ERR_STATE, "set() before initialize()");
     BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
     BBO_HIP(hipSetDevice(params_.device));
-    drop_draw();      // (whatever changes: the next sampler draws for itself)
     BBO_HIP(hipStreamSynchronize(stream_));
     const CmaConst &c = c_;
     const size_t ld = c.ld, n = c.n;

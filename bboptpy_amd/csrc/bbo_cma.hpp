@@ -24,7 +24,7 @@ struct CmaScal {
     int eigenlastev, eigen_done;
     int hist_head, hist_len;
     int basis_ok;             // C^-1/2 = B D^-1 B^T for the (B, D) the sampler uses (see cma_whiten128)
-    int zreq;                 // the generation cma_draw128 draws next (= it + 1, written by the sampler)
+    int pad0_;
     int pad_;
 };
 
@@ -66,8 +66,6 @@ struct CmaDev {
     double *S;          // [P][mu_pad]  whitened squared norms of the worst mu
     double *csep;       // [P][ld] diagonal covariance of the separable variant (D = its sqrt)
     double *zn2;        // [P][lambda_pad] ||z||^2 of every candidate (cma_sample_eval128 only)
-    double *zbuf;       // [P][lambda_pad/16][16][64][2] next generation's normals in A-fragment order
-                        // (cma_draw128 -> cma_sample_eval128z), or null
     double *gram_part;  // [P][splits][ld][ld]
     double *mean_part;  // [P][splits][ld]
     double *hist_best, *hist_kth;     // [P][hlen]
@@ -113,9 +111,6 @@ private:
     bool small_fused_ok() const;
     void launch_small(int gens, bool honor_stop);
     void launch_sample_eval();
-    bool async_draw_ok() const;
-    void enqueue_draw();
-    void drop_draw() { pending_draw_ = false; }
     void launch_post(int mode);
     void launch_rank();
     void launch_update();
@@ -130,18 +125,12 @@ private:
     CmaConst c_ {};
     CmaDev d_ {};
     hipStream_t stream_ = nullptr;
-    // next generation's normals, drawn on a second (low-priority) stream while this generation
-    // ranks / updates / decomposes (cma_draw128): ev_sampled_ orders the draw behind the sampler
-    // that reads the previous buffer, ev_drawn_ the next sampler behind the draw
-    hipStream_t draw_stream_ = nullptr;
-    hipEvent_t ev_sampled_ = nullptr, ev_drawn_ = nullptr;
-    bool pending_draw_ = false;      // the buffer holds (or will hold) the NEXT generation's normals
     bool inited_ = false;
     bool keep_bc_ = false;    // B and C survive a re-init of the same object (cmaes.cpp:53-54)
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;
 
-    DevBuf<double> zn2_, csep_, zbuf_;
+    DevBuf<double> zn2_, csep_;
     DevBuf<double> X_, f_, xmean_, xold_, pc_, ps_, C_, B_, D_, isc_, BDp_, ISp_, S_,
             gram_part_, mean_part_, hist_best_, hist_kth_, eig_work_, weights_, lower_,
             upper_, aux_, zinject_, zrecord_;

@@ -447,12 +447,7 @@ __device__ inline void sample128_epilogue(const CmaDev &d, const CmaConst &c, in
     }
 }
 
-// ZBUF (with FULL): the 32 normals of a lane come from d.zbuf, where cma_draw128 left them in
-// this very register order, instead of being drawn here -- the draw is 1360 of the 1940 vector
-// instructions a tile costs next to its 256 MFMAs, and the fp64 matrix instruction shares its pipe
-// with every one of them.  The next tile's chunks are requested as soon as the k-steps that read
-// the registers they land in have been issued: loads do not occupy the vector pipe.
-template<bool FULL, bool ZBUF = false>
+template<bool FULL>
 __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaConst &c,
         int rows_per_wg, double *bd, const double2 *ntab, const double *ftab, const double *xms)
 {
@@ -467,14 +462,6 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
     const int fr = lane & 15, fk = lane >> 4;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
 
-    // ZBUF: chunk j of a tile = (z[2 j], z[2 j + 1]) of every lane, 1 KB per wavefront load
-    const double2 *zsrc = ZBUF ? reinterpret_cast<const double2*>(d.zbuf)
-                    + ((size_t) p * (c.lambda_pad >> 4) + (row0 >> 4)) * 1024 + lane : nullptr;
-    double2 zc[16];
-    if (ZBUF && wave < tiles) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) zc[j] = zsrc[(size_t) wave * 1024 + j * 64];
-    }
     for (int tile = wave; tile < tiles; tile += 8) {
         const int rowbase = row0 + tile * 16;
         const int row = rowbase + fr;
@@ -482,27 +469,7 @@ __device__ __forceinline__ void sample_eval128_body(const CmaDev &d, const CmaCo
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[t] = d4_t { 0., 0., 0., 0. };
         double zz = 0.;
-        if (FULL && ZBUF) {
-            const bool more = tile + 8 < tiles;
-            const double2 *znext = zsrc + (size_t) (more ? tile + 8 : tile) * 1024;
-#pragma unroll
-            for (int j = 0; j < 16; j++) zz = __builtin_fma(zc[j].y, zc[j].y, __builtin_fma(zc[j].x, zc[j].x, zz));
-            int hi = lane + 8192;
-            asm volatile("" : "+v"(hi));
-#pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const double zi = (i & 1) ? zc[i >> 1].y : zc[i >> 1].x;
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const int idx = (i >> 3) * 8 + t * 32 + (i & 7);      // fragment number
-                    const double bv = idx < 128 ? bd[lane + idx * 64] : bd[hi + (idx - 128) * 64];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zi, bv, acc[t], 0, 0, 0);
-                }
-                // both k-steps of chunk i >> 1 are issued: its registers take the next tile's chunk
-                if (i & 1) zc[i >> 1] = znext[(i >> 1) * 64];
-                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (FULL) {
+        if (FULL) {
             // the 32 normals this lane feeds: z[4 q + i] = Z[row][16 q + fk + 4 i], i.e. the A
             // elements of k-steps 4 q .. 4 q + 3; candidates first, the unsettled draws of all
             // eight calls together afterwards (normal_quad_fast)
@@ -592,7 +559,6 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
     if (pop_frozen(c, sc)) return;
     extern __shared__ __attribute__((aligned(16))) double bd[];
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) d.scal[p].zreq = sc->it + 1;    // what cma_draw128 draws next
     {
         const double2 *src = reinterpret_cast<const double2*>(d.BDp + (size_t) p * 128 * 128);
         double2 *dst = reinterpret_cast<double2*>(bd);
@@ -608,79 +574,6 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
     __syncthreads();
     if (full) sample_eval128_body<true>(d, c, rows_per_wg, bd, ntab, ftab, xms);
     else sample_eval128_body<false>(d, c, rows_per_wg, bd, ntab, ftab, xms);
-}
-
-// The lean build with the normals PRE-DRAWN (d.zbuf, written by cma_draw128 for exactly this
-// generation on the engine's second stream while the previous generation ranked, updated and
-// decomposed).  Same sweep, same epilogue, same bits; no generator tables in LDS.
-__global__ __launch_bounds__(512, 1) void cma_sample_eval128z(CmaDev d, CmaConst c, int rows_per_wg)
-{
-    const int p = blockIdx.y;
-    const CmaScal *sc = d.scal + p;
-    if (pop_frozen(c, sc)) return;
-    extern __shared__ __attribute__((aligned(16))) double bd[];
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) d.scal[p].zreq = sc->it + 1;
-    {
-        const double2 *src = reinterpret_cast<const double2*>(d.BDp + (size_t) p * 128 * 128);
-        double2 *dst = reinterpret_cast<double2*>(bd);
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[tid + 512 * i] = src[tid + 512 * i];
-    }
-    __shared__ double xms[128];
-    if (tid < 128) xms[tid] = d.xmean[(size_t) p * 128 + tid];
-    __syncthreads();
-    sample_eval128_body<true, true>(d, c, rows_per_wg, bd, nullptr, nullptr, xms);
-}
-
-// The draw of generation sc->zreq for the lean n = 128 sampler, as a kernel of its own: lane
-// (fr, fk) of the wavefront that owns tile T draws the 32 normals z[4 q + i] =
-// Z[16 T + fr][16 q + fk + 4 i] (eight Philox calls, two-step ziggurat: exactly the statements of
-// sample_eval128_body<true>) and stores them as 16 chunks (z[2 j], z[2 j + 1]) at
-// zbuf[p][T][j][lane] -- the register order the sweep consumes, 1 KB per wavefront store.
-// grid (ceil(tiles / (4 * DRAW_TPW)), P), 256 threads; runs beside the rank / paths / cov / stop
-// kernels, which leave the vector pipes idle.  Short workgroups (DRAW_TPW tiles per wavefront)
-// on purpose: a resident draw workgroup keeps cma_eigen's workgroup (a whole CU) waiting.
-constexpr int DRAW_TPW = 4;
-__global__ __launch_bounds__(256) void cma_draw128(CmaDev d, CmaConst c)
-{
-    const int p = blockIdx.y;
-    const CmaScal *sc = d.scal + p;
-    if (pop_frozen(c, sc)) return;
-    __shared__ double2 ntab[NORMAL_TABLE_N];
-    __shared__ double ftab[NORMAL_FTABLE_N];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    normal_table_fill(ntab, tid, 256);
-    normal_ftable_fill(ftab, tid, 256);
-    __syncthreads();
-    const int gen = sc->zreq;
-    const int tiles = c.lambda_pad >> 4;
-    const int fr = lane & 15, fk = lane >> 4;
-    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
-    for (int k = 0; k < DRAW_TPW; k++) {
-        const int tile = (blockIdx.x * 4 + wave) * DRAW_TPW + k;
-        if (tile >= tiles) break;
-        const int row = tile * 16 + fr;
-        double z[32];
-        uint32_t pend = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            pend |= normal_quad_fast(c.seed, (uint32_t) row, (uint32_t) (4 * q + fk),
-                    (uint32_t) gen, sw, ntab, z[4 * q], z[4 * q + 1], z[4 * q + 2],
-                    z[4 * q + 3]) << (4 * q);
-        while (pend) {
-            const int b = __ffs(pend) - 1;
-            pend &= pend - 1;
-            const double v = normal_quad_settle(c.seed, (uint32_t) row,
-                    (uint32_t) (4 * (b >> 2) + fk), (uint32_t) (b & 3), (uint32_t) gen, sw,
-                    ntab, ftab);
-#pragma unroll
-            for (int i = 0; i < 32; i++) z[i] = (i == b) ? v : z[i];
-        }
-        double2 *dst = reinterpret_cast<double2*>(d.zbuf) + ((size_t) p * tiles + tile) * 1024 + lane;
-#pragma unroll
-        for (int j = 0; j < 16; j++) dst[j * 64] = make_double2(z[2 * j], z[2 * j + 1]);
-    }
 }
 
 // ---------------------------------------------------------------------------

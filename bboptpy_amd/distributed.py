@@ -60,13 +60,29 @@ def _group_wanted(group, world_size):
     return world_size is None and (group is not None or os.environ.get("RANK") is not None)
 
 
+def _default_device(device):
+    """the GPU of this process when the caller named none: LOCAL_RANK under torchrun (one process
+    per GPU -- with 0 for everybody every rank of an RCCL group would sit on cuda:0, which RCCL
+    refuses as 'Duplicate GPU'), else torch's current device if torch has one, else 0"""
+    import os
+    import sys
+    if device is not None:
+        return int(device)
+    if os.environ.get("LOCAL_RANK") is not None:
+        return int(os.environ["LOCAL_RANK"])
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    return 0
+
+
 def _device_of(dist, group, device):
-    """where the collective's buffers live: the engine's own GPU under nccl (NOT torch's current
-    device -- the caller may never have called torch.cuda.set_device), host memory otherwise"""
+    """where the collective's buffers live: the engine's own GPU under nccl (the same
+    _default_device the engine was created on), host memory otherwise"""
     import torch
     if dist.get_backend(group) != "nccl":
         return torch.device("cpu")
-    return torch.device("cuda", int(device or 0))
+    return torch.device("cuda", _default_device(device))
 
 
 _GOLDEN = 0x9E3779B97F4A7C15
@@ -107,27 +123,16 @@ class _State:
         self.history = []
 
 
-class ConcurrentBiPop:
-    """BIPOP/NBIPOP-CMA-ES with world_size concurrent restart populations.
+class _ConcurrentRestarts:
+    """rounds of world_size * slots_per_rank concurrent restart runs: topology, the restart
+    stream's draws, the inner runs, ONE all-gather of (n + 7) doubles per slot and round, the
+    replicated reduction.  Subclasses state a schedule: plan_round / apply_round / finished."""
 
-    Parameters mirror BiPopCMAES(base, mfev, print, sigma0, maxlargeruns, nbipop, ksigmadec,
-    kbudget) (py/multivariate_py.cpp:144-151); instead of a `base` object the inner optimizer
-    is described by `variant` ("active" | "cmaes") and `tol`.  `group` is a torch.distributed
-    process group (None = the default group, or no collective at all when torch.distributed is
-    not initialised: a single-process run).  `runner(lam, sigma, maxfev, x0, seed) -> (x,
-    evaluations_used, f(x))` replaces the device run in the CPU tests.  `slots_per_rank` > 1 packs
-    several concurrent restart populations onto each GPU (a rank's slots of a round run at the same
-    time on separate engines / HIP streams); a round has world_size * slots_per_rank slots and
-    the plan, the seeds and the reduction depend on the global slot only, so (W ranks, S slots)
-    and (W S ranks, 1 slot) produce the same history.
-    """
+    _name = "ConcurrentRestarts"
 
-    def __init__(self, mfev, tol=1e-8, sigma0=2., maxlargeruns=9, nbipop=True, ksigmadec=1.6,
-                 kbudget=2., variant="active", seed=0, device=None, group=None, runner=None,
-                 world_size=None, rank=None, slots_per_rank=1):
+    def _common(self, mfev, tol, sigma0, variant, seed, device, group, runner, world_size, rank,
+                slots_per_rank):
         self.mfev, self.tol, self.sigma0 = int(mfev), float(tol), float(sigma0)
-        self.maxlargeruns, self.nbipop = int(maxlargeruns), bool(nbipop)
-        self.ksigmadec, self.kbudget = float(ksigmadec), float(kbudget)
         self.variant, self.seed = variant, int(seed) & _M64
         self.device, self.group, self.runner = device, group, runner
         self._world, self._rank = world_size, rank
@@ -138,7 +143,7 @@ class ConcurrentBiPop:
         self.slots = max(1, int(slots_per_rank))
         self._algs = {}
         if _group_wanted(group, world_size):
-            torch_first("ConcurrentBiPop")
+            torch_first(self._name)
 
     # -- topology ---------------------------------------------------------------------------
     def _topology(self):
@@ -171,6 +176,118 @@ class ConcurrentBiPop:
         `uniform`), so a plan does not depend on which rank executes the run"""
         w = philox4x32_10(self.seed, run & 0xFFFFFFFF, k, 0, _STREAM_RESTART << 24)
         return _u01(w[0], w[1]) * (b - a) + a
+
+    # -- one inner run on this rank's GPU -----------------------------------------------------
+    def _device_run(self, f, lam, sigma, maxfev, x0, seed, slot=0):
+        """like the reference's drivers (bipop_cmaes.cpp:83-87): ONE inner optimizer per driver
+        (here: per slot), re-parameterised through setParams before every run -- so B and C
+        keep their off-diagonals from this slot's previous run (cmaes.cpp:53-59) -- and one
+        extra evaluation of the point it returns"""
+        if slot not in self._algs:
+            cls = ActiveCMAES if self.variant == "active" else CMAES
+            self._algs[slot] = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
+                                   device=_default_device(self.device))
+        alg = self._algs[slot]
+        alg.set_params(lam, sigma, maxfev)
+        alg.set_seed(seed)
+        sol = alg.optimize(f, self.lower, self.upper, x0)
+        return sol.x, sol.n_evals, alg.evaluate(sol.x)
+
+    def _run_slots(self, f, slots, st, total, first):
+        """the records of the slots first .. first + len(slots) - 1 of this round.  Device runs
+        of several slots go out concurrently (one host thread each: the C calls release the
+        GIL, every engine has its own HIP stream); a `runner` is called slot after slot."""
+        reclen = 7 + self.n
+
+        def one(k):
+            plan = slots[k]
+            r = _np.zeros(reclen)
+            if plan is None:
+                return r
+            s = first + k
+            seed = (self.seed + _GOLDEN * (st.round * total + s)) & _M64
+            if self.runner is not None:
+                x, used, fx = self.runner(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"],
+                                          seed)
+            else:
+                x, used, fx = self._device_run(f, plan["lam"], plan["sigma"], plan["maxfev"],
+                                               plan["x0"], seed, slot=s)
+            r[:7] = [1., plan["regime"], plan["lam"], plan["sigma"], plan["maxfev"], used, fx]
+            r[7:] = x
+            return r
+
+        live = [k for k in range(len(slots)) if slots[k] is not None]
+        if self.runner is not None or len(live) <= 1:
+            return [one(k) for k in range(len(slots))]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(live)) as pool:
+            return list(pool.map(one, range(len(slots))))
+
+    def optimize(self, f, lower, upper, guess):
+        self.lower = _np.ascontiguousarray(lower, dtype=_np.float64)
+        self.upper = _np.ascontiguousarray(upper, dtype=_np.float64)
+        self.guess = _np.ascontiguousarray(guess, dtype=_np.float64)
+        self.n = self.lower.size
+        self.lambdadef = 4 + int(3. * math.log(1. * self.n))
+        world, rank, dist = self._topology()
+        S = self.slots
+        total = world * S                     # slots of a round
+        st = _State()
+        self.state = st
+        reclen = 7 + self.n
+        while True:
+            slots = self.plan_round(st, total)
+            if all(p is None for p in slots):
+                break
+            if dist is not None:
+                import torch
+                mine = _np.concatenate(self._run_slots(f, slots[rank * S:(rank + 1) * S], st, total,
+                                                       rank * S))
+                dev = _device_of(dist, self.group, self.device)
+                mine_t = torch.from_numpy(mine).to(dev)
+                out = [torch.empty_like(mine_t) for _ in range(world)]
+                dist.all_gather(out, mine_t, group=self.group)
+                records = [r for t in out for r in t.cpu().numpy().reshape(S, reclen)]
+                self.collectives = getattr(self, "collectives", 0) + 1
+            else:
+                # no process group: every rank's slots run in this process, rank after rank (the
+                # serial stand-in for the collective -- same plan, same reduction)
+                records = []
+                for g in range(world):
+                    records += self._run_slots(f, slots[g * S:(g + 1) * S], st, total, g * S)
+            self.apply_round(st, slots, records)
+            if self.finished(st):
+                break
+        return MultivariateSolution(st.xbest, st.fev, False)
+
+
+class ConcurrentBiPop(_ConcurrentRestarts):
+    """BIPOP/NBIPOP-CMA-ES with world_size concurrent restart populations.
+
+    Parameters mirror BiPopCMAES(base, mfev, print, sigma0, maxlargeruns, nbipop, ksigmadec,
+    kbudget) (py/multivariate_py.cpp:144-151); instead of a `base` object the inner optimizer
+    is described by `variant` ("active" | "cmaes") and `tol`.  `group` is a torch.distributed
+    process group (None = the default group, or no collective at all when torch.distributed is
+    not initialised: a single-process run).  `runner(lam, sigma, maxfev, x0, seed) -> (x,
+    evaluations_used, f(x))` replaces the device run in the CPU tests.  `slots_per_rank` > 1 packs
+    several concurrent restart populations onto each GPU (a rank's slots of a round run at the same
+    time on separate engines / HIP streams); a round has world_size * slots_per_rank slots and
+    the plan, the seeds and the reduction depend on the global slot only, so (W ranks, S slots)
+    and (W S ranks, 1 slot) produce the same history.
+    """
+
+    _name = "ConcurrentBiPop"
+
+    def __init__(self, mfev, tol=1e-8, sigma0=2., maxlargeruns=9, nbipop=True, ksigmadec=1.6,
+                 kbudget=2., variant="active", seed=0, device=None, group=None, runner=None,
+                 world_size=None, rank=None, slots_per_rank=1):
+        self._common(mfev, tol, sigma0, variant, seed, device, group, runner, world_size, rank,
+                     slots_per_rank)
+        self.maxlargeruns, self.nbipop = int(maxlargeruns), bool(nbipop)
+        self.ksigmadec, self.kbudget = float(ksigmadec), float(kbudget)
+
+    def finished(self, st):
+        return st.largerestarts >= self.maxlargeruns or st.fev >= self.mfev
 
     def plan_round(self, st, world):
         """the W runs of round st.round: a list of dicts (or None for an idle slot)"""
@@ -248,88 +365,96 @@ class ConcurrentBiPop:
                                    used=used, fx=fx))
         st.round += 1
 
-    # -- one inner run on this rank's GPU -----------------------------------------------------
-    def _device_run(self, f, lam, sigma, maxfev, x0, seed, slot=0):
-        """like the reference's drivers (bipop_cmaes.cpp:83-87): ONE inner optimizer per driver
-        (here: per slot), re-parameterised through setParams before every run -- so B and C
-        keep their off-diagonals from this slot's previous run (cmaes.cpp:53-59) -- and one
-        extra evaluation of the point it returns"""
-        if slot not in self._algs:
-            cls = ActiveCMAES if self.variant == "active" else CMAES
-            self._algs[slot] = cls(mfev=maxfev, tol=self.tol, np=lam, sigma0=sigma, seed=seed,
-                                   device=self.device or 0)
-        alg = self._algs[slot]
-        alg.set_params(lam, sigma, maxfev)
-        alg.set_seed(seed)
-        sol = alg.optimize(f, self.lower, self.upper, x0)
-        return sol.x, sol.n_evals, alg.evaluate(sol.x)
 
-    def _run_slots(self, f, slots, st, total, first):
-        """the records of the slots first .. first + len(slots) - 1 of this round.  Device runs
-        of several slots go out concurrently (one host thread each: the C calls release the
-        GIL, every engine has its own HIP stream); a `runner` is called slot after slot."""
-        reclen = 7 + self.n
+class ConcurrentIPop(_ConcurrentRestarts):
+    """IPOP / NIPOP-aCMA-ES (IPopCmaes, src/multivariate/cma/ipop_cmaes.cpp:65-189) with
+    world_size concurrent restart populations -- the IPOP variant of the all-gather of
+    SURVEY.md section 8e, beside ConcurrentBiPop.
 
-        def one(k):
-            plan = slots[k]
-            r = _np.zeros(reclen)
-            if plan is None:
-                return r
-            s = first + k
-            seed = (self.seed + _GOLDEN * (st.round * total + s)) & _M64
-            if self.runner is not None:
-                x, used, fx = self.runner(plan["lam"], plan["sigma"], plan["maxfev"], plan["x0"],
-                                          seed)
+    The reference's schedule is a fixed sequence: run r >= 1 starts from a uniform point of the
+    box with lambda doubled (:122-133; with `boundlambda` the doubling is cycled at lambda_max =
+    10 n^2 -- to lambda_max if that is the nearer of the two, else back to lambda_def) and,
+    with `nipop`, sigma divided by `ksigmadec` down to 0.01 sigma0 (:134-137); only the
+    evaluation cap of a run depends on what the earlier runs used (:178-189).  Round k therefore
+    runs the NEXT world_size * slots_per_rank entries of that sequence side by side -- lambda_def
+    2^(kW+1) ... 2^(kW+W) while nothing cycles -- each charged its cap (the remaining budget
+    split evenly over the slots still to plan) until the real counts arrive with the round's ONE
+    all-gather of (n + 7) doubles per slot; every rank then applies the same reduction in slot
+    order (budget, incumbent on strict improvement :150-153).  With one slot per round every cap
+    is the reference's `mfev - fev` and the driver IS the sequential IPopCMAES / bbo_restart.hip,
+    draw for draw and bit for bit: run r takes its restart point from the RESTART Philox stream
+    at counter (r, k) and runs under the key seed + golden * r.
+
+    Parameters mirror IPopCMAES(base, mfev, print, sigma0, nipop, ksigmadec, boundlambda)
+    (py/multivariate_py.cpp:137-142); `variant` / `tol` describe the inner optimizer, the rest is
+    ConcurrentBiPop's."""
+
+    _name = "ConcurrentIPop"
+
+    def __init__(self, mfev, tol=1e-8, sigma0=2., nipop=True, ksigmadec=1.6, boundlambda=True,
+                 variant="active", seed=0, device=None, group=None, runner=None, world_size=None,
+                 rank=None, slots_per_rank=1):
+        self._common(mfev, tol, sigma0, variant, seed, device, group, runner, world_size, rank,
+                     slots_per_rank)
+        self.nipop, self.ksigmadec = bool(nipop), float(ksigmadec)
+        self.boundlambda = bool(boundlambda)
+
+    def finished(self, st):
+        return st.fev >= self.mfev                      # ipop_cmaes.cpp:171-173
+
+    def _next(self, lam, sigma):
+        """(lambda, sigma) of the run after one with (lam, sigma): ipop_cmaes.cpp:122-137"""
+        lam <<= 1
+        if self.boundlambda:
+            lmax = 10 * self.n * self.n
+            if lam > lmax:
+                lam = lmax if lam - lmax < lmax - (lam >> 1) else self.lambdadef
+        if self.nipop:
+            sigma = max(sigma / self.ksigmadec, 0.01 * self.sigma0)
+        return lam, sigma
+
+    def plan_round(self, st, world):
+        slots = []
+        fev = st.fev
+        lam = getattr(st, "lam", self.lambdadef)
+        sigma = getattr(st, "sigma", self.sigma0)
+        for s in range(world):
+            run = st.round * world + s
+            if fev >= self.mfev:
+                slots.append(None)
+                continue
+            if run == 0:
+                # the first default run from the user's guess (:89-96)
+                x0 = self.guess.copy()
+                lam, sigma = self.lambdadef, self.sigma0
             else:
-                x, used, fx = self._device_run(f, plan["lam"], plan["sigma"], plan["maxfev"],
-                                               plan["x0"], seed, slot=s)
-            r[:7] = [1., plan["regime"], plan["lam"], plan["sigma"], plan["maxfev"], used, fx]
-            r[7:] = x
-            return r
+                x0 = _np.array([self._uniform(run, j, self.lower[j], self.upper[j])
+                                for j in range(self.n)])
+                lam, sigma = self._next(lam, sigma)
+            maxfev = self._max_evals(lam, fev, world - s)
+            if maxfev <= 0:
+                slots.append(None)
+                continue
+            slots.append(dict(regime=0 if run == 0 else 1, lam=lam, sigma=sigma, maxfev=maxfev,
+                              x0=x0))
+            fev += maxfev + 1
+        return slots
 
-        live = [k for k in range(len(slots)) if slots[k] is not None]
-        if self.runner is not None or len(live) <= 1:
-            return [one(k) for k in range(len(slots))]
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=len(live)) as pool:
-            return list(pool.map(one, range(len(slots))))
-
-    def optimize(self, f, lower, upper, guess):
-        self.lower = _np.ascontiguousarray(lower, dtype=_np.float64)
-        self.upper = _np.ascontiguousarray(upper, dtype=_np.float64)
-        self.guess = _np.ascontiguousarray(guess, dtype=_np.float64)
-        self.n = self.lower.size
-        self.lambdadef = 4 + int(3. * math.log(1. * self.n))
-        world, rank, dist = self._topology()
-        S = self.slots
-        total = world * S                     # slots of a round
-        st = _State()
-        self.state = st
-        reclen = 7 + self.n
-        while True:
-            slots = self.plan_round(st, total)
-            if all(p is None for p in slots):
-                break
-            if dist is not None:
-                import torch
-                mine = _np.concatenate(self._run_slots(f, slots[rank * S:(rank + 1) * S], st, total,
-                                                       rank * S))
-                dev = _device_of(dist, self.group, self.device)
-                mine_t = torch.from_numpy(mine).to(dev)
-                out = [torch.empty_like(mine_t) for _ in range(world)]
-                dist.all_gather(out, mine_t, group=self.group)
-                records = [r for t in out for r in t.cpu().numpy().reshape(S, reclen)]
-                self.collectives = getattr(self, "collectives", 0) + 1
-            else:
-                # no process group: every rank's slots run in this process, rank after rank (the
-                # serial stand-in for the collective -- same plan, same reduction)
-                records = []
-                for g in range(world):
-                    records += self._run_slots(f, slots[g * S:(g + 1) * S], st, total, g * S)
-            self.apply_round(st, slots, records)
-            if st.largerestarts >= self.maxlargeruns or st.fev >= self.mfev:
-                break
-        return MultivariateSolution(st.xbest, st.fev, False)
+    def apply_round(self, st, slots, records):
+        for s, (plan, rec) in enumerate(zip(slots, records)):
+            if plan is None or rec[0] == 0.:
+                continue
+            used, fx, x = int(rec[5]), float(rec[6]), _np.array(rec[7:7 + self.n])
+            st.fev += used + 1          # +1: the re-evaluation of the returned point (:93-94, :145-146)
+            st.lam, st.sigma = plan["lam"], plan["sigma"]
+            if plan["regime"] == 1:
+                st.largerestarts += 1                  # (restarts so far: IPopCmaes::_it)
+            if st.xbest is None or fx < st.fxbest:
+                st.fxbest, st.xbest = fx, x
+            st.history.append(dict(round=st.round, slot=s, regime=plan["regime"],
+                                   lam=plan["lam"], sigma=plan["sigma"], maxfev=plan["maxfev"],
+                                   used=used, fx=fx))
+        st.round += 1
 
 
 class ShardedCCPSO:
@@ -375,7 +500,7 @@ class ShardedCCPSO:
         if self._factory is not None:
             return self._factory()
         from .multivariate import CCPSO
-        return CCPSO(seed=self.seed, device=self.device or 0, **self._ctor)
+        return CCPSO(seed=self.seed, device=_default_device(self.device), **self._ctor)
 
     def _topology(self):
         import os

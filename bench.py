@@ -68,7 +68,7 @@ WORKLOADS = {
 }
 
 CMA_KERNELS = ["cma_sample_eval", "cma_rank", "cma_whiten", "cma_gram", "cma_paths", "cma_cov",
-               "cma_eigen", "cma_post", "cma_history_stop", "cma_draw"]
+               "cma_eigen", "cma_post", "cma_history_stop"]
 DE_KERNELS = ["de_generation", "de_bookkeep", "de_archive_copy", "de_rank", "de_finish",
               "de_select"]
 PSO_KERNELS = ["pso_center", "pso_ese", "pso_control", "pso_update", "pso_finish"]
@@ -124,11 +124,6 @@ def cma_kernel_costs(n, lam, P):
     # (DESIGN.md "whitened norms"); beyond that it is the GEMM
     whiten = ("hbm", P * mu * 12) if n <= 256 else ("mfma", P * mu * 2 * n * n)
     return {
-        # (the lean n = 128 sampler: the next generation's normals are drawn by a kernel of their
-        # own on a second stream, beside rank / paths / cov / eigen / stop -- it OVERLAPS them, so
-        # the shares of a profiled pass add up to more than the step.  Priced in the bytes it
-        # writes; what bounds it is the vector pipe: ~170 instructions per Philox call)
-        "cma_draw": ("hbm", P * lam * n * 8),
         "cma_sample_eval": ("mfma", P * lam * (2 * n * n + 8 * n)),
         "cma_whiten": whiten,
         "cma_gram": ("mfma", P * lam * n * (n + 1)),      # lower triangle only, like the reference
@@ -300,14 +295,9 @@ def generations_to_ftarget(bb, wl, device, ftarget=1e-4, pops=8, cap=30000):
             "all_stopped": bool(launched < cap), "wall_s": dt}
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """the same workload on ONE host core: the real reference when oracle/_ref travelled
-    here, else the oracle restatement (a port)"""
-    import pyoracle as po
-    lib = po.reference()
-    kind = "reference" if lib is not None else "port"
-    if lib is None:
-        lib = po.oracle()
+def _cpu_handle(po, lib, wl, seed):
+    """one optimizer of the compiled reference (or of the oracle) for workload `wl`; returns
+    (handle, the np actually used, a note when it had to be reduced)"""
     n, lam = wl["n"], wl["np"]
     a = wl["algo"]
     note = ""
@@ -318,8 +308,8 @@ def cpu_baseline(wl, budget_s=12.0):
             lam, 0.45 * (lam / 1024.) ** 2)
         lam = 1024
     lo, up = wl["box"][0] * np.ones(n), wl["box"][1] * np.ones(n)
-    guess = np.random.default_rng(1).uniform(wl["box"][0], wl["box"][1], n)
-    lib.seed(1)
+    guess = np.random.default_rng(seed).uniform(wl["box"][0], wl["box"][1], n)
+    lib.seed(seed)
     if a == "ActiveCMAES":
         h = po.cma(lib, "active", 2 ** 31 - 1, 0., lam)
     elif a == "SepCMAES":
@@ -337,12 +327,23 @@ def cpu_baseline(wl, budget_s=12.0):
     else:
         h = po.apso(lib, 2 ** 31 - 1, 0., lam)
     h.init(wl["objective"], lo, up, guess)
+    return h, lam, note
+
+
+def _cpu_run(wl, seed, budget_s, max_gens=200):
+    """generations of the CPU implementation for `budget_s` seconds on THIS process's core"""
+    import pyoracle as po
+    lib = po.reference()
+    kind = "reference" if lib is not None else "port"
+    if lib is None:
+        lib = po.oracle()
+    h, lam, note = _cpu_handle(po, lib, wl, seed)
     fev0 = h.scalar("fev")
     gens = 0
     # the reference's CCPSO prints _fyhat to stdout every generation (ccpso.cpp:121): keep it
     # out of this script's one-line JSON
     saved_fd = None
-    if a == "CCPSO":
+    if wl["algo"] == "CCPSO":
         sys.stdout.flush()
         saved_fd = os.dup(1)
         devnull = os.open(os.devnull, os.O_WRONLY)
@@ -354,16 +355,82 @@ def cpu_baseline(wl, budget_s=12.0):
             h.iterate()
             gens += 1
             dt = time.perf_counter() - t0
-            if dt >= budget_s or gens >= 200:
+            if dt >= budget_s or gens >= max_gens:
                 break
     finally:
         if saved_fd is not None:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    evals = h.scalar("fev") - fev0
-    return {"value": evals / dt, "unit": "candidate-evals/s", "cores": 1, "kind": kind,
-            "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s%s" % (
-                gens, a, n, lam, wl["objective"], dt, note)}
+    return {"evals": h.scalar("fev") - fev0, "dt": dt, "gens": gens, "kind": kind, "np": lam,
+            "note": note}
+
+
+def host_core_count():
+    """(cores of the host, cores THIS process may use): the scheduler affinity mask, cut down to
+    the cgroup's CPU quota where one is set -- a GPU box hands each job a share of its host"""
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = total
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return total, usable
+
+
+def cpu_replica_main(spec):
+    """child of cpu_baseline(): `bench.py --cpu-replica WORKLOAD:SEED:SECONDS` -- one independent
+    replica in a process of its own (the reference's generator is one global, non-thread-safe
+    object, /root/reference/src/random.hpp:168, so replicas cannot be threads); no GPU touched"""
+    key, seed, budget = spec.split(":")
+    r = _cpu_run(WORKLOADS[key], int(seed), float(budget), max_gens=10 ** 9)
+    print(json.dumps(r))
+
+
+def cpu_all_cores(key, replicas, budget_s=8.0):
+    """N independent replicas of the CPU implementation, one PROCESS each, started together:
+    aggregate evaluations / the slowest replica's wall time"""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-replica",
+                               "%s:%d:%g" % (key, 100 + r, budget_s)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, env=env) for r in range(replicas)]
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=budget_s * 4 + 60)
+            lines = [ln for ln in o.decode().splitlines() if ln.startswith("{")]
+            if pr.returncode == 0 and lines:
+                outs.append(json.loads(lines[-1]))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    if not outs:
+        return None
+    wall = max(o["dt"] for o in outs)
+    return {"value": sum(o["evals"] for o in outs) / wall, "unit": "candidate-evals/s",
+            "replicas": len(outs), "kind": outs[0]["kind"],
+            "sample": "%d independent replicas, one process each (the reference's generator is a "
+                      "process-wide global), %.1f s each" % (len(outs), wall)}
+
+
+def cpu_baseline(wl, budget_s=12.0, key=None):
+    """the same workload on the host cores of this box: the real reference when oracle/_ref
+    travelled here, else the oracle restatement (a port).  `value` is ONE core -- the reference is
+    single-threaded -- and `all_cores` the aggregate of one independent replica per usable core."""
+    r = _cpu_run(wl, 1, budget_s)
+    total, usable = host_core_count()
+    out = {"value": r["evals"] / r["dt"], "unit": "candidate-evals/s", "cores": 1,
+           "kind": r["kind"], "host_cores": total, "usable_cores": usable,
+           "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s%s" % (
+               r["gens"], wl["algo"], wl["n"], r["np"], wl["objective"], r["dt"], r["note"])}
+    if key is not None and usable > 1:
+        out["all_cores"] = cpu_all_cores(key, min(usable, 64))
+    return out
 
 
 def max_over_ranks(dt):
@@ -538,10 +605,14 @@ def main():
                     help="skip the single-population legs (profiling runs: keeps rocprofv3's "
                          "per-kernel averages to the P-population launches)")
     ap.add_argument("--no-bipop", action="store_true", help="skip the bipop_scaling leg")
+    ap.add_argument("--cpu-replica", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--slots", type=int, default=1,
                     help="C5: concurrent restart populations per GPU (default 1, as configured)")
     args = ap.parse_args()
 
+    if args.cpu_replica:
+        cpu_replica_main(args.cpu_replica)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -671,7 +742,7 @@ def main():
             ftar = generations_to_ftarget(bb, wl, local_rank)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(wl)
+            cpu = cpu_baseline(wl, key=args.workload)
         out = {
             "metric": "candidate-evals/sec", "value": value, "unit": "candidate-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

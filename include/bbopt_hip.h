@@ -249,7 +249,15 @@ int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out);
  * | fY block, each ceil(max swarms / world) * np doubles (max swarms = n / the smallest swarm
  * size); `device_memory` != 0 says the caller's pointer is device memory (e.g. an RCCL buffer),
  * else host memory.  One population.  While world > 1, bbo_iterate / bbo_run / bbo_optimize
- * return BBO_ERR_STATE: only the phase / merge protocol advances a sharded handle. */
+ * return BBO_ERR_STATE: only the phase / merge protocol advances a sharded handle.
+ * BUFFER LIFETIME with device_memory != 0: bbo_ccpso_merge_tables only ENQUEUES the merge kernel
+ * on the handle's stream and returns; `gathered` must stay allocated and unmodified until the
+ * next call on this handle that waits for the stream -- bbo_ccpso_export_tables (host or device),
+ * bbo_get, bbo_solution, or bbo_ccpso_phase(h, 1) -- has returned (ShardedCCPSO reuses one
+ * buffer per handle and overwrites it only in the next generation's all-gather, which follows the
+ * next export).  A kernel error of the merge surfaces at that call.  With host memory the call
+ * has copied `gathered` when it returns.  bbo_ccpso_export_tables with device_memory != 0 has
+ * finished writing `dst` when it returns (the collective may start at once). */
 int bbo_ccpso_set_shard(bbo_handle h, int rank, int world);
 int bbo_ccpso_phase(bbo_handle h, int phase);
 int bbo_ccpso_table_record(bbo_handle h);

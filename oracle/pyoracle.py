@@ -15,7 +15,9 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(HERE, "_build", "libbbo_oracle.so")
+# (BBO_ORACLE_SO: another build of the same restatement -- `make -C oracle asan` -- for the
+# sanitizer run of tests/test_oracle_asan.py)
+ORACLE_SO = os.environ.get("BBO_ORACLE_SO") or os.path.join(HERE, "_build", "libbbo_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libbbo_ref.so")
 
 OBJ = {"sphere": 0, "rosenbrock": 1, "rastrigin": 2, "ellipsoid": 3, "ackley": 4,
@@ -29,6 +31,8 @@ _ip = C.POINTER(C.c_int)
 
 def build_oracle(force=False):
     """compile the oracle restatement (g++, a few seconds)"""
+    if os.environ.get("BBO_ORACLE_SO"):
+        return ORACLE_SO
     if force or not os.path.exists(ORACLE_SO) or any(
             os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(ORACLE_SO)
             for f in ("bbo_oracle.cpp", "bbo_oracle_pop.inc", "objectives.h", "philox.h", "zig_table.inc")):

@@ -39,12 +39,14 @@ def shared_oracle_runner(lo, up, obj, tol=1e-8):
     return run
 
 
-def drive(world=None, rank=None, mfev=60000, n=5, seed=17, shared=False, slots=1):
-    from bboptpy_amd.distributed import ConcurrentBiPop
+def drive(world=None, rank=None, mfev=60000, n=5, seed=17, shared=False, slots=1, kind="bipop",
+          **kw):
+    from bboptpy_amd.distributed import ConcurrentBiPop, ConcurrentIPop
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     make = shared_oracle_runner if shared else oracle_runner
-    d = ConcurrentBiPop(mfev=mfev, seed=seed, runner=make(lo, up, "rastrigin"),
-                        world_size=world, rank=rank, slots_per_rank=slots)
+    cls = ConcurrentBiPop if kind == "bipop" else ConcurrentIPop
+    d = cls(mfev=mfev, seed=seed, runner=make(lo, up, "rastrigin"),
+            world_size=world, rank=rank, slots_per_rank=slots, **kw)
     sol = d.optimize(None, lo, up, np.random.default_rng(seed).uniform(-5, 5, n))
     st = d.state
     return {"x": [float(v).hex() for v in sol.x], "fev": sol.n_evals, "fxbest": st.fxbest.hex(),
@@ -57,6 +59,9 @@ if __name__ == "__main__":
     dist.init_process_group("gloo")
     res = drive()
     with open(os.path.join(sys.argv[1], "rank%d.json" % dist.get_rank()), "w") as fh:
+        json.dump(res, fh)
+    res = drive(kind="ipop", mfev=30000)
+    with open(os.path.join(sys.argv[1], "ipop_rank%d.json" % dist.get_rank()), "w") as fh:
         json.dump(res, fh)
     dist.barrier()
     dist.destroy_process_group()

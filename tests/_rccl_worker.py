@@ -27,13 +27,17 @@ def free_port():
     return port
 
 
-def bipop(n, mfev, tol, group_run):
+def bipop(n, mfev, tol, group_run, kind="bipop"):
     import bboptpy_amd as bb
-    from bboptpy_amd.distributed import ConcurrentBiPop
+    from bboptpy_amd.distributed import ConcurrentBiPop, ConcurrentIPop
     lo, up = -5.12 * np.ones(n), 5.12 * np.ones(n)
     guess = np.random.default_rng(n).uniform(-5, 5, n)
     kw = {} if group_run else dict(world_size=1, rank=0)      # explicit topology = no group
-    d = ConcurrentBiPop(mfev=mfev, tol=tol, seed=31, device=0, **kw)
+    # (no device= on the group run: the drivers take LOCAL_RANK / torch's current device there)
+    if not group_run:
+        kw["device"] = 0
+    cls = ConcurrentBiPop if kind == "bipop" else ConcurrentIPop
+    d = cls(mfev=mfev, tol=tol, seed=31, **kw)
     sol = d.optimize(bb.objectives.rastrigin, lo, up, guess)
     return {"history": [sorted((k, float(v).hex()) for k, v in h.items()) for h in d.state.history],
             "x": [float(v).hex() for v in sol.x], "fev": sol.n_evals,
@@ -55,6 +59,10 @@ def ccpso(n, npp, pps, group_run, gens=6):
             "x": [float(v).hex() for v in d.get_state("x")], "collectives": d.collectives}
 
 
+def ipop(n, mfev, tol, group_run):
+    return bipop(n, mfev, tol, group_run, kind="ipop")
+
+
 def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(free_port()))
@@ -68,6 +76,7 @@ def main():
     dist.all_reduce(t)
     out["all_reduce"] = float(t.item())
     cases = {"bipop6": (bipop, (6, 30000, 1e-8)), "bipop256": (bipop, (256, 9000, 0.5)),
+             "ipop6": (ipop, (6, 20000, 1e-8)),
              "ccpso24": (ccpso, (24, 12, [2, 4, 6])), "ccpso1000": (ccpso, (1000, 30, [2, 5, 10, 50]))}
     for name, (fn, a) in cases.items():
         out[name] = {"group": fn(*a, True), "nogroup": fn(*a, False)}

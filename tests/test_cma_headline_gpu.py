@@ -259,34 +259,3 @@ def test_generations_to_the_reference_stop(hip, lam, ref_gens, ref_flag, f_lo, f
     assert abs(np.median(its) - ref_gens) <= 0.01 * ref_gens, its
     assert max(abs(i - ref_gens) for i in its) <= 0.03 * ref_gens, its
     assert all(f_lo <= f <= f_hi for f in fbest), fbest
-
-
-def test_normals_drawn_ahead_give_the_same_run(hip):
-    """Diagnostic bit 2048: run() / iterate() on the lean n = 128 path draw generation g + 1's
-    normals on a second stream while generation g ranks, updates and decomposes (cma_draw128 ->
-    cma_sample_eval128z; off by default -- it lengthens the step).  Same
-    Philox counters, same ziggurat statements, same sweep: the state after any number of
-    generations must equal, BIT FOR BIT, the one with the draw inside the sampler -- also across
-    host polls, single iterate() calls, and a state change in between (which makes the next
-    sampler draw for itself)."""
-    n, lam, P = 128, 4096, 8
-    lo, up = -10. * np.ones(n), 10. * np.ones(n)
-    guess = np.random.default_rng(3).uniform(-10, 10, (P, n))
-    out = []
-    for dbg in (0, 2048):
-        g = hip.ActiveCMAES(mfev=2 ** 31 - 1, tol=0., np=lam, seed=5, populations=P, poll_every=4)
-        g.initialize(hip.objectives.rosenbrock, lo, up, guess)
-        if dbg:
-            g.set_state("dbg", [float(dbg)])
-        assert g.run(10) == 10                      # two polls and a half
-        g.iterate()
-        g.iterate()
-        snap = [g.get_state(k, p).copy() for p in (0, 3, 7)
-                for k in ("arx", "xmean", "sigma", "C", "fit_val", "D")]
-        g.set_state("sigma", [0.5 * g.get_state("sigma", 2)[0]], 2)      # pending draw dropped
-        assert g.run(5) == 5
-        snap += [g.get_state(k, p).copy() for p in (0, 2, 7)
-                 for k in ("arx", "xmean", "sigma", "C", "fit_val", "it", "fev")]
-        out.append(snap)
-    for a, b in zip(*out):
-        np.testing.assert_array_equal(a, b)

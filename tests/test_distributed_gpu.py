@@ -59,6 +59,72 @@ def test_world1_on_device_equals_the_cxx_driver_and_the_oracle_plan(hip, oracle_
             int(o.scalar("last_maxfev")), int(o.scalar("last_inner_fev"))) == got[1][:5]
 
 
+@pytest.mark.parametrize("n,mfev,kw", [(6, 30000, {}), (3, 40000, {}),
+                                       (4, 20000, dict(nipop=False, boundlambda=False))])
+def test_ipop_world1_on_device_equals_the_cxx_driver(hip, oracle_lib, n, mfev, kw):
+    """ConcurrentIPop with one slot per round on the device IS the sequential IPopCMAES
+    (bbo_restart.hip, ipop_cmaes.cpp:112-162): the whole history -- lambda (incl. the cycling at
+    10 n^2 for n = 3), sigma, cap, evaluations used, f* of every run -- the budget and the
+    incumbent, bit for bit; and the oracle's IPOP restatement plans the same first restart from
+    the same first run"""
+    from bboptpy_amd.distributed import ConcurrentIPop
+    seed = 40 + n
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(-5, 5, n)
+    d = ConcurrentIPop(mfev=mfev, tol=1e-8, seed=seed, world_size=1, rank=0, **kw)
+    sol = d.optimize("rastrigin", lo, up, guess)
+    got = [(h["lam"], h["sigma"], h["maxfev"], h["used"], h["fx"]) for h in d.state.history]
+
+    base = hip.ActiveCMAES(mfev=1, tol=1e-8, np=4)
+    c = hip.IPopCMAES(base, mfev=mfev, seed=seed, **kw)
+    c.initialize(hip.objectives.rastrigin, lo, up, guess)
+    g = lambda k: c.get_state(k)[0]
+    row = lambda: (int(g("last_lambda")), g("last_sigma"), int(g("last_maxfev")),
+                   int(g("last_inner_fev")), g("fx"))
+    rows_c = [row()]
+    while g("fev") < mfev:
+        c.iterate()
+        rows_c.append(row())
+    assert got == rows_c
+    assert sol.n_evals == int(g("fev")) and not sol.converged
+    np.testing.assert_array_equal(sol.x, c.get_state("xbest"))
+    assert len(got) >= 3
+
+    o = po.ipop(oracle_lib, po.cma(oracle_lib, "active", 1, 1e-8, 4), mfev, **kw)
+    o.set_mode(False, po.RNG_PHILOX, seed)
+    o.init("rastrigin", lo, up, guess)
+    orow = lambda: (int(o.scalar("last_lambda")), o.scalar("last_sigma"),
+                    int(o.scalar("last_maxfev")), int(o.scalar("last_inner_fev")))
+    assert orow() == got[0][:4]
+    o.iterate()
+    assert orow() == got[1][:4]
+
+
+def test_ipop_world2_rounds_on_device(hip):
+    """W = 2 with the serial stand-in for the collective: round k runs two consecutive doublings
+    side by side, the replicated budget is the sum of what the runs reported, every run stayed
+    inside its cap, and (2 ranks, 1 slot) equals (1 rank, 2 concurrent slots) bit for bit"""
+    from bboptpy_amd.distributed import ConcurrentIPop
+    n, seed, mfev = 8, 9, 60000
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(seed).uniform(-5, 5, n)
+    a = ConcurrentIPop(mfev=mfev, tol=1e-8, seed=seed, world_size=2, rank=0)
+    sa = a.optimize(hip.objectives.rastrigin, lo, up, guess)
+    b = ConcurrentIPop(mfev=mfev, tol=1e-8, seed=seed, world_size=1, rank=0, slots_per_rank=2)
+    sb = b.optimize(hip.objectives.rastrigin, lo, up, guess)
+    assert a.state.history == b.state.history and sa.n_evals == sb.n_evals
+    np.testing.assert_array_equal(sa.x, sb.x)
+    st = a.state
+    lamdef = 4 + int(3. * math.log(n))
+    assert [h["lam"] for h in st.history[:4]] == [lamdef, 2 * lamdef, 4 * lamdef, 8 * lamdef]
+    assert [(h["round"], h["slot"]) for h in st.history[:4]] == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    assert st.fev == sum(h["used"] + 1 for h in st.history) == sa.n_evals
+    for h in st.history:
+        assert 0 < h["used"] <= h["maxfev"] + h["lam"] and h["used"] % h["lam"] == 0
+    assert st.fxbest == min(h["fx"] for h in st.history)
+    assert hip.objectives.rastrigin(sa.x) == pytest.approx(st.fxbest, rel=1e-9)
+
+
 def test_world2_n256_bookkeeping_equals_the_plan(hip):
     from bboptpy_amd.distributed import ConcurrentBiPop
     n, seed, mfev = 256, 5, 400000

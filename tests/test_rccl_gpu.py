@@ -32,7 +32,7 @@ def test_drivers_through_a_real_rccl_group_equal_the_no_group_run(hip):
     line = [l for l in out.stdout.splitlines() if l.startswith("RCCL_RESULT ")][-1]
     res = json.loads(line[len("RCCL_RESULT "):])
     assert res["backend"] == "nccl" and res["all_reduce"] == 3.5
-    for name in ("bipop6", "bipop256"):
+    for name in ("bipop6", "bipop256", "ipop6"):
         g, s = res[name]["group"], res[name]["nogroup"]
         assert g["collectives"] >= 2 and s["collectives"] == 0      # one all_gather per round
         assert g["history"] == s["history"] and g["x"] == s["x"] and g["fev"] == s["fev"]
