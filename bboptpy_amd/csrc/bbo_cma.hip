@@ -417,9 +417,9 @@ void CmaEngine::launch_rank()
     } else if (c.lambda <= SORT_LDS_MAX && c.npop >= 4) {
         int m = 2;
         while (m < c.lambda) m <<= 1;
-        allow_lds((const void*) cma_rank_sort, SORT_LDS_MAX * 12);
-        hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(sort_threads(m)), (size_t) std::max(m, 1024) * 12,
-                stream_, d_,
+        allow_lds((const void*) cma_rank_sort, 128 * 1024);
+        const size_t lds = rank_sort_merges(m, d_.dbg) ? (size_t) m * 24 : (size_t) std::max(m, 1024) * 12;
+        hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(sort_threads(m)), lds, stream_, d_,
                 c_, m);
     } else {
         dim3 grid((c.lambda + 31) / 32, c.npop);

@@ -603,8 +603,14 @@ __global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
     if (blockIdx.x == 0 && tid == 0) sc->fev += c.lambda;   // base_cmaes.cpp:218
 }
 
-// the same ranking by one in-LDS bitonic sort per population (lambda <= SORT_LDS_MAX):
-// grid (P), 1024 threads, dynamic LDS m * 12 bytes
+// the same ranking by one in-LDS sort per population (lambda <= SORT_LDS_MAX): merge sort by
+// merge path for 2048 / 4096 padded keys (`merge`: two buffers, 24 m bytes of dynamic LDS), the
+// bitonic network otherwise (12 max(m, 1024) bytes).  grid (P), 1024 threads (256 for m <= 256)
+__host__ __device__ inline bool rank_sort_merges(int m, int dbg)
+{
+    return (m == 2048 || m == 4096) && !(dbg & 262144);
+}
+
 __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int m)
 {
     const int p = blockIdx.x;
@@ -615,6 +621,11 @@ __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int 
     int *idx = reinterpret_cast<int*>(sortbuf + max(m, 1024));   // the sort pads to >= 1024
     const double *f = d.f + (size_t) p * c.lambda_pad;
     int *order = d.order + (size_t) p * c.lambda_pad, *rank = d.rank + (size_t) p * c.lambda_pad;
+    if (rank_sort_merges(m, d.dbg)) {
+        int *ibuf = reinterpret_cast<int*>(sortbuf + 2 * m);
+        if (m == 2048) merge_sort_lds<2>(f, c.lambda, sortbuf, ibuf, order, rank, &keys, &idx);
+        else merge_sort_lds<4>(f, c.lambda, sortbuf, ibuf, order, rank, &keys, &idx);
+    } else
     bitonic_sort_lds(f, c.lambda, m, keys, idx, order, rank);
     if (threadIdx.x == 0) {
         const int L = c.lambda;

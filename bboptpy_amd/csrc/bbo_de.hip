@@ -160,7 +160,9 @@ void DeEngine::launch_rank(int which_next, int np_bound)
         int m = 2;
         while (m < np_bound) m <<= 1;
         allow_lds((const void*) de_rank_sort, SORT_LDS_MAX * 12);
-        hipLaunchKernelGGL(de_rank_sort, dim3(c.npop), dim3(sort_threads(m)), (size_t) std::max(m, 1024) * 12,
+        // (2048 / 4096 keys: merge sort by merge path, two buffers; bbo_rank.hpp)
+        hipLaunchKernelGGL(de_rank_sort, dim3(c.npop), dim3(sort_threads(m)),
+                (m == 2048 || m == 4096) ? (size_t) m * 24 : (size_t) std::max(m, 1024) * 12,
                 stream_, d_,
                 c_, which_next, m);
     } else {

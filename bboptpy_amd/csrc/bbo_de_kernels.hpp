@@ -109,6 +109,16 @@ __global__ __launch_bounds__(1024) void de_rank_sort(DeDev d, DeConst c, int whi
     int *idx = reinterpret_cast<int*>(sortbuf + max(m, 1024));   // the sort pads to >= 1024
     const int which = which_next ? (sc->cur ^ 1) : sc->cur;
     const double *f = d.f[which] + (size_t) p * c.npinit;
+    if (m == 2048 || m == 4096) {
+        int *ibuf = reinterpret_cast<int*>(sortbuf + 2 * m);
+        if (m == 2048)
+            merge_sort_lds<2>(f, sc->np, sortbuf, ibuf, d.order + (size_t) p * c.npinit,
+                    d.rank + (size_t) p * c.npinit, &keys, &idx);
+        else
+            merge_sort_lds<4>(f, sc->np, sortbuf, ibuf, d.order + (size_t) p * c.npinit,
+                    d.rank + (size_t) p * c.npinit, &keys, &idx);
+        return;
+    }
     bitonic_sort_lds(f, sc->np, m, keys, idx, d.order + (size_t) p * c.npinit,
             d.rank + (size_t) p * c.npinit);
 }

@@ -105,18 +105,36 @@ __device__ inline int dc_rank_of(const double *v, int cnt, double key, int self)
 // The same rank for an entry of one of two lists that are EACH in ascending key order: its place in
 // its own list plus the number of entries of the other list that go before it -- entries with a
 // smaller key, and (for an entry of the second list, whose positions all come later) those with an
-// equal one.  A binary search: 7 dependent LDS reads instead of 128 comparisons.
-__device__ inline int dc_count_before(const double *v, int cnt, double key, bool or_equal)
+// equal one.  A binary search: log2 dependent LDS reads instead of 128 comparisons.
+// ONE loop with a trip count that is the same for every lane (`trips` >= log2(cnt) + 1 for the
+// longest list of the team), the list, its length and the tie rule per-lane VALUES: written as
+// `first ? a + search(listB, strict) : b + search(listA, or_equal)` -- two data-dependent while
+// loops under a select -- the 128- / 256-thread instantiations of the eigensolver came out of the
+// compiler with the tie rule of the two lists exchanged and the last entry of the second list
+// ranked 0 (round 4: B of the identity matrix at n = 18 had column 0 twice and column 8 missing;
+// every n in 17..64 was wrong, and whether a build showed it depended on unrelated code nearby).
+__device__ inline int dc_count_before(const double *v, int cnt, double key, bool or_equal, int trips)
 {
     int lo = 0, hi = cnt;          // v[0 .. lo) go before, v[hi .. cnt) do not
-    while (lo < hi) {
+    for (int t = 0; t < trips; t++) {
+        const bool open = lo < hi;
         const int mid = (lo + hi) >> 1;
-        const double d = dc_key(v[mid]);
+        const double d = dc_key(v[open ? mid : 0]);       // (v[0] is a legal address for cnt = 0)
         const bool before = or_equal ? d <= key : d < key;
-        lo = before ? mid + 1 : lo;
-        hi = before ? hi : mid;
+        lo = (open && before) ? mid + 1 : lo;
+        hi = (open && !before) ? mid : hi;
     }
     return lo;
+}
+
+// rank of entry `self` (key) of the concatenation [list A: n_a entries | list B: n_b entries] at v
+__device__ inline int dc_rank_sorted2(const double *v, int n_a, int n_b, double key, int self, int trips)
+{
+    const bool first = self < n_a;
+    const double *other = first ? v + n_a : v;
+    const int ocnt = first ? n_b : n_a;
+    const int own = first ? self : self - n_a;
+    return own + dc_count_before(other, ocnt, key, !first, trips);
 }
 
 // the team of wavefronts that works on one merge
@@ -231,6 +249,8 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const int ttid = tm.ttid, TT = tm.tthreads;
     const bool on = tm.active != 0;
     const int m = on ? b - a : 0;
+    // trips of the binary-search rankings: log2(longest list) + 1, the same for every team
+    const int search_trips = 32 - __builtin_clz(max(mlevel > 0 ? mlevel : (BIG ? 512 : 256), 1));
     const double sgn = rho_in >= 0. ? 1. : -1.;
     // this merge's slices of the shared work arrays
     DcWork W = W0;
@@ -270,8 +290,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         const int m1 = mid - a;
         const bool by_search = tm.sorted_in && !any_unsorted;
         const int r = !by_search ? dc_rank_of(W.lam, m, dc_key(di), ttid)
-                : ttid < m1 ? ttid + dc_count_before(W.lam + m1, m - m1, dc_key(di), false)
-                            : (ttid - m1) + dc_count_before(W.lam, m1, dc_key(di), true);
+                : dc_rank_sorted2(W.lam, m1, m - m1, dc_key(di), ttid, search_trips);
         W.dS[r] = di;
         W.zS[r] = zi;
         W.srcS[r] = a + ttid;
@@ -697,8 +716,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     if (ttid < m) {
         const double key = dc_key(W.lam[ttid]);
         W.outpos[ttid] = (nr > 0 || W.cnt[3] != 0) ? dc_rank_of(W.lam, m, key, ttid)
-                : ttid < k ? ttid + dc_count_before(W.lam + k, nd, key, false)
-                           : (ttid - k) + dc_count_before(W.lam, k, key, true);
+                : dc_rank_sorted2(W.lam, k, nd, key, ttid, search_trips);
     }
     __syncthreads();
     if (ttid < k) {
@@ -968,6 +986,26 @@ __device__ inline void dc_leaf_ql(const DcMat &Q, int a, int s, const double *dv
     const int sweeps = ql_produce_reg<true>(st, s, d, e, rot, desc, 64, lane, blk);
     if (dbgout && lane == 0) dbgout[0] = sweeps;
     if (lane < s) dv_out[a + lane] = d;
+    dc_wave_sync();
+}
+
+// two leaves by one wavefront, one in each 32-lane half (ql_leaf_pair): blocks [a0, a0 + s0) and
+// [a1, a1 + s1) (s1 = 0: none), s <= 32
+__device__ inline void dc_leaf_ql_pair(const DcMat &Q, int a0, int s0, int a1, int s1,
+        const double *dv_in, const double *ev_in, double *dv_out, int lane)
+{
+    const int hl = lane & 31;
+    const int a = lane < 32 ? a0 : a1, s = lane < 32 ? s0 : s1;
+    double d = hl < s ? dv_in[a + hl] : 0.;
+    double e = hl + 1 < s ? ev_in[a + hl] : 0.;
+    for (int q = hl; q < s * s; q += 32) {
+        const int r = q / s, c = q - r * s;
+        Q(a + r, a + c) = r == c ? 1. : 0.;
+    }
+    dc_wave_sync();
+    double *zrow = &Q(a + (hl < s ? hl : 0), a);
+    ql_leaf_pair(s, d, e, zrow, lane);
+    if (hl < s) dv_out[a + hl] = d;
     dc_wave_sync();
 }
 
@@ -1305,6 +1343,16 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
 
     DC_STAMP(17);
     // ---- leaves: one wavefront each; the merge work area is not in use yet ------------------
+    // (two per wavefront, one in each 32-lane half: dc_leaf_ql_pair; diagnostic bit 524288 keeps
+    // the one-leaf-at-a-time form)
+    if (!(dbg & 8) && !(dbg & 524288)) {
+        for (int pr = wave; 2 * pr < nblk; pr += NW) {
+            const int b0 = 2 * pr, b1 = 2 * pr + 1;
+            const int a0 = bounds[b0], s0 = bounds[b0 + 1] - a0;
+            const int a1 = b1 < nblk ? bounds[b1] : 0, s1 = b1 < nblk ? bounds[b1 + 1] - a1 : 0;
+            dc_leaf_ql_pair(Q, a0, s0, a1, s1, dv, ev, dv, lane);
+        }
+    } else
     if (!(dbg & 8))
     for (int blk = wave; blk < nblk; blk += NW) {
         const int a = bounds[blk], s = bounds[blk + 1] - a;

@@ -388,6 +388,139 @@ __device__ inline int ql_produce_reg(QlState &st, int n, double &d, double &e, d
     return ns;
 }
 
+// ---- two leaves per wavefront, one in each 32-lane half ---------------------------------------------
+// A leaf of the divide and conquer (<= 32 rows; 8 or 16 in practice) is one chain of Givens
+// rotations, ~40 dependent vector instructions each, walked by all 64 lanes on uniform values while
+// at most 16 of them hold data: with 16 leaves on 8 wavefronts the kernel solved them two IN TURN
+// (61 us of the 400 at n = 128; 220 of 1470 at n = 256).  Here lanes 0-31 walk leaf A and lanes
+// 32-63 leaf B in the SAME instruction stream: the state (l, m, f, the sweep's running values) is
+// per half, an element of (d, e) is fetched by one v_readlane per half and a select, and where the
+// two recurrences part (different sweep lengths, one finished) the hardware masks lanes as for any
+// divergent loop.  Every leaf executes exactly the operations of ql_produce_reg<true> in the same
+// order: the same bits.  (Tried in round 3 as two leaves interleaved BY HAND in one uniform stream:
+// twice the instructions per rotation, slower.)
+// v of lane (32 * half + idx): idx is per half (the same in all lanes of a half), 0 <= idx < 32
+__device__ inline double ql_half_lane(double v, int idx, int lane)
+{
+    const int ia = __builtin_amdgcn_readlane(idx, 0) & 31;
+    const int ib = 32 + (__builtin_amdgcn_readlane(idx, 32) & 31);
+    const int lo_a = __builtin_amdgcn_readlane(__double2loint(v), ia);
+    const int hi_a = __builtin_amdgcn_readlane(__double2hiint(v), ia);
+    const int lo_b = __builtin_amdgcn_readlane(__double2loint(v), ib);
+    const int hi_b = __builtin_amdgcn_readlane(__double2hiint(v), ib);
+    return lane < 32 ? __hiloint2double(hi_a, lo_a) : __hiloint2double(hi_b, lo_b);
+}
+
+// hl = lane & 31 holds d[hl], e[hl] of its half's block of n rows (n per half, 0: no block);
+// zrow: row hl of the half's eigenvector block (LDS), identity on entry.  Returns the sweeps.
+__device__ inline int ql_leaf_pair(int n, double &d, double &e, double *zrow, int lane)
+{
+    const double eps = 0x1.0p-52;
+    const int hl = lane & 31;
+    int l = 0, m = 0, ns = 0;
+    bool need_m = true, done = n <= 0;
+    double fsum = 0., tst1 = 0.;
+    while (!done) {
+        if (need_m) {
+            const double dl = ql_half_lane(d, l, lane), el = ql_half_lane(e, l, lane);
+            tst1 = fmax(tst1, fabs(dl) + fabs(el));
+            const double thr = eps * tst1;
+            const bool ok = hl >= l && hl < n && fabs(e) <= thr;
+            const unsigned long long mask = __ballot(ok);
+            const unsigned mh = lane < 32 ? (unsigned) mask : (unsigned) (mask >> 32);
+            m = mh ? (int) __builtin_ctz(mh) : n;
+            need_m = false;
+            if (m >= n) {   // unreachable for finite input: e[n-1] == 0
+                done = true;
+                continue;
+            }
+            if (m == l) {
+                if (hl == l) {
+                    d = dl + fsum;
+                    e = 0.;
+                }
+                l++;
+                need_m = true;
+                if (l >= n) done = true;
+                continue;
+            }
+        }
+        // (sweep bound: see ql_produce_reg)
+        if (ns >= 30 * n) {
+            done = true;
+            continue;
+        }
+        const double thr = eps * tst1;
+        // implicit shift (cmaes.cpp:405-417)
+        const double g0 = ql_half_lane(d, l, lane), d1 = ql_half_lane(d, l + 1, lane),
+                el = ql_half_lane(e, l, lane);
+        const double p0 = (d1 - g0) * ql_rcp(2. * el);
+        double r0 = ql_hypot1(p0);
+        r0 = p0 >= 0. ? r0 : -r0;
+        const double dl_new = el * ql_rcp(p0 + r0);
+        const double dl1 = el * (p0 + r0);
+        const double h0 = g0 - dl_new;
+        if (hl >= l + 2 && hl < n) d -= h0;
+        fsum += h0;
+        if (hl == l) d = dl_new;
+        if (hl == l + 1) d = dl1;
+
+        // implicit QL sweep (cmaes.cpp:419-449)
+        double pp = ql_half_lane(d, m, lane);
+        double cth = 1., c2 = 1., c3 = 1., sn = 0., s2 = 0.;
+        const double el1 = ql_half_lane(e, l + 1, lane);
+        double ei = ql_half_lane(e, m - 1, lane), di = ql_half_lane(d, m - 1, lane);
+        double hcur = zrow[m], zx = zrow[m - 1];
+        for (int i = m - 1; i >= l; i--) {
+            const int ip = i > 0 ? i - 1 : 0;              // (the value for i = l is not used)
+            const double ein = ql_half_lane(e, ip, lane), din = ql_half_lane(d, ip, lane);
+            const double zn = zrow[ip];
+            c3 = c2;
+            c2 = cth;
+            s2 = sn;
+            const double g = cth * ei;
+            const double h = cth * pp;
+            const double t = fma(pp, pp, ei * ei);
+            double y = __builtin_amdgcn_rsq(t);
+            const double err = fma(-t * y, y, 1.);
+            y = fma(y * err, fma(err, 0.375, 0.5), y);
+            const double r = t * y;             // = hypot(pp, ei) to rounding
+            const double e_up = sn * r;
+            sn = ei * y;
+            cth = pp * y;
+            pp = fma(cth, di, -(sn * g));
+            const double d_up = h + sn * fma(cth, g, sn * di);
+            if (hl == i + 1) {
+                e = e_up;
+                d = d_up;
+            }
+            if (hl < n) zrow[i + 1] = sn * zx + cth * hcur;
+            hcur = cth * zx - sn * hcur;
+            zx = zn;
+            ei = ein;
+            di = din;
+        }
+        if (hl < n) zrow[l] = hcur;
+        pp = -sn * s2 * c3 * el1 * ql_half_lane(e, l, lane) * ql_rcp(dl1);
+        const double el_new = sn * pp;
+        if (hl == l) {
+            e = el_new;
+            d = cth * pp;
+        }
+        ns++;
+        if (!(fabs(el_new) > thr)) {
+            if (hl == l) {
+                d += fsum;
+                e = 0.;
+            }
+            l++;
+            need_m = true;
+            if (l >= n) done = true;
+        }
+    }
+    return ns;
+}
+
 // Consumer: applies the recorded sweeps to row k of the eigenvector matrix
 // (the inner k-loop of cmaes.cpp:438-443, one lane per k)
 __device__ inline void ql_apply_row(const EigMat &A, int k, const double2 *rot,

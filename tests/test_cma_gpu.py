@@ -300,6 +300,35 @@ def test_eigendecomposition_special_matrices(hip, n):
         assert np.linalg.norm(isc @ Cm @ isc - np.eye(n)) <= 1e-13 * cond * n + 1e-10 * n, name
 
 
+def test_eigendecomposition_every_dimension_to_130(hip):
+    """every n in 2 .. 130 (each kernel: wavefront-per-matrix to 16, 128 threads to 32, 256 to 64,
+    512 above; every leaf / block-size pattern of the divide and conquer) on the identity (all
+    poles equal: the tie rules of every ranking), a near-identity and a generic covariance.
+    Round 4 met builds in which ALL of n = 17 .. 64 were wrong while 17, 37 and 64 -- the sizes the
+    parametrized test above holds -- had passed a build earlier: the sorted-list ranking of the
+    merges (bbo_eig_dc.hpp, dc_rank_sorted2) had come out of the compiler with its tie rule
+    exchanged in the 128- / 256-thread instantiations, depending on unrelated code nearby."""
+    from bboptpy_amd import _ffi
+    bad = []
+    for n in range(2, 131):
+        rng = np.random.default_rng(n)
+        g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=max(4, 2 * n), seed=1)
+        g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
+        X = rng.normal(size=(n, 3 * n))
+        for Cm in (np.eye(n), np.eye(n) + 1e-3 * (X @ X.T) / (3 * n), X @ X.T / (3 * n)):
+            Cm = 0.5 * (Cm + Cm.T)
+            g.set_state("C", Cm)
+            g.set_state("fev", [10 ** 6])
+            g.set_state("eigenlastev", [0])
+            g.phase(_ffi.PHASE_EIGEN)
+            B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+            res = np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) / np.linalg.norm(Cm)
+            orth = np.linalg.norm(B.T @ B - np.eye(n)) / n
+            if not (res <= 1e-11 and orth <= 1e-12):
+                bad.append((n, res, orth))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("n", [10, 16, 40, 128, 200, 256, 300, 512])
 def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     """The QL leaves stop after 30 sweeps per eigenvalue (ql_produce_reg), so a covariance with
