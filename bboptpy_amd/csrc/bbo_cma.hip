@@ -341,9 +341,32 @@ void CmaEngine::launch_sample_eval()
             const dim3 grid(std::min((c.lambda_pad + 7) / 8, per_pop), c.npop);
             if (c.n == c.ld && !c.bound && c.lambda == c.lambda_pad && !d_.zinject
                     && !d_.zrecord && !(d_.dbg & 256)) {   // nothing to guard (the benchmark's SEP)
-                allow_lds((const void*) sep_sample_eval<64, 512, true>, 140 * 1024);
-                hipLaunchKernelGGL((sep_sample_eval<64, 512, true>), grid, dim3(512), lds,
-                        stream_, d_, c_);
+                if (sep_sum_objective(c.obj) && !(d_.dbg & 1048576)) {
+                    // sums of per-coordinate terms: no row in LDS (sep_sample_sum); 256-thread
+                    // workgroups, as many rows in flight as the registers allow
+                    const dim3 sgrid(std::min(c.lambda_pad / (4 * SEP_K), per_pop), c.npop);
+#define BBO_SEP_SUM(NCV, OBJV) hipLaunchKernelGGL((sep_sample_sum<256, NCV, OBJV>), sgrid, dim3(256), 0, stream_, d_, c_)
+#define BBO_SEP_SUM_OBJ(NCV) \
+                    switch (c.obj) { \
+                    case OBJ_SPHERE: BBO_SEP_SUM(NCV, OBJ_SPHERE); break; \
+                    case OBJ_ELLIPSOID: BBO_SEP_SUM(NCV, OBJ_ELLIPSOID); break; \
+                    case OBJ_RASTRIGIN: BBO_SEP_SUM(NCV, OBJ_RASTRIGIN); break; \
+                    case OBJ_CIGAR: BBO_SEP_SUM(NCV, OBJ_CIGAR); break; \
+                    case OBJ_DISCUS: BBO_SEP_SUM(NCV, OBJ_DISCUS); break; \
+                    default: BBO_SEP_SUM(NCV, OBJ_DIFFPOW); break; \
+                    }
+                    // (the cosine / pow objectives inline a long body per coordinate: with the
+                    // lane's 32 constants resident as well they spill or fall to one wavefront
+                    // per SIMD -- Rastrigin took 512 registers and ran slower than from LDS rows)
+                    if (c.ld == 1024 && c.obj != OBJ_RASTRIGIN && c.obj != OBJ_DIFFPOW) { BBO_SEP_SUM_OBJ(4) }
+                    else { BBO_SEP_SUM_OBJ(0) }
+#undef BBO_SEP_SUM_OBJ
+#undef BBO_SEP_SUM
+                } else {
+                    allow_lds((const void*) sep_sample_eval<64, 512, true>, 140 * 1024);
+                    hipLaunchKernelGGL((sep_sample_eval<64, 512, true>), grid, dim3(512), lds,
+                            stream_, d_, c_);
+                }
             } else {
                 allow_lds((const void*) sep_sample_eval<64, 512>, 140 * 1024);
                 hipLaunchKernelGGL((sep_sample_eval<64, 512>), grid, dim3(512), lds, stream_,

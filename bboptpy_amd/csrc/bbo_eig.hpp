@@ -1090,7 +1090,9 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, T = TT, lane = tid & 63, wave = tid >> 6;
-    const int n = c.n, ld = c.ld, nv = pl.vl;
+    // (LDSM: n <= 128 and the vectors are 130 apart, eig_plan -- a compile-time fact makes every LDS
+    // vector and the whole merge work area constant addresses instead of scalar registers)
+    const int n = c.n, ld = c.ld, nv = LDSM ? 130 : pl.vl;
     double *dv = lds + 2;         // diagonal / eigenvalues        (each vector: 2-element front pad)
     double *ev = dv + nv;         // sub-diagonal
     double *uv = ev + nv;         // Householder vector u / scaled reflector column

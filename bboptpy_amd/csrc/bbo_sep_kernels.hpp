@@ -108,6 +108,224 @@ __global__ __launch_bounds__(T) void sep_sample_eval(CmaDev d, CmaConst c)
 }
 
 // ---------------------------------------------------------------------------
+// sample + evaluate for the objectives that are a SUM OF PER-COORDINATE TERMS (sphere, ellipsoid,
+// Rastrigin, cigar, discus, different powers), lean case only (n == ld, no box, lambda ==
+// lambda_pad, nothing injected or recorded): a lane adds the term of every coordinate it draws to
+// its own partial sum the moment the draw is settled, the 64 lanes of the row meet in one
+// butterfly -- the row never goes through LDS.  sep_sample_eval keeps a row in LDS only because a
+// lane draws the columns of its Philox calls (cma_quad_col0) and the objective walks the row in
+// another order; 8 rows x 8 KB + the generator's 16 KB table filled half the LDS of a CU and held
+// the kernel to 16 wavefronts per CU, and it is latency the kernel is short of (with 8 wavefronts
+// per CU it ran at half the speed: round 4, two rows per wavefront tried for a dense settle).
+// The terms are added in the lane's draw order, not in the strided order of eval_row_group: f
+// agrees with it and with the oracle to rounding (1e-13 relative), X is bit-identical.
+// grid (<= lambda_pad / (SEP_K T / 64), P), T threads, no dynamic LDS
+// ---------------------------------------------------------------------------
+__host__ __device__ inline bool sep_sum_objective(int obj)
+{
+    return obj == OBJ_SPHERE || obj == OBJ_ELLIPSOID || obj == OBJ_RASTRIGIN || obj == OBJ_CIGAR
+            || obj == OBJ_DISCUS || obj == OBJ_DIFFPOW;
+}
+
+template<int OBJ>
+__device__ __forceinline__ void sep_term(int j, double v, const double *aux, double &a, double &b)
+{
+    if (OBJ == OBJ_SPHERE) a += v * v;
+    else if (OBJ == OBJ_ELLIPSOID) a += aux[j] * (v * v);
+    else if (OBJ == OBJ_RASTRIGIN) a += v * v - 10. * cos_2pi(v);
+    else if (OBJ == OBJ_DIFFPOW) a += pow(fabs(v), aux[j]);
+    else {                                   // cigar / discus: coordinate 0 apart
+        if (j > 0) a += v * v;
+        else b = v * v;
+    }
+}
+
+// sum of v over the wavefront, the same total in every lane (DPP row rotations + one readlane per
+// 16-lane row: a fixed order)
+__device__ inline double sep_wave_sum(double v)
+{
+    v = row16_sum(v);
+    auto rl = [](double x, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                __builtin_amdgcn_readlane(__double2loint(x), l));
+    };
+    return ((rl(v, 0) + rl(v, 16)) + rl(v, 32)) + rl(v, 48);
+}
+
+// A wavefront takes SEP_K consecutive rows at a time: the fast step of all of them first, then
+// ONE dense settle for what they left open.  A settle round costs the wavefront ~370 instructions
+// whether one lane or sixty-four need it; settled row by row (sep_sample_eval) a round runs with
+// four or five lanes active, 1.2 rounds per row -- 105 of the 235 instructions per Philox call.
+// Here the open draws of the batch (0.43 % of 4 K n: ~18 at n = 1024) are gathered into a list
+// (ballot + prefix count per pass, as many passes as the busiest lane has open draws) and settled
+// by CONSECUTIVE lanes, one round for up to 64 of them; the settled value goes to HBM and its
+// term to the row's sum through one wavefront reduction per row -- any lane can settle any draw
+// because nothing has to come back to a register of the lane that drew it.
+constexpr int SEP_K = 4;
+constexpr int SEP_PLIST = 128;
+
+// NC > 0: ld = 256 NC exactly and the lane keeps the mean and sigma d of ITS 4 NC columns in
+// registers for all rows (the columns a lane draws depend on the lane and the call only).  Read
+// next to their use -- load, wait, multiply, store, four times per call, each wait behind the
+// store in front of it on the one in-order memory counter -- they were what the kernel waited for
+// (round 4, from the ISA: the settle work had gone and the time had not).  NC = 0: any ld, loads.
+template<int OBJ, int T, int NC>
+__device__ __forceinline__ void sep_sample_sum_body(const CmaDev &d, const CmaConst &c,
+        const double2 *ntab, int *plist)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    constexpr int R = T / 64;
+    const int tid = threadIdx.x, r = tid >> 6, g = tid & 63;
+    const int ld = c.ld;
+    const int gen = sc->it;
+    const double sigma = sc->sigma;
+    const double *xm = d.xmean + (size_t) p * ld, *dd = d.D + (size_t) p * ld;
+    const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
+    int *pl = plist + r * SEP_PLIST;
+    const int chunks = c.lambda_pad / (R * SEP_K);
+    constexpr int NCR = NC > 0 ? NC : 1;
+    double mreg[NCR][4], sreg[NCR][4];
+    if (NC > 0) {
+#pragma unroll
+        for (int it = 0; it < NCR; it++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = cma_quad_col0(g + 64 * it) + 4 * i;
+                mreg[it][i] = xm[j];
+                sreg[it][i] = sigma * dd[j];
+            }
+    }
+    for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const int row0 = (chunk * R + r) * SEP_K;
+        double *X0 = d.X + ((size_t) p * c.lambda_pad + row0) * ld;
+        double a[SEP_K], b[SEP_K];
+        uint32_t pend[SEP_K];                        // 4 bits per call, <= 8 calls per lane and row
+#pragma unroll
+        for (int k = 0; k < SEP_K; k++) {
+            a[k] = b[k] = 0.;
+            pend[k] = 0;
+            double *Xp = X0 + (size_t) k * ld;
+            auto one_call = [&](int q, int it, const double (&mm)[4], const double (&ss)[4]) {
+                double z[4];
+                const uint32_t open = normal_quad_fast(c.seed, (uint32_t) (row0 + k), (uint32_t) q,
+                        (uint32_t) gen, sw, ntab, z[0], z[1], z[2], z[3]);
+                pend[k] |= open << (4 * it);
+                const int j0 = cma_quad_col0(q);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = j0 + 4 * i;
+                    const double v = mm[i] + ss[i] * z[i];
+                    Xp[j] = v;
+                    // (an open draw's term is added when it is settled: nothing to take back)
+                    double ta = 0., tb = b[k];
+                    sep_term<OBJ>(j, v, d.aux, ta, tb);
+                    const bool ok = !((open >> i) & 1u);
+                    a[k] += ok ? ta : 0.;
+                    b[k] = ok ? tb : b[k];
+                }
+                // (one call at a time: left alone the scheduler interleaves the sixteen calls of a
+                // batch and needs 512 registers for it -- one wavefront per SIMD)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (NC > 0) {
+#pragma unroll
+                for (int it = 0; it < NCR; it++) one_call(g + 64 * it, it, mreg[it], sreg[it]);
+            } else {
+                int it = 0;
+                for (int q = g; q < ld / 4; q += 64, it++) {
+                    double mm[4], ss[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int j = cma_quad_col0(q) + 4 * i;
+                        mm[i] = xm[j];
+                        ss[i] = sigma * dd[j];
+                    }
+                    one_call(q, it, mm, ss);
+                }
+            }
+        }
+        // ---- the open draws of the batch, densely ---------------------------------------------
+        for (;;) {
+            int cnt = 0;
+            for (;;) {                               // gather up to SEP_PLIST of them
+                int k = -1;
+#pragma unroll
+                for (int kk = SEP_K - 1; kk >= 0; kk--) k = pend[kk] ? kk : k;
+                const bool has = k >= 0;
+                const unsigned long long mk = __ballot(has);
+                if (!mk) break;
+                const int slot = cnt + __popcll(mk & ((1ull << g) - 1ull));
+                if (has && slot < SEP_PLIST) {
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int kk = 0; kk < SEP_K; kk++) pk = kk == k ? pend[kk] : pk;
+                    const int bit = __ffs(pk) - 1;
+                    pl[slot] = (g << 16) | (k << 8) | bit;
+#pragma unroll
+                    for (int kk = 0; kk < SEP_K; kk++) pend[kk] = kk == k ? (pk & (pk - 1)) : pend[kk];
+                }
+                cnt += __popcll(mk);
+                if (cnt >= SEP_PLIST) break;
+            }
+            if (cnt == 0) break;
+            cnt = min(cnt, SEP_PLIST);
+            cma_wave_sync();
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                double ta = 0., tb = 0.;
+                int ek = -1, ej = -1;
+                if (i0 + g < cnt) {
+                    const int e = pl[i0 + g];
+                    const int sl = e >> 16, bit = e & 255;
+                    ek = (e >> 8) & 255;
+                    const int q = sl + 64 * (bit >> 2);
+                    ej = cma_quad_col0(q) + 4 * (bit & 3);
+                    const double z = normal_quad_settle(c.seed, (uint32_t) (row0 + ek), (uint32_t) q,
+                            (uint32_t) (bit & 3), (uint32_t) gen, sw, ntab, zig_global_f());
+                    const double v = xm[ej] + sigma * dd[ej] * z;
+                    X0[(size_t) ek * ld + ej] = v;
+                    sep_term<OBJ>(ej, v, d.aux, ta, tb);
+                }
+#pragma unroll
+                for (int kk = 0; kk < SEP_K; kk++) {
+                    const double sa = sep_wave_sum(ek == kk ? ta : 0.);
+                    if (g == 0) a[kk] += sa;
+                    if (OBJ == OBJ_CIGAR || OBJ == OBJ_DISCUS) {
+                        const double sb = sep_wave_sum((ek == kk && ej == 0) ? tb : 0.);
+                        if (g == 0) b[kk] += sb;        // (lane 0 draws column 0: its b was left 0)
+                    }
+                }
+            }
+            cma_wave_sync();
+        }
+#pragma unroll
+        for (int k = 0; k < SEP_K; k++) {
+            const double sa = group_sum<64>(a[k]);
+            double f = sa;
+            if (OBJ == OBJ_RASTRIGIN) f = 10. * c.n + sa;
+            if (OBJ == OBJ_CIGAR || OBJ == OBJ_DISCUS) {
+                const double sb = group_sum<64>(b[k]);   // (one lane holds x_0^2, the others 0)
+                f = OBJ == OBJ_CIGAR ? sb + 1.0e6 * sa : 1.0e6 * sb + sa;
+            }
+            if (g == 0) d.f[(size_t) p * c.lambda_pad + row0 + k] = f != f ? BBO_INF : f;
+        }
+    }
+}
+
+// (a kernel per objective: in one kernel behind a switch every objective paid the register
+// allocation of the hungriest -- pow and the cosine, inlined per coordinate)
+template<int T, int NC, int OBJ>
+__global__ __launch_bounds__(T) void sep_sample_sum(CmaDev d, CmaConst c)
+{
+    if (pop_frozen(c, d.scal + blockIdx.y)) return;
+    __shared__ double2 ntab[NORMAL_TABLE_N];
+    __shared__ int plist[(T / 64) * SEP_PLIST];
+    normal_table_fill(ntab, threadIdx.x, T);
+    __syncthreads();
+    sep_sample_sum_body<OBJ, T, NC>(d, c, ntab, plist);
+}
+
+// ---------------------------------------------------------------------------
 // first and second weighted moments of the mu best candidates, slab s of the ranks:
 //   mean_part[s][j] = sum_k w_k x_k[j]                      (sep_cmaes.cpp:88-93)
 //   gram_part[s][j] = sum_k w_k ((x_k[j] - m_j) / sigma)^2  (:124-128)

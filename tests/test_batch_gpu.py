@@ -152,22 +152,56 @@ def test_lean_sampler_build_equals_the_general_one(hip, lam, P):
 
 def test_lean_separable_sampler_equals_the_general_one(hip):
     """sep_sample_eval has the same kind of lean build (n == ld, no box, lambda == lambda_pad: the
-    benchmark's SEP shape): X, f and the state downstream BIT-IDENTICAL to the general build."""
+    benchmark's SEP shape): X, f and the state downstream BIT-IDENTICAL to the general build
+    (diagnostic bit 1048576 keeps the row-in-LDS form where the sum-on-draw kernel would run)."""
     n, lam, P = 1024, 256, 4
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
     guess = np.random.default_rng(6).uniform(-5, 5, (P, n))
     runs = []
-    for dbg in (0, 256):
+    for dbg in (1048576, 256):
         g = hip.SepCMAES(mfev=10 ** 9, tol=0., np=lam, seed=78, populations=P)
         g.initialize(hip.objectives.ellipsoid, lo, up, guess)
-        if dbg:
-            g.set_state("dbg", [float(dbg)])
+        g.set_state("dbg", [float(dbg)])
         g.run(5)
         runs.append([(g.get_state("arx", p), g.get_state("fitness", p), g.get_state("D", p), g.get_state("csep", p),
                       g.get_state("sigma", p)) for p in (0, P - 1)])
     for a, b in zip(runs[0], runs[1]):
         for u, v in zip(a, b):
             np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.parametrize("obj", ["sphere", "ellipsoid", "rastrigin", "cigar", "discus", "diffpow"])
+@pytest.mark.parametrize("n,lam", [(1024, 256), (512, 64), (2048, 48)])
+def test_sum_on_draw_separable_sampler(hip, obj, n, lam):
+    """sep_sample_sum (objectives that are sums of per-coordinate terms, lean shapes): no row in
+    LDS, a lane adds the terms of the coordinates it draws.  X is BIT-IDENTICAL to the row-in-LDS
+    kernel's (same Philox counters, same ziggurat, same x = m + sigma d z); f equals the objective
+    of the stored row (numpy, and the row-in-LDS kernel's value) to rounding -- the terms are added
+    in another order."""
+    from bboptpy_amd import _ffi
+    P = 3
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(n + lam).uniform(-4, 4, (P, n))
+    out = []
+    for dbg in (0, 1048576):
+        g = hip.SepCMAES(mfev=10 ** 9, tol=0., np=lam, seed=5, populations=P)
+        g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+        if dbg:
+            g.set_state("dbg", [float(dbg)])
+        g.run(2)
+        g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+        out.append([(g.get_state("arx", p).reshape(lam, n), g.get_state("fitness", p)[:lam]) for p in range(P)])
+    t = np.arange(n) / (n - 1.)
+    for (Xa, fa), (Xb, fb) in zip(*out):
+        np.testing.assert_array_equal(Xa, Xb)
+        np.testing.assert_allclose(fa, fb, rtol=2e-13, atol=0)
+        want = {"sphere": lambda X: (X * X).sum(1),
+                "ellipsoid": lambda X: ((10. ** (6. * t)) * X * X).sum(1),
+                "rastrigin": lambda X: 10. * n + (X * X - 10. * np.cos(2. * np.pi * X)).sum(1),
+                "cigar": lambda X: X[:, 0] ** 2 + 1e6 * (X[:, 1:] ** 2).sum(1),
+                "discus": lambda X: 1e6 * X[:, 0] ** 2 + (X[:, 1:] ** 2).sum(1),
+                "diffpow": lambda X: (np.abs(X) ** (2. + 4. * t)).sum(1)}[obj](Xa)
+        np.testing.assert_allclose(fa, want, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("variant,n,lam,P", [("ActiveCMAES", 128, 4096, 8), ("ActiveCMAES", 128, 1000, 16),
