@@ -92,6 +92,7 @@ def lib():
     L.bbo_cma_set_seed.argtypes = [C.c_void_p, C.c_uint64]
     L.bbo_cma_evaluate.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_double)]
     L.bbo_ccpso_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.bbo_ccpso_set_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.bbo_ccpso_phase.argtypes = [C.c_void_p, C.c_int]
     L.bbo_ccpso_table_record.argtypes = [C.c_void_p]
     L.bbo_ccpso_export_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -103,7 +104,7 @@ def lib():
     for name in ("bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init", "bbo_iterate",
                  "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
                  "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
-                 "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_phase",
+                 "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_set_local", "bbo_ccpso_phase",
                  "bbo_ccpso_table_record", "bbo_ccpso_export_tables", "bbo_ccpso_merge_tables"):
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -114,7 +115,7 @@ EXPORTED_SYMBOLS = (
     "bbo_params_default", "bbo_create", "bbo_create_restart", "bbo_destroy", "bbo_init",
     "bbo_iterate", "bbo_solution", "bbo_solution_of", "bbo_optimize", "bbo_run", "bbo_get",
     "bbo_set", "bbo_cma_phase_run", "bbo_cma_inject_normals", "bbo_cma_set_params",
-    "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_phase",
+    "bbo_cma_set_seed", "bbo_cma_evaluate", "bbo_ccpso_set_shard", "bbo_ccpso_set_local", "bbo_ccpso_phase",
     "bbo_ccpso_table_record", "bbo_ccpso_export_tables", "bbo_ccpso_merge_tables",
     "bbo_last_error", "bbo_version",
     "bbo_device_count",

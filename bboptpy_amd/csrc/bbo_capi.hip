@@ -325,6 +325,15 @@ int bbo_ccpso_set_shard(bbo_handle h, int rank, int world)
     return guarded(h, [&] { as_ccpso(h)->set_shard(rank, world); });
 }
 
+int bbo_ccpso_set_local(bbo_handle h, bbo_handle local, int localfreq)
+{
+    return guarded(h, [&] {
+        if (local && !local->opt) throw bbo::Error(BBO_ERR_ARG, "bbo_ccpso_set_local: dead local handle");
+        if (local == h) throw bbo::Error(BBO_ERR_ARG, "bbo_ccpso_set_local: local must be another optimizer");
+        as_ccpso(h)->set_local(local ? local->opt.get() : nullptr, localfreq);
+    });
+}
+
 int bbo_ccpso_phase(bbo_handle h, int phase)
 {
     return guarded(h, [&] { as_ccpso(h)->phase(phase); });

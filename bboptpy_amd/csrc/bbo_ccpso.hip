@@ -1,5 +1,6 @@
 // bbo_ccpso.hip -- host side of the CCPSO2 engine (ccpso.cpp:51-148; no local optimizer).
 #include "bbo_ccpso_kernels.hpp"
+#include "bbo_cma.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -90,6 +91,9 @@ void CcpsoEngine::init(int n, const double *lower, const double *upper, const do
     lower_.upload(lo.data(), ld);
     upper_.upload(up.data(), ld);
     aux_.upload(aux_h_.data(), ld);
+    lower_h_.assign(lower, lower + n);
+    upper_h_.assign(upper, upper + n);
+    nlocal_ = 0;
     std::vector<int> zi(sw, 0);
     strat_.upload(zi.data(), sw);
     ibest_.upload(zi.data(), sw);
@@ -344,13 +348,145 @@ void CcpsoEngine::require_unsharded(const char *what) const
                 "bbo_ccpso_phase(0) / bbo_ccpso_merge_tables / bbo_ccpso_phase(1)");
 }
 
+// ---- the local optimizer (CCPSOSearch::localSearch, ccpso.cpp:371-435; adaptive weighting) -----
+// Every `localfreq` generations one weight per swarm, scaling that swarm's coordinates of the
+// context vector, is optimized by `local` inside the box that keeps the scaled vector in bounds;
+// the result replaces yhat if it is better.  The generations run on the device, the search is
+// driven from here: its objective is a host callback that evaluates f(yhat * w[group]) (the
+// caller's callable, or the built-in's formula on the host).  Each search starts `local` afresh
+// (B = C = I) under the seed base + search index -- the reference's CMA-ES objects start from the
+// previous search's matrices (cmaes.cpp:53-54), which corrupts the heap when the swarm count
+// grows; not reproduced (CCPSO2).
+void CcpsoEngine::set_local(Optimizer *local, int localfreq)
+{
+    BBO_REQUIRE(c_.npop <= 1 && params_.populations <= 1,
+            "CCPSO: the local optimizer works on one population");
+    local_ = local;
+    localfreq_ = localfreq;
+    nlocal_ = 0;
+    if (auto *cma = dynamic_cast<CmaEngine*>(local)) local_seed0_ = cma->seed();
+}
+
+double CcpsoEngine::eval_full(const double *x)
+{
+    if (!obj_.on_device()) {
+        double f = 0.;
+        obj_.eval_host(x, 1, c_.n, c_.n, &f);
+        return f != f ? std::numeric_limits<double>::infinity() : f;
+    }
+    return builtin_objective_host(obj_.builtin, c_.n, x, aux_h_.data());
+}
+
+namespace {
+struct LocalCtx {
+    CcpsoEngine *eng;
+    const double *yhat;
+    const int *group;
+    int n;
+    std::vector<double> x;
+    std::string error;
+};
+
+double local_objective(const double *w, int nsw, void *user, int *failed)
+{
+    (void) nsw;
+    auto *cx = static_cast<LocalCtx*>(user);
+    for (int j = 0; j < cx->n; j++) cx->x[j] = cx->yhat[j] * w[cx->group[j]];
+    try {
+        return cx->eng->eval_full(cx->x.data());
+    } catch (const std::exception &e) {
+        cx->error = e.what();
+        *failed = 1;
+        return 0.;
+    }
+}
+}
+
+void CcpsoEngine::local_search()
+{
+    const int n = c_.n;
+    BBO_HIP(hipStreamSynchronize(stream_));
+    CcpScal s;
+    scal_.download(&s, 1, 0);
+    std::vector<double> yh(c_.ld);
+    yhat_.download(yh.data(), c_.ld, 0);
+    std::vector<int> k(n);                       // position -> coordinate, swarm-major
+    range_.download(k.data(), n, 0);
+    const int cps = s.cpswarm, nsw = s.nswarm;
+    std::vector<int> group(n);
+    for (int pos = 0; pos < n; pos++) group[k[pos]] = pos / cps;
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> wlb(nsw, -inf), wub(nsw, inf), wguess(nsw);
+    for (int j = 0; j < n; j++) {
+        const double y = yh[j];
+        const double scale = std::fabs(y) < 1e-3 ? (y > 0. ? 1e-3 : -1e-3) : y;
+        double lb = lower_h_[j] / scale, ub = upper_h_[j] / scale;
+        if (lb > ub) std::swap(lb, ub);
+        wlb[group[j]] = std::max(wlb[group[j]], lb);
+        wub[group[j]] = std::min(wub[group[j]], ub);
+    }
+    for (int g = 0; g < nsw; g++) wguess[g] = std::max(wlb[g], std::min(1., wub[g]));
+
+    LocalCtx cx { this, yh.data(), group.data(), n, std::vector<double>(n), std::string() };
+    ObjectiveSpec faux;
+    faux.kind = BBO_OBJECTIVE_SCALAR_CALLBACK;
+    faux.scalar = local_objective;
+    faux.user = &cx;
+    if (auto *cma = dynamic_cast<CmaEngine*>(local_)) cma->fresh_start(local_seed0_ + (uint64_t) nlocal_);
+    nlocal_++;
+    std::vector<double> w(nsw);
+    int lfev = 0, lconv = 0;
+    local_->optimize(nsw, wlb.data(), wub.data(), wguess.data(), faux, w.data(), &lfev, &lconv);
+    BBO_HIP(hipSetDevice(params_.device));       // (the local optimizer may live on another device)
+    int fev = s.fev + lfev;
+    std::vector<double> trial(c_.ld, 0.);
+    bool inside = true;
+    for (int j = 0; j < n; j++) {
+        trial[j] = yh[j] * w[group[j]];
+        if (c_.correct && !(trial[j] >= lower_h_[j] && trial[j] <= upper_h_[j])) inside = false;
+    }
+    scal_.download(&s, 1, 0);
+    if (inside) {
+        const double fwy = eval_full(trial.data());
+        fev++;
+        if (fwy < s.fyhat) {
+            yhat_.upload(trial.data(), c_.ld, 0);
+            s.fyhat = fwy;
+            s.improved = 1;
+        }
+    }
+    s.fev = fev;
+    // (the reference tests the budget right after the search, ccpso.cpp:137-141: the next
+    // generation must not start once the search has spent it)
+    if (fev >= c_.mfev && !s.stop) s.stop = 2;
+    scal_.upload(&s, 1, 0);
+}
+
+void CcpsoEngine::after_generation(int gen_before)
+{
+    if (local_ && localfreq_ > 0 && gen_before % localfreq_ == 0) {   // ccpso.cpp:116-118
+        CcpScal s;
+        BBO_HIP(hipStreamSynchronize(stream_));
+        scal_.download(&s, 1, 0);
+        if (!s.stop) local_search();
+    }
+}
+
 void CcpsoEngine::iterate()
 {
     if (!inited_) throw Error(BBO_ERR_STATE, "iterate() before initialize()");
     require_unsharded("iterate()");
     BBO_HIP(hipSetDevice(params_.device));
+    int gen0 = 0;
+    if (local_) {
+        CcpScal s;
+        BBO_HIP(hipStreamSynchronize(stream_));
+        scal_.download(&s, 1, 0);
+        gen0 = s.gen;
+    }
     generation(false);
     BBO_HIP(hipStreamSynchronize(stream_));
+    if (local_ && localfreq_ > 0 && gen0 % localfreq_ == 0) local_search();
     timer_.collect();
 }
 
@@ -373,9 +509,16 @@ int CcpsoEngine::run(int max_generations)
     int done = 0;
     while (done < max_generations) {
         if (all_stopped()) break;
-        const int chunk = obj_.on_device() ? std::min(poll, max_generations - done) : 1;
+        const int chunk = (obj_.on_device() && !local_) ? std::min(poll, max_generations - done) : 1;
+        int gen0 = 0;
+        if (local_) {
+            CcpScal s;
+            scal_.download(&s, 1, 0);
+            gen0 = s.gen;
+        }
         for (int g = 0; g < chunk; g++) generation(true);
         BBO_HIP(hipStreamSynchronize(stream_));
+        if (local_) after_generation(gen0);
         timer_.collect();
         done += chunk;
     }

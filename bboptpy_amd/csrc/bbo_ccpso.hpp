@@ -63,6 +63,10 @@ public:
     void export_tables(double *dst, bool device_memory);
     void merge_tables(const double *gathered, int world, bool device_memory);
 
+    // ---- the optional local optimizer (ccpso.cpp:116-118, 371-435; bbo_ccpso_set_local) ------
+    void set_local(Optimizer *local, int localfreq);
+    double eval_full(const double *x);     // the objective at one n-vector, on the host
+
 private:
     void launch_regroup_eval();
     void launch_rest();
@@ -80,6 +84,12 @@ private:
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
     int shard_rank_ = 0, shard_world_ = 1;     // survive init() (c_ is rebuilt there)
+    void local_search();
+    void after_generation(int gen_before);
+    Optimizer *local_ = nullptr;               // borrowed, like the reference's `local` pointer
+    int localfreq_ = 10, nlocal_ = 0;
+    uint64_t local_seed0_ = 0;
+    std::vector<double> lower_h_, upper_h_;
     std::vector<double> aux_h_;
     DevBuf<double> X_, Y_, yhat_, ysave_, fX_, fY_, radius_, rpart_, lower_, upper_, aux_, gather_, stage_;
     DevBuf<int> ibest_, strat_, range_, grp_of_;

@@ -803,61 +803,7 @@ double CmaEngine::evaluate_point(const double *x)
     }
     // restart drivers re-evaluate one point per restart (bipop_cmaes.cpp:86): host
     // arithmetic with the same definition and the same per-coordinate table
-    const int obj = obj_.builtin, n = c_.n;
-    const double *aux = aux_h_.data();
-    double s = 0.;
-    switch (obj) {
-    case BBO_OBJ_SPHERE:
-        for (int i = 0; i < n; i++) s += x[i] * x[i];
-        return s;
-    case BBO_OBJ_ROSENBROCK:
-        for (int i = 0; i + 1 < n; i++) {
-            const double a = x[i + 1] - x[i] * x[i], b = 1. - x[i];
-            s += 100. * (a * a) + b * b;
-        }
-        return s;
-    case BBO_OBJ_RASTRIGIN:
-        for (int i = 0; i < n; i++) s += x[i] * x[i] - 10. * std::cos(TWO_PI * x[i]);
-        return 10. * n + s;
-    case BBO_OBJ_ELLIPSOID:
-        for (int i = 0; i < n; i++) s += aux[i] * (x[i] * x[i]);
-        return s;
-    case BBO_OBJ_ACKLEY: {
-        double cs = 0.;
-        for (int i = 0; i < n; i++) {
-            s += x[i] * x[i];
-            cs += std::cos(TWO_PI * x[i]);
-        }
-        return -20. * std::exp(-0.2 * std::sqrt(s / n)) - std::exp(cs / n) + 20. + EULER_E;
-    }
-    case BBO_OBJ_GRIEWANK: {
-        double pr = 1.;
-        for (int i = 0; i < n; i++) {
-            s += x[i] * x[i];
-            pr *= std::cos(x[i] * aux[i]);
-        }
-        return 1. + s / 4000. - pr;
-    }
-    case BBO_OBJ_CIGAR:
-        for (int i = 1; i < n; i++) s += x[i] * x[i];
-        return x[0] * x[0] + 1.0e6 * s;
-    case BBO_OBJ_DISCUS:
-        for (int i = 1; i < n; i++) s += x[i] * x[i];
-        return 1.0e6 * (x[0] * x[0]) + s;
-    case BBO_OBJ_DIFFPOW:
-        for (int i = 0; i < n; i++) s += std::pow(std::fabs(x[i]), aux[i]);
-        return s;
-    case BBO_OBJ_SCHWEFEL12: {
-        double run = 0.;
-        for (int i = 0; i < n; i++) {
-            run += x[i];
-            s += run * run;
-        }
-        return s;
-    }
-    default:
-        throw Error(BBO_ERR_ARG, "unknown builtin objective");
-    }
+    return builtin_objective_host(obj_.builtin, c_.n, x, aux_h_.data());
 }
 
 // ---- named state access ---------------------------------------------------------------

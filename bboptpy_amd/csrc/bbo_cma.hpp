@@ -105,6 +105,12 @@ public:
     int populations() const { return params_.populations; }
     uint64_t seed() const { return params_.seed; }
     void set_seed(uint64_t s) { params_.seed = s; }
+    // the next init() starts like a new object: B = C = I (not the previous run's, cmaes.cpp:53-59)
+    void fresh_start(uint64_t s)
+    {
+        params_.seed = s;
+        keep_bc_ = false;
+    }
 
 private:
     void generation(bool honor_stop);

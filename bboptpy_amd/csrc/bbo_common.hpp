@@ -207,6 +207,68 @@ inline void fill_objective_aux(int obj, int n, double *aux)
     }
 }
 
+// a built-in objective at ONE point on the host: the same definition and the same per-coordinate
+// table as the device kernels (bbo_objectives.hpp).  For the few places that evaluate a single
+// point between device generations: the restart drivers' extra evaluation (bipop_cmaes.cpp:86),
+// CCPSO's local search (ccpso.cpp:371-435).
+inline double builtin_objective_host(int obj, int n, const double *x, const double *aux)
+{
+    const double two_pi = 6.283185307179586476925286766559, euler_e = 2.718281828459045235360287471352;
+    double s = 0.;
+    switch (obj) {
+    case BBO_OBJ_SPHERE:
+        for (int i = 0; i < n; i++) s += x[i] * x[i];
+        return s;
+    case BBO_OBJ_ROSENBROCK:
+        for (int i = 0; i + 1 < n; i++) {
+            const double a = x[i + 1] - x[i] * x[i], b = 1. - x[i];
+            s += 100. * (a * a) + b * b;
+        }
+        return s;
+    case BBO_OBJ_RASTRIGIN:
+        for (int i = 0; i < n; i++) s += x[i] * x[i] - 10. * std::cos(two_pi * x[i]);
+        return 10. * n + s;
+    case BBO_OBJ_ELLIPSOID:
+        for (int i = 0; i < n; i++) s += aux[i] * (x[i] * x[i]);
+        return s;
+    case BBO_OBJ_ACKLEY: {
+        double cs = 0.;
+        for (int i = 0; i < n; i++) {
+            s += x[i] * x[i];
+            cs += std::cos(two_pi * x[i]);
+        }
+        return -20. * std::exp(-0.2 * std::sqrt(s / n)) - std::exp(cs / n) + 20. + euler_e;
+    }
+    case BBO_OBJ_GRIEWANK: {
+        double pr = 1.;
+        for (int i = 0; i < n; i++) {
+            s += x[i] * x[i];
+            pr *= std::cos(x[i] * aux[i]);
+        }
+        return 1. + s / 4000. - pr;
+    }
+    case BBO_OBJ_CIGAR:
+        for (int i = 1; i < n; i++) s += x[i] * x[i];
+        return x[0] * x[0] + 1.0e6 * s;
+    case BBO_OBJ_DISCUS:
+        for (int i = 1; i < n; i++) s += x[i] * x[i];
+        return 1.0e6 * (x[0] * x[0]) + s;
+    case BBO_OBJ_DIFFPOW:
+        for (int i = 0; i < n; i++) s += std::pow(std::fabs(x[i]), aux[i]);
+        return s;
+    case BBO_OBJ_SCHWEFEL12: {
+        double run = 0.;
+        for (int i = 0; i < n; i++) {
+            run += x[i];
+            s += run * run;
+        }
+        return s;
+    }
+    default:
+        throw Error(BBO_ERR_ARG, "unknown builtin objective");
+    }
+}
+
 // The C++ statement of MultivariateOptimizer (multivariate.h:132-146) that every
 // engine implements and the C ABI dispatches to.
 class Optimizer {

@@ -442,15 +442,17 @@ class CCPSO(MultivariateSearch):
     -- :291-295 (cooperatively coevolving PSO, Li & Yao 2012; ccpso.cpp).  `pps` lists the
     candidate swarm sizes (each must divide n).
 
-    `local` (ccpso.cpp:116-118, 371-435): another optimizer of this package (any object with
-    optimize(f, lower, upper, guess) -> solution carrying .x and .n_evals).  Every `localfreq`
-    generations one weight per swarm, scaling that swarm's coordinates of the context vector, is
-    optimized by it inside the box that keeps the scaled vector in bounds, and the result
-    replaces the context vector if it is better.  The generations run on the device; the local
-    search is driven from here (its objective evaluates on the host: the callable itself, or the
-    built-in's formula), one population only.  Each search starts `local` afresh with the seed
-    base + search index (the reference's CMA-ES objects start from the previous search's
-    matrices, cmaes.cpp:53-54 -- not reproduced)."""
+    `local` (ccpso.cpp:116-118, 371-435): another optimizer.  Every `localfreq` generations one
+    weight per swarm, scaling that swarm's coordinates of the context vector, is optimized by it
+    inside the box that keeps the scaled vector in bounds, and the result replaces the context
+    vector if it is better.  The generations run on the device; the search's objective evaluates
+    on the host (the callable itself, or the built-in's formula), one population only.  Each
+    search starts `local` afresh with the seed base + search index (the reference's CMA-ES
+    objects start from the previous search's matrices, cmaes.cpp:53-54 -- not reproduced).
+    A CMA-ES optimizer of THIS package is handed to the library (bbo_ccpso_set_local: the whole
+    loop then runs behind bbo_iterate / bbo_optimize, as for a C caller); any other object with
+    optimize(f, lower, upper, guess) -> solution carrying .x and .n_evals is driven from here
+    between device generations through bbo_get / bbo_set."""
     _algo = _ffi.ALGO_CCPSO
 
     def __init__(self, mfev, sigmatol, np, pps, npps=None, correct=True, pcauchy=-1., local=None,
@@ -474,6 +476,31 @@ class CCPSO(MultivariateSearch):
         self._local, self._localfreq = local, int(localfreq)
         self._nlocal = 0
         self._local_seed0 = getattr(getattr(local, "_params", None), "seed", 0)
+        # a CMA-ES object of this package: the search runs inside the library
+        self._local_native = isinstance(local, BaseCMAES)
+        self._local_handle = None
+
+    def _attach_local(self):
+        """(native local optimizer) hand its handle to the engine; again whenever either handle
+        has been re-created"""
+        lh = self._local._ensure_handle()
+        if self._local_handle is not lh:
+            self._check(_ffi.lib().bbo_ccpso_set_local(self._handle, lh, self._localfreq))
+            self._local_handle = lh
+
+    def _create(self):
+        h = super()._create()
+        self._local_handle = None
+        return h
+
+    def __del__(self):
+        # detach first: the engine only borrows the local optimizer's handle
+        try:
+            if getattr(self, "_handle", None) is not None and getattr(self, "_local_native", False):
+                _ffi.lib().bbo_ccpso_set_local(self._handle, None, 0)
+        except Exception:
+            pass
+        super().__del__()
 
     # ---- swarm groups sharded over GPUs (bboptpy_amd.distributed.ShardedCCPSO) ---------------
     def set_shard(self, rank, world):
@@ -510,6 +537,10 @@ class CCPSO(MultivariateSearch):
 
     # ---- the reference's loop with the local search between generations ------------------
     def initialize(self, f, lower, upper, guess):
+        if self._local is not None and self._local_native:
+            self._ensure_handle()
+            self._attach_local()
+            return super().initialize(f, lower, upper, guess)
         super().initialize(f, lower, upper, guess)
         if isinstance(f, str):
             from . import objectives as _objectives
@@ -519,13 +550,27 @@ class CCPSO(MultivariateSearch):
         self._nlocal = 0
 
     def iterate(self):
+        if self._local is not None and self._local_native:
+            self._attach_local()
+            return super().iterate()
         gen = int(self.get_state("it")[0]) if self._local is not None else 0
         super().iterate()
         if self._local is not None and self._localfreq > 0 and gen % self._localfreq == 0:
             self._local_search()
 
+    def run(self, max_generations):
+        if self._local is not None and not self._local_native:
+            raise RuntimeError("CCPSO.run() with a local optimizer driven from Python: use iterate()")
+        if self._local is not None:
+            self._attach_local()
+        return super().run(max_generations)
+
     def optimize(self, f, lower, upper, guess):
         if self._local is None:
+            return super().optimize(f, lower, upper, guess)
+        if self._local_native:
+            self._ensure_handle()
+            self._attach_local()
             return super().optimize(f, lower, upper, guess)
         self.initialize(f, lower, upper, guess)
         mfev = self._params.mfev

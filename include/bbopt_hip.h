@@ -151,7 +151,7 @@ typedef struct {
     int ring;              /* ring neighbourhood instead of the swarm mean         */
     double vmax;           /* velocity clamp as a fraction of the box width        */
     /* CCPSO(mfev,sigmatol,np,pps,npps,correct=True,pcauchy=-1,local=None,localfreq=10) :291-295
-     * (`sigmatol` travels in `tol`; the optional local optimizer is not supported) */
+     * (`sigmatol` travels in `tol`; the optional local optimizer: bbo_ccpso_set_local below) */
     int npps;              /* number of candidate swarm sizes                      */
     int pps[16];           /* the candidate swarm sizes (each must divide n)       */
     double pcauchy;        /* fixed Cauchy rate in (0,1), else adaptive            */
@@ -259,6 +259,15 @@ int bbo_cma_evaluate(bbo_handle h, const double *x, double *f_out);
  * has copied `gathered` when it returns.  bbo_ccpso_export_tables with device_memory != 0 has
  * finished writing `dst` when it returns (the collective may start at once). */
 int bbo_ccpso_set_shard(bbo_handle h, int rank, int world);
+/* CCPSO's optional local optimizer (CCPSOSearch(..., local, localfreq), ccpso.cpp:51-70; used at
+ * :116-118 and :371-435; py/multivariate_py.cpp:291-295).  `local` is BORROWED, like the
+ * reference's pointer (and like `base` of bbo_create_restart): it must outlive h or be detached
+ * with bbo_ccpso_set_local(h, NULL, 0).  After generation g with g % localfreq == 0, bbo_iterate /
+ * bbo_run / bbo_optimize optimize one weight per swarm with it (objective evaluated on the host:
+ * the callback of h's objective, or the built-in's formula), replace the context vector if the
+ * result is better and charge the evaluations.  A CMA-ES `local` starts every search afresh
+ * (B = C = I, seed = its own seed + search index).  One population; not with bbo_ccpso_set_shard. */
+int bbo_ccpso_set_local(bbo_handle h, bbo_handle local, int localfreq);
 int bbo_ccpso_phase(bbo_handle h, int phase);
 int bbo_ccpso_table_record(bbo_handle h);
 int bbo_ccpso_export_tables(bbo_handle h, double *dst, int device_memory);

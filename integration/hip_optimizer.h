@@ -41,6 +41,16 @@ public:
     explicit HipOptimizer(const bbo_params &prm) {
         if (bbo_create(&prm, &_h) != BBO_OK) fail(nullptr);
     }
+    /* the optimizers that take another optimizer, as the reference's constructors do
+     * (IPopCmaes / BiPopCmaes(base, ...): ipop_cmaes.cpp:41, bipop_cmaes.cpp:41;
+     *  CCPSOSearch(..., local, localfreq): ccpso.cpp:51-70): the other object is borrowed and must
+     * outlive this one, exactly like the reference's raw pointer */
+    HipOptimizer(const bbo_params &prm, HipOptimizer &base) {
+        if (bbo_create_restart(&prm, base._h, &_h) != BBO_OK) fail(nullptr);
+    }
+    void setLocal(HipOptimizer *local, int localfreq) {       /* CCPSO only */
+        if (bbo_ccpso_set_local(_h, local ? local->_h : nullptr, localfreq) < 0) fail(_h);
+    }
     HipOptimizer(const HipOptimizer&) = delete;
     HipOptimizer &operator=(const HipOptimizer&) = delete;
     ~HipOptimizer() override { bbo_destroy(_h); }

@@ -136,6 +136,73 @@ def test_local_optimizer_hook_matches_oracle(hip, oracle_lib, n, npp, cps, obj, 
     assert improved_by_local >= 1
 
 
+class _ForeignLocal:
+    """any object with optimize(f, lower, upper, guess): what the Python class drives itself"""
+
+    def __init__(self, inner):
+        self._inner, self._params = inner, inner._params
+
+    def reseed(self, seed):
+        self._inner.reseed(seed)
+
+    def optimize(self, f, lower, upper, guess):
+        return self._inner.optimize(f, lower, upper, guess)
+
+
+def test_local_search_inside_the_library_equals_the_python_driven_one(hip, oracle_lib):
+    """bbo_ccpso_set_local (a CMA-ES object of this package: the whole loop behind bbo_iterate,
+    what a C caller of INTEGRATION.md section B gets) against the same search driven from the
+    Python class through bbo_get / bbo_set (any foreign object with optimize()): the same
+    evaluation counts, context vector and swarm after every generation, bit for bit -- and the C
+    ABI used directly, without the Python class"""
+    import ctypes as C
+    from bboptpy_amd import _ffi
+    n, npp, cps, lf = 24, 8, 4, 2
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    f = lambda x: oracle_lib.objective("ellipsoid", x)
+    runs = []
+    for native in (True, False):
+        loc = hip.ActiveCMAES(mfev=320, tol=1e-9, np=16, seed=77)
+        g = hip.CCPSO(mfev=10 ** 8, sigmatol=1e-12, np=npp, pps=[cps], localfreq=lf, seed=31,
+                      local=loc if native else _ForeignLocal(loc))
+        assert g._local_native == native
+        g.initialize(f, lo, up, np.zeros(n))
+        trace = []
+        for _ in range(7):
+            g.iterate()
+            trace.append((int(g.get_state("fev")[0]), int(g.get_state("improved")[0]),
+                          g.get_state("yhat").copy(), g.get_state("x").copy(),
+                          float(g.get_state("fyhat")[0])))
+        runs.append(trace)
+    for a, b in zip(*runs):
+        assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
+        np.testing.assert_array_equal(a[2], b[2])
+        np.testing.assert_array_equal(a[3], b[3])
+    # the C ABI by hand: two handles, bbo_ccpso_set_local, bbo_optimize on a built-in objective
+    L = _ffi.lib()
+    pl = _ffi.default_params(_ffi.ALGO_CMAES)
+    pl.mfev, pl.tol, pl.np, pl.seed = 200, 1e-8, 8, 5
+    pc = _ffi.default_params(_ffi.ALGO_CCPSO)
+    pc.mfev, pc.tol, pc.np, pc.npps, pc.seed = 40000, 1e-6, 10, 1, 9
+    pc.pps[0] = 3
+    hl, hc = C.c_void_p(), C.c_void_p()
+    _ffi.check(L.bbo_create(C.byref(pl), C.byref(hl)))
+    _ffi.check(L.bbo_create(C.byref(pc), C.byref(hc)))
+    _ffi.check(L.bbo_ccpso_set_local(hc, hl, 5), hc)
+    obj = _ffi.Objective()
+    obj.kind, obj.builtin = _ffi.OBJ_BUILTIN, _ffi.BUILTIN_IDS["sphere"]
+    m = 12
+    x, fev, conv = np.zeros(m), C.c_int(), C.c_int()
+    _ffi.check(L.bbo_optimize(hc, m, -5. * np.ones(m), 5. * np.ones(m), np.zeros(m), C.byref(obj),
+                              x, C.byref(fev), C.byref(conv)), hc)
+    assert 0 < fev.value <= 40000 + 400 and float(np.sum(x * x)) < 1e-3
+    assert L.bbo_ccpso_set_local(hc, hc, 5) < 0           # itself: refused
+    assert L.bbo_ccpso_set_local(hl, hc, 5) < 0           # not a CCPSO handle: refused
+    _ffi.check(L.bbo_ccpso_set_local(hc, None, 0), hc)    # detach before the local one goes
+    L.bbo_destroy(hl)
+    L.bbo_destroy(hc)
+
+
 def test_local_optimizer_whole_run(hip):
     """optimize() with a local optimizer: the reference's loop (generation, local search every
     localfreq generations, budget test, spread test) driven from the Python class"""
