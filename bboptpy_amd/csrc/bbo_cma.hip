@@ -555,7 +555,18 @@ void CmaEngine::launch_eigen()
     else if (pl.use_lds)
         hipLaunchKernelGGL(cma_eigen, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
-    else if (pl.hybrid)
+    else if (pl.hybrid && !(d_.dbg & (2 | 1024 | 4194304))) {
+        // 128 < n <= 256: reduction, the two halves side by side (eigenvector blocks in LDS), top
+        // merge -- three launches (diagnostic bit 4194304: everything in one workgroup, round 3)
+        const EigPlan plh = eig_plan(128, 128);
+        allow_lds((const void*) cma_eigen_g1, 160 * 1024 - 768);
+        allow_lds((const void*) cma_eigen_g2, 160 * 1024 - 768);
+        allow_lds((const void*) cma_eig_halves, 160 * 1024 - 768);
+        hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
+        hipLaunchKernelGGL(cma_eig_halves, dim3(2, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,
+                plh, pl.lda);
+        hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
+    } else if (pl.hybrid)
         hipLaunchKernelGGL(cma_eigen_g, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
     else

@@ -24,7 +24,7 @@ struct CmaScal {
     int eigenlastev, eigen_done;
     int hist_head, hist_len;
     int basis_ok;             // C^-1/2 = B D^-1 B^T for the (B, D) the sampler uses (see cma_whiten128)
-    int pad0_;
+    int eig_stage;            // 128 < n <= 256, split decomposition: 1 = tridiagonal form handed to the next kernels
     int pad_;
 };
 

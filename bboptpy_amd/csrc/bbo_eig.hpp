@@ -1076,16 +1076,27 @@ __device__ inline void eig_tred_sym256(const double *C, int ld, int n, const Eig
 // leaf, the fragment reads of the merge products -- became a FLAT load or store, waited for with
 // vmcnt(0) & lgkmcnt(0) in the middle of the recurrences (round 3: read in the ISA).
 // HYB (matrix in global memory only): 1 = 128 < n <= 256, 0 = 256 < n <= 512 -- a kernel each
-template<int TT, bool LDSM, int HYB = 1>
+// STAGE (128 < n <= 256 only, round 4): 0 = the whole decomposition in this workgroup; 1 = the
+// Householder reduction only -- the tridiagonal form (d, e) and the reflectors' scalars go to
+// eig_work[3] = [d | e | h | .] and cma_eig_halves / STAGE 2 take over; 2 = the top merge of the two
+// halves cma_eig_halves has solved (their eigenvalues at eig_work[3] + 3 n, their eigenvector blocks
+// on the diagonal of the work matrix), the reflectors' T factors and the closing repair / root.
+template<int TT, bool LDSM, int HYB = 1, int STAGE = 0>
 __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &c, const EigPlan &pl,
         int force)
 {
     const int p = blockIdx.x;
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
+    if (STAGE == 2) {
+        if (sc->eig_stage != 1) return;
+    } else
     // cmaes.cpp:233: skip until enough evaluations have passed
     if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
-        if (threadIdx.x == 0) sc->eigen_done = 0;
+        if (threadIdx.x == 0) {
+            sc->eigen_done = 0;
+            sc->eig_stage = 0;
+        }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1119,6 +1130,15 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         dv[-1 - tid] = 0.;
         ev[-1 - tid] = 0.;
     }
+    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld);     // (STAGE 1 / 2 hand-over)
+    if (STAGE == 2) {
+        for (int i = tid; i < n; i += T) {
+            dv[i] = tri[3 * n + i];
+            ev[i] = tri[n + i];
+            hvec[i] = tri[2 * n + i];
+        }
+        __syncthreads();
+    } else {
     if (LDSM) {      // (use_lds implies the register-resident reduction: n <= 128)
         // (with the D&C stage the reflectors stay stashed in A: eig_dc_phase applies them to the
         // tridiagonal eigenvectors in blocked form on the matrix cores)
@@ -1145,7 +1165,17 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         if (tid < n) ev[tid] = t;
     }
     __syncthreads();
+    }   // STAGE != 2
     EIG_STAMP(3);
+    if (STAGE == 1) {
+        for (int i = tid; i < n; i += T) {
+            tri[i] = dv[i];
+            tri[n + i] = ev[i];
+            tri[2 * n + i] = hvec[i];
+        }
+        if (tid == 0) sc->eig_stage = 1;
+        return;
+    }
 
     const bool use_dc = pl.dc && !(d.dbg & 2);
     if (use_dc) {
@@ -1159,7 +1189,8 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         if (LDSM || HYB || TT != EIG_THREADS) {
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
             eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
-                    !LDSM && !(d.dbg & 2) && !(d.dbg & 1024));   // (hybrid: V already in its place)
+                    !LDSM && !(d.dbg & 2) && !(d.dbg & 1024),   // (hybrid: V already in its place)
+                    nullptr, STAGE == 2 ? 2 : 0);
         } else if (TT == EIG_THREADS && !LDSM) {
             // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
             // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
@@ -1253,6 +1284,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     if (tid == 0) {
         sc->eigenlastev = sc->fev;
         sc->eigen_done = 1;
+        sc->eig_stage = 0;
     }
     if (use_dc && LDSM && c.lazy_isc) {
         // the sampler's packed operand B D straight from the LDS copy of B (what cma_post would
@@ -1291,6 +1323,74 @@ __global__ __launch_bounds__(512) void cma_eigen_b(CmaDev d, CmaConst c, EigPlan
 {
     cma_eigen_impl<512, false, 0>(d, c, pl, force);
 }
+// 128 < n <= 256 split over workgroups (round 4): the reduction (one workgroup, as before), then the
+// two HALVES of the torn tridiagonal matrix as problems of their own, each by a workgroup with its
+// eigenvector block in LDS (the n <= 128 divide and conquer: 8-row leaves two to a wavefront, four
+// merge levels in LDS -- ~0.2 ms side by side, where the single workgroup spent ~0.55 ms on 16-row
+// leaves in two rounds and three merge levels with the blocks in L2), then the top merge.
+__global__ __launch_bounds__(512) void cma_eigen_g1(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, false, 1, 1>(d, c, pl, force);
+}
+__global__ __launch_bounds__(512) void cma_eigen_g2(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, false, 1, 2>(d, c, pl, force);
+}
+
+// grid (2, P), 512 threads, dynamic LDS of the n = 128 plan (plh); lda_work: row stride of the
+// global work matrix the blocks go to
+__global__ __launch_bounds__(512) void cma_eig_halves(CmaDev d, CmaConst c, EigPlan plh, int lda_work)
+{
+    const int p = blockIdx.y, h = blockIdx.x;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (sc->eig_stage != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, T = 512;
+    const int n = c.n, ld = c.ld;
+    constexpr int nv = 130;
+    double *dv = lds + 2, *ev = dv + nv, *uv = ev + nv;
+    double *uh1 = uv + 6 * nv;                    // (the layout of cma_eigen_impl<512, true>)
+    double *part = uh1 + nv - 2;
+    double2 *rot = reinterpret_cast<double2*>(part);
+    int *ibuf = reinterpret_cast<int*>(rot + 2 * plh.rc);
+    double *Am = reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8);
+    const int mid = n / 2;                        // (= eig_dc_phase's edge of two blocks, mode 2)
+    const int off = h ? mid : 0, m = h ? n - mid : mid;
+    const size_t slab = eig_slab(ld);
+    double *base = d.eig_work + (size_t) 4 * p * slab;
+    double *tri = base + 3 * slab;
+    if (tid < 2) {
+        dv[-1 - tid] = 0.;
+        ev[-1 - tid] = 0.;
+    }
+    // the half as a tridiagonal problem of its own: the rank-one tear at `mid` comes off its end
+    const double tear = fabs(tri[n + mid - 1]);
+    for (int i = tid; i < m; i += T) {
+        double di = tri[off + i];
+        if ((h == 0 && i == m - 1) || (h == 1 && i == 0)) di -= tear;
+        dv[i] = di;
+        ev[i] = i + 1 < m ? tri[n + off + i] : 0.;
+    }
+    __syncthreads();
+    DcMat Qm { Am, m | 1 };
+    // 2 m^2 doubles of merge scratch per half, in the room the top merge's factor F takes later
+    // (behind Q_house = V: [n^2, 2 n^2) from eig_work[1]; 4 (n - mid)^2 <= n^2 + 2 n + 1 fits with
+    // the slab's padding -- a fixed stride sized for n = 256 ran into eig_work[3] at n = 141..144)
+    const size_t mm = (size_t) (n - mid) * (n - mid);
+    double *G = base + slab + (size_t) n * n + (size_t) h * 2 * mm;
+    double *Bout = base + (size_t) off * lda_work + off;
+    eig_dc_phase<512, false, false>(Qm, m, dv, ev, G, Bout, lda_work, uv, nullptr, d.dbg, 0, nullptr,
+            true, nullptr, 1);
+    // the rest of this half's rows of the work matrix: the other half's columns are zero
+    const int c0 = h ? 0 : mid, cw = h ? mid : n - mid;
+    for (int q = tid; q < m * cw; q += T) {
+        const int r = q / cw, cc = q - r * cw;
+        base[(size_t) (off + r) * lda_work + c0 + cc] = 0.;
+    }
+    for (int i = tid; i < m; i += T) tri[3 * n + off + i] = dv[i];
+}
+
 __global__ __launch_bounds__(256, 2) void cma_eigen_256(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
     cma_eigen_impl<256, true>(d, c, pl, force);       // n <= 64: the matrix always fits LDS

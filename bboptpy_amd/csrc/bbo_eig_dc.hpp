@@ -1239,8 +1239,13 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 template<int TT = 512, bool BIG = false, bool WIDE = true>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
-        const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr)
+        const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr, int mode = 0)
 {
+    // mode (round 4, 128 < n <= 256 split over workgroups): 0 = the whole decomposition;
+    // 1 = a HALF of a torn matrix as a problem of its own (Q in LDS, no reflectors): leaves and all
+    //     merges, then the eigenvectors of the tridiagonal block go to Bout as they are;
+    // 2 = the TOP merge only: the two halves [0, n / 2) and [n / 2, n) arrive solved (dv = their
+    //     eigenvalues in ascending order each, Q = their eigenvector blocks, global memory)
 #define DC_STAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
     DC_STAMP(16);
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -1312,7 +1317,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         // at a time through a per-thread array -- scratch memory: most of the 15 us this set-up took)
         int nb = 1;
         while ((n + nb - 1) / nb > leaf_rows && nb < MAXB) nb <<= 1;
-        nblk_s = nb;
+        nblk_s = mode == 2 ? 2 : nb;
     }
     __syncthreads();
     if (tid <= nblk_s) bounds[tid] = (int) (((long long) tid * n) / nblk_s);
@@ -1325,15 +1330,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     }
     // Q becomes the eigenvector matrix of T: clear it (16-byte stores where the rows allow: the
     // global work matrix of n > 128 is 512 KB for this one workgroup)
-    if ((Q.ld & 1) == 0 && (reinterpret_cast<size_t>(Q.a) & 15) == 0) {
+    if (mode == 2) {
+        // (the halves' blocks are in place)
+    } else if ((Q.ld & 1) == 0 && (reinterpret_cast<size_t>(Q.a) & 15) == 0) {
         double2 *q2 = reinterpret_cast<double2*>(Q.a);
         for (int q = tid; q < (n * Q.ld) >> 1; q += T) q2[q] = make_double2(0., 0.);
     } else {
         for (int q = tid; q < n * Q.ld; q += T) Q.a[q] = 0.;
     }
     __syncthreads();
-    // rank-one tears at the block boundaries
-    if (tid >= 1 && tid < nblk) {
+    // rank-one tears at the block boundaries (mode 2: the halves were torn before they were solved)
+    if (tid >= 1 && tid < nblk && mode != 2) {
         const int bd = bounds[tid];
         const double r = fabs(ev[bd - 1]);
         dv[bd - 1] -= r;
@@ -1345,7 +1352,9 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     // ---- leaves: one wavefront each; the merge work area is not in use yet ------------------
     // (two per wavefront, one in each 32-lane half: dc_leaf_ql_pair; diagnostic bit 524288 keeps
     // the one-leaf-at-a-time form)
-    if (!(dbg & 8) && !(dbg & 524288)) {
+    if (mode == 2) {
+        // (no leaves)
+    } else if (!(dbg & 8) && !(dbg & 524288)) {
         for (int pr = wave; 2 * pr < nblk; pr += NW) {
             const int b0 = 2 * pr, b1 = 2 * pr + 1;
             const int a0 = bounds[b0], s0 = bounds[b0 + 1] - a0;
@@ -1399,7 +1408,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         __syncthreads();
         const int q = tm.active ? q0 : 0;
         // (a block that came out of a merge -- two leaves or more -- has its eigenvalues in order)
-        tm.sorted_in = L >= 1 && min((2 * q + 2) << L, nblk) - ((2 * q + 1) << L) >= 2;
+        tm.sorted_in = mode == 2 || (L >= 1 && min((2 * q + 2) << L, nblk) - ((2 * q + 1) << L) >= 2);
         const int a = edge(2 * q, L), mid = edge(2 * q + 1, L), b = edge(2 * q + 2, L);
         double *Fg = F + (size_t) a * n;
         double *Tbuf = Tscratch ? Tscratch + (size_t) a * n : nullptr;
@@ -1444,6 +1453,14 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     __syncthreads();
 
     DC_STAMP(22);
+    if (mode == 1) {
+        for (int q = tid; q < n * n; q += T) {
+            const int r = q / n, cc = q - r * n;
+            Bout[(size_t) r * ldb + (single ? W.outpos[cc] : cc)] = Q(r, cc);
+        }
+        __syncthreads();
+        return;
+    }
     if (ext_top) {
         // (the products run as separate kernels; with stashed reflectors the second one is
         // cma_eig_wy and needs the panels' T factors: G + 2 n^2 = [tau (n) | T (npanel x 256)])
