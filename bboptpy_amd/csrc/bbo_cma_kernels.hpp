@@ -1058,17 +1058,22 @@ __device__ inline void gram128_chunk(const double *Yb, const double *Vb, const d
     }
 }
 
+// The sums are formed on x - m (not on y = (x - m) / sigma): the division by sigma is applied ONCE,
+// to the finished sums (isig^2 for the products, isig for the mean) -- a multiplication per fragment
+// and k-step less on the pipe the matrix instruction needs (round 4: 6 of the ~25 vector
+// instructions a wavefront issues next to the 9 MFMAs of a k-step).
 template<int WV>
 __device__ inline void gram128_store(double *G, double *mp, const d4_t (&acc)[9],
-        double (&macc)[8], int lane)
+        double (&macc)[8], int lane, double isig)
 {
+    const double isig2 = isig * isig;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = G128_TI[WV][t] * 16 + (lane >> 4) + 4 * r;
             const int j = G128_TJ[WV][t] * 16 + (lane & 15);
-            G[(size_t) i * 128 + j] = acc[t][r];
+            G[(size_t) i * 128 + j] = acc[t][r] * isig2;
         }
     }
 #pragma unroll
@@ -1077,7 +1082,7 @@ __device__ inline void gram128_store(double *G, double *mp, const d4_t (&acc)[9]
             double m = macc[i];
             m += __shfl_xor(m, 16, 64);
             m += __shfl_xor(m, 32, 64);
-            if (lane < 16) mp[i * 16 + lane] = m;
+            if (lane < 16) mp[i * 16 + lane] = m * isig;
         }
     }
 }
@@ -1131,10 +1136,10 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
             const int r = r0 + 8 * i;
             const bool in = base + r < c.lambda;
             double2 y01, y23;
-            y01.x = (in && in0) ? (pf[i][0].x - xo01.x) * isig : 0.;
-            y01.y = (in && in1) ? (pf[i][0].y - xo01.y) * isig : 0.;
-            y23.x = (in && in2) ? (pf[i][1].x - xo23.x) * isig : 0.;
-            y23.y = (in && in3) ? (pf[i][1].y - xo23.y) * isig : 0.;
+            y01.x = (in && in0) ? pf[i][0].x - xo01.x : 0.;
+            y01.y = (in && in1) ? pf[i][0].y - xo01.y : 0.;
+            y23.x = (in && in2) ? pf[i][1].x - xo23.x : 0.;
+            y23.y = (in && in3) ? pf[i][1].y - xo23.y : 0.;
             *reinterpret_cast<double2*>(&Y[buf][r * G128_LDY + c4]) = y01;
             *reinterpret_cast<double2*>(&Y[buf][r * G128_LDY + c4 + 2]) = y23;
         }
@@ -1171,10 +1176,10 @@ __global__ __launch_bounds__(256, 2) void cma_gram128(CmaDev d, CmaConst c)
     double *G = d.gram_part + ((size_t) p * c.splits + s) * 128 * 128;
     double *mp = d.mean_part + ((size_t) p * c.splits + s) * 128;
     switch (wave) {
-    case 0: gram128_store<0>(G, mp, acc, macc, lane); break;
-    case 1: gram128_store<1>(G, mp, acc, macc, lane); break;
-    case 2: gram128_store<2>(G, mp, acc, macc, lane); break;
-    default: gram128_store<3>(G, mp, acc, macc, lane); break;
+    case 0: gram128_store<0>(G, mp, acc, macc, lane, isig); break;
+    case 1: gram128_store<1>(G, mp, acc, macc, lane, isig); break;
+    case 2: gram128_store<2>(G, mp, acc, macc, lane, isig); break;
+    default: gram128_store<3>(G, mp, acc, macc, lane, isig); break;
     }
 }
 
@@ -1275,7 +1280,7 @@ __device__ __forceinline__ void gram128_stream(const CmaDev &d, const CmaConst &
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             y[i] = a[i] = 0.;
-            if (g128_needs_y(WV, i)) y[i] = (ring[slot][i] - xo[i]) * isig;
+            if (g128_needs_y(WV, i)) y[i] = ring[slot][i] - xo[i];
             if (g128_needs_a(WV, i)) a[i] = vk * y[i];
         }
         if (WV == 1 || WV == 2) {
@@ -1332,7 +1337,7 @@ __device__ __forceinline__ void gram128_stream(const CmaDev &d, const CmaConst &
     }
     double *G = d.gram_part + ((size_t) p * c.splits + s) * 128 * 128;
     double *mp = d.mean_part + ((size_t) p * c.splits + s) * 128;
-    gram128_store<WV>(G, mp, acc, macc, lane);
+    gram128_store<WV>(G, mp, acc, macc, lane, isig);
 }
 
 __global__ __launch_bounds__(256, 2) void cma_gram128s(CmaDev d, CmaConst c)

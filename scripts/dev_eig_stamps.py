@@ -8,8 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bboptpy_amd as bb   # noqa: E402
 from bboptpy_amd import _ffi   # noqa: E402
+if os.environ.get("BBO_LIB"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["BBO_LIB"])
+import bboptpy_amd as bb   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
