@@ -270,6 +270,7 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         s.basis_ok = same_shape ? 0 : 1;
     }
     scal_.upload(sc.data(), P);
+    basis_maybe_stale_ = same_shape;
 
     // the eigensolver keeps its matrix in LDS when it fits
     // global scratch of the eigensolver: the work matrix when it does not fit LDS, or
@@ -432,6 +433,7 @@ void CmaEngine::launch_sample_eval()
 void CmaEngine::launch_rank()
 {
     const CmaConst &c = c_;
+    rank_wrote_norms_ = false;
     timer_.begin(stream_, K_RANK);
     // few populations: the counting kernel spreads one ranking over many CUs; many
     // populations: one in-LDS sort per population is far less work in total
@@ -444,6 +446,10 @@ void CmaEngine::launch_rank()
         const size_t lds = rank_sort_merges(m, d_.dbg) ? (size_t) m * 24 : (size_t) std::max(m, 1024) * 12;
         hipLaunchKernelGGL(cma_rank_sort, dim3(c.npop), dim3(sort_threads(m)), lds, stream_, d_,
                 c_, m);
+        // the whitened norms of the worst mu, where they are the sampler's sigma^2 ||z||^2 handed
+        // round through the ranking (cma_whiten128's shortcut): written by the sort itself, which
+        // has the ranking in LDS -- a launch less per generation (10 us of the M step)
+        rank_wrote_norms_ = c.variant == 1 && c.use_zn && !basis_maybe_stale_;
     } else {
         dim3 grid((c.lambda + 31) / 32, c.npop);
         hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
@@ -466,7 +472,9 @@ void CmaEngine::launch_update()
         BBO_HIP(hipGetLastError());
         return;
     }
-    if (c.variant == 1) {
+    const bool norms_done = rank_wrote_norms_;
+    rank_wrote_norms_ = false;             // (one ranking serves one update)
+    if (c.variant == 1 && !norms_done) {
         timer_.begin(stream_, K_WHITEN);
         if (c.ld == 128 && (long) c.npop * c.mu_pad >= 256 * 128) {
             int rw = (int) (((long) c.npop * c.mu_pad / 256 + 127) / 128) * 128;
@@ -724,6 +732,10 @@ bool CmaEngine::all_stopped()
 {
     std::vector<CmaScal> sc;
     fetch_scal(sc);
+    // (the one host-side copy of "every population's C^-1/2 matches its (B, D)": see launch_rank)
+    bool stale = false;
+    for (const auto &s : sc) stale = stale || !s.basis_ok;
+    basis_maybe_stale_ = stale;
     for (const auto &s : sc)
         if (!s.stop) return false;
     return true;

@@ -133,6 +133,8 @@ private:
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
     bool keep_bc_ = false;    // B and C survive a re-init of the same object (cmaes.cpp:53-54)
+    bool basis_maybe_stale_ = false;   // some population's basis_ok may be 0 (refreshed at every poll)
+    bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;
 

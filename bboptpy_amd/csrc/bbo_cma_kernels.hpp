@@ -627,6 +627,14 @@ __global__ __launch_bounds__(1024) void cma_rank_sort(CmaDev d, CmaConst c, int 
         else merge_sort_lds<4>(f, c.lambda, sortbuf, ibuf, order, rank, &keys, &idx);
     } else
     bitonic_sort_lds(f, c.lambda, m, keys, idx, order, rank);
+    if (c.variant == 1 && c.use_zn && sc->basis_ok) {
+        // active CMA-ES, unclamped samples, consistent basis: || C^-1/2 (x - m) ||^2 of the worst
+        // mu is sigma^2 ||z||^2 (cma_whiten128), gathered through the ranking that sits in LDS here
+        const double s2 = sc->sigma * sc->sigma;
+        for (int wr = threadIdx.x; wr < c.mu_pad; wr += blockDim.x)
+            d.S[(size_t) p * c.mu_pad + wr] = wr < c.mu
+                    ? s2 * d.zn2[(size_t) p * c.lambda_pad + idx[c.lambda - c.mu + wr]] : 0.;
+    }
     if (threadIdx.x == 0) {
         const int L = c.lambda;
         sc->ibw[0] = idx[0]; sc->ybw[0] = keys[0];
