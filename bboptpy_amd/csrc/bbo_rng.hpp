@@ -297,8 +297,16 @@ __device__ __forceinline__ uint32_t normal_quads_fast(uint64_t seed, uint32_t c0
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const u32x4 w = wn;
+#ifdef BBO_DIAG_STRIP_NOCONFLICT
+        // timing / counter diagnostic only (wrong normals): the 16 lanes of a b128 read group take
+        // 16 consecutive records, so the strip reads cannot conflict
+        const uint32_t dl = threadIdx.x & 15u;
+        const double2 e0 = tab[((w.x & 1023u) & ~15u) | dl], e1 = tab[((w.y & 1023u) & ~15u) | dl],
+                e2 = tab[((w.z & 1023u) & ~15u) | dl], e3 = tab[((w.w & 1023u) & ~15u) | dl];
+#else
         const double2 e0 = tab[w.x & 1023u], e1 = tab[w.y & 1023u], e2 = tab[w.z & 1023u],
                 e3 = tab[w.w & 1023u];
+#endif
         __builtin_amdgcn_sched_barrier(0);       // the reads go out before the next call's rounds
         if (q + 1 < NQ) wn = philox4x32_10(seed, c0, c1_0 + (uint32_t) (q + 1) * c1_step, c2, c3);
         __builtin_amdgcn_sched_barrier(0);

@@ -155,7 +155,7 @@ def measured_traffic(workload, P, kernel):
         return None
     # the timer slot is named after the phase; the launched kernel may be a shape-specific
     # variant of it (cma_sample_eval -> cma_sample_eval128, pso_ese -> pso_ese_sym + _finish)
-    alias = {"SEP": {"cma_sample_eval": "sep_sample_eval", "cma_gram": "sep_moments",
+    alias = {"SEP": {"cma_sample_eval": "sep_sample", "cma_gram": "sep_moments",
                      "cma_paths": "sep_paths"},
              "SANSDE": {"de_generation": "sansde_generation", "de_bookkeep": "sansde_bookkeep"},
              "CSO": {"cso_mean": "cso_colsum"}}.get(workload, {})
