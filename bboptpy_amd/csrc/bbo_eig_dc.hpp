@@ -48,6 +48,17 @@ __device__ inline void dc_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// the synchronisation of a team inside a merge: a team of ONE wavefront (the lowest merge level:
+// 16-pole merges of 8 x 8 leaves, a wavefront each) only has to order its own LDS traffic -- its
+// ~25 phase boundaries cost a wavefront fence each instead of a workgroup barrier that waits for
+// the slowest of eight unrelated merges (round 4).  `wv` is the same for every thread of the
+// workgroup (all teams of a level have the same number of wavefronts).
+__device__ inline void dc_sync(bool wv)
+{
+    if (wv) dc_wave_sync();
+    else __syncthreads();
+}
+
 // 1/x to (nearly) full precision: hardware estimate + two Newton steps
 __device__ inline double dc_rcp(double x)
 {
@@ -145,6 +156,7 @@ struct DcTeam {
     int wave0, nwaves, twave;
     int id;
     int sorted_in;    // both blocks come out of merges: their eigenvalues are in ascending order
+    int wave_scope;   // the team is one wavefront and synchronises as one (dc_sync)
 };
 
 // LDS work area shared by all merges of a level: every array is indexed by the block's
@@ -184,6 +196,7 @@ __device__ inline double dc_wave_max(double v)
 __device__ inline double dc_team_sum(double v, double *red, const DcTeam &tm)
 {
     v = eig_wave_sum(v);
+    if (tm.wave_scope) return 0. + v;        // (what the loop below adds up for one wavefront)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -198,6 +211,10 @@ __device__ inline double dc_team_sum_flag(double v, bool flag, bool &any, double
 {
     v = eig_wave_sum(v);
     const bool wf = __ballot(flag) != 0ull;
+    if (tm.wave_scope) {
+        any = wf;
+        return 0. + v;
+    }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
         red[threadIdx.x >> 6] = v;
@@ -216,6 +233,7 @@ __device__ inline double dc_team_sum_flag(double v, bool flag, bool &any, double
 __device__ inline double dc_team_max(double v, double *red, const DcTeam &tm)
 {
     v = dc_wave_max(v);
+    if (tm.wave_scope) return v;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -248,6 +266,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const int lane = threadIdx.x & 63;
     const int ttid = tm.ttid, TT = tm.tthreads;
     const bool on = tm.active != 0;
+    const bool wv = tm.wave_scope != 0;
     const int m = on ? b - a : 0;
     // trips of the binary-search rankings: log2(longest list) + 1, the same for every team
     const int search_trips = 32 - __builtin_clz(max(mlevel > 0 ? mlevel : (BIG ? 512 : 256), 1));
@@ -285,7 +304,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.lam[ttid] = di;          // unsorted copies for the ranking below
         W.what[ttid] = zi;
     }
-    __syncthreads();
+    dc_sync(wv);
     if (ttid < m) {
         const int m1 = mid - a;
         const bool by_search = tm.sorted_in && !any_unsorted;
@@ -298,7 +317,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     const double dmax = dc_team_max(ttid < m ? fabs(di) : 0., W.red, tm);
     const double zmax = dc_team_max(ttid < m ? fabs(zi) : 0., W.red, tm);
     const double tol = 8. * DC_EPS * fmax(dmax, zmax);
-    __syncthreads();
+    dc_sync(wv);
 
     MG_STAMP(25);
     // ---- deflation (LAPACK dlaed2's rules).  Fast path, all lanes: drop the poles with a
@@ -315,7 +334,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             W.bald[tm.wave0 + tm.twave] = bd;
         }
         if (ttid == 0) W.cnt[3] = 0;
-        __syncthreads();
+        dc_sync(wv);
         int pk = 0, pd = 0, tk = 0, td = 0;
         for (int w = 0; w < tm.nwaves; w++) {
             const int ck = __popcll(W.balk[tm.wave0 + w]), cd = __popcll(W.bald[tm.wave0 + w]);
@@ -336,14 +355,14 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             W.cnt[1] = td;
             W.cnt[2] = 0;
         }
-        __syncthreads();
+        dc_sync(wv);
         if (on && ttid >= 1 && ttid < tk) {
             const int pj = W.kp[ttid - 1], j = W.kp[ttid];
             const double zj = W.zS[j], zp = W.zS[pj];
             const double t = W.dS[j] - W.dS[pj];
             if (fabs(t * zj * zp) <= tol * (zj * zj + zp * zp)) W.cnt[3] = 1;
         }
-        __syncthreads();
+        dc_sync(wv);
     }
     if (on && ttid == 0 && W.cnt[3]) {
         int k = 0, nd = 0, nr = 0;
@@ -390,9 +409,11 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.cnt[2] = nr;
         atomicMax(W.maxnr, nr);
     }
-    __syncthreads();
+    dc_sync(wv);
     const int k = on ? W.cnt[0] : 0, nd = on ? W.cnt[1] : 0, nr = on ? W.cnt[2] : 0;
-    const int maxnr = *W.maxnr;
+    // (rotations anywhere on this level; a one-wavefront team shares no barrier with the others
+    // and goes by its own count)
+    const int maxnr = wv ? nr : *W.maxnr;
 
     // kept poles ascending (a rotation may perturb the order by rounding)
     if (ttid < k) {
@@ -414,9 +435,9 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.w2[r] = z * z;
         W.org[r] = pos;            // temporarily: sorted position of kept pole r
     }
-    __syncthreads();
+    dc_sync(wv);
     if (ttid < k) W.kp[ttid] = W.org[ttid];
-    __syncthreads();
+    dc_sync(wv);
 
     MG_STAMP(26);
     // ---- secular equation: LPR lanes per root -------------------------------------------
@@ -470,7 +491,6 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         const int npl = (k + LPR - 1) / LPR;
         const int npl_s = __builtin_amdgcn_readfirstlane(npl);     // (k is the team's: uniform in a wavefront)
         const bool inreg = LPR == 4 && npl_s <= NREG;
-        const int tsplit = j >= sub ? (j - sub) / LPR : -1;        // i <= j  <=>  t <= tsplit
         double dreg[NREG], wreg[NREG];
         if (inreg) {
 #pragma unroll
@@ -484,7 +504,11 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             }
         }
         for (int it = 0; it < 64; it++) {
-            double psi = 0., dpsi = 0., phi = 0., dphi = 0., fabs_ = 0.;
+            // psi / phi: the terms of the poles up to j / beyond j.  The iterate stays strictly
+            // between d_j and d_j+1, so the first are the NEGATIVE terms and the second the positive
+            // ones: the split is a v_min / v_max with zero (it was two 64-bit selects on the pole's
+            // position), and sum |term| = phi - psi needs no accumulator of its own (round 4).
+            double psi = 0., dpsi = 0., phi = 0., dphi = 0.;
             if (!done && inreg) {
                 // same terms in the same order as the LDS form below: same bits
                 // (four poles per scalar branch: four independent reciprocal chains in flight; the
@@ -498,9 +522,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const double tt = wreg[t0 + u] * r[u];
-                            const bool low = t0 + u <= tsplit;
-                            const double tp = low ? tt : 0., tq = low ? 0. : tt;
-                            fabs_ += fabs(tt);
+                            const double tp = fmin(tt, 0.), tq = fmax(tt, 0.);
                             psi += tp;
                             dpsi = __builtin_fma(tp, r[u], dpsi);
                             phi += tq;
@@ -517,7 +539,6 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 // own wait.)  Adding the zeros of the other run leaves each sum as it was.
                 for (int t0 = 0; t0 < npl; t0 += 4) {
                     double rr[4], ww[4], dd[4];
-                    bool lowr[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int ic = min(sub + (t0 + u) * LPR, k - 1);
@@ -534,13 +555,11 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                         const bool in = i < k;
                         ww[u] = in ? ww[u] : 0.;
                         rr[u] = dc_rcp(in ? (dd[u] - dorg) - mu : 1.);
-                        lowr[u] = i <= j;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const double t = ww[u] * rr[u];
-                        const double tp = lowr[u] ? t : 0., tq = lowr[u] ? 0. : t;
-                        fabs_ += fabs(t);
+                        const double tp = fmin(t, 0.), tq = fmax(t, 0.);
                         psi += tp;
                         dpsi = __builtin_fma(tp, rr[u], dpsi);
                         phi += tq;
@@ -552,8 +571,8 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             dpsi = dc_quad_sum<LPR>(dpsi);
             phi = dc_quad_sum<LPR>(phi);
             dphi = dc_quad_sum<LPR>(dphi);
-            fabs_ = dc_quad_sum<LPR>(fabs_);
             if (!done) {
+                const double fabs_ = phi - psi;
                 psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho;
                 const double f = 1. + psi + phi;
                 const double err = 8. * DC_EPS * (1. + rho * fabs_ * (1. + k));
@@ -595,8 +614,23 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
 #ifdef BBO_EIG_SECULAR_HIST
                         hist_it = it + 1 + 100;      // (ended by the bracket, not the residual)
 #endif
+                    } else {
+                        // A model step (not a bisection) shorter than 2^-22 of the distance to the
+                        // nearer pole is the last one: the iteration converges quadratically, the
+                        // step that would follow is below the rounding of mu, and the evaluation
+                        // that would only confirm it is a sixth of the solve (round 4; on the
+                        // merges of scripts/dev_secular_model.py the accepted offset is, bit for
+                        // bit, the one the confirming evaluation accepts).
+                        const double step = fabs(nmu - mu);
+                        const double dist = fmin(fabs((dj - dorg) - nmu), last ? fabs(nmu) : fabs((dn - dorg) - nmu));
+                        if (nmu != 0.5 * (lo + hi) && step <= 0x1p-22 * dist) {
+                            done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                            hist_it = it + 1;
+#endif
+                        }
+                        mu = nmu;
                     }
-                    else mu = nmu;
                 }
             }
             // every wavefront leaves when ITS roots are done (the loop reads the merge's vectors
@@ -632,7 +666,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             W.org[0] = 0;
         }
     }
-    __syncthreads();
+    dc_sync(wv);
 
     MG_STAMP(27);
     // ---- Loewner z and column norms -------------------------------------------------------
@@ -678,7 +712,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             W.what[0] = 1.;
             W.ninv[0] = 1.;
         }
-        __syncthreads();
+        dc_sync(wv);
         const int j = i;
         double ss = 0.;
         if (on && k > 1 && j < k) {
@@ -704,13 +738,13 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         ss = dc_quad_sum<LPR>(ss);
         if (on && k > 1 && j < k && sub == 0) W.ninv[j] = 1. / sqrt(ss);
     }
-    __syncthreads();
+    dc_sync(wv);
 
     MG_STAMP(28);
     // ---- all eigenvalues, their output order, the row / column maps of F ---------------------
     if (ttid < k) W.lam[ttid] = W.dl[W.org[ttid]] + W.mu[ttid];
     if (ttid < nd) W.lam[k + ttid] = W.dS[W.dp[ttid]];
-    __syncthreads();
+    dc_sync(wv);
     // (the roots come in ascending order -- each lies on its side of the pole it shares with its
     // neighbour, in floating point too -- and so do the deflated poles unless a rotation changed them)
     if (ttid < m) {
@@ -718,7 +752,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.outpos[ttid] = (nr > 0 || W.cnt[3] != 0) ? dc_rank_of(W.lam, m, key, ttid)
                 : dc_rank_sorted2(W.lam, k, nd, key, ttid, search_trips);
     }
-    __syncthreads();
+    dc_sync(wv);
     if (ttid < k) {
         W.rowmap[W.srcS[W.kp[ttid]] - a] = ttid;
         W.colroot[W.outpos[ttid]] = ttid;
@@ -727,7 +761,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         W.rowmap[W.srcS[W.dp[ttid]] - a] = -(1 + W.outpos[k + ttid]);
         W.colroot[W.outpos[k + ttid]] = -1;
     }
-    __syncthreads();
+    dc_sync(wv);
     // The in-place product below keeps F as MFMA B fragments in registers: when no deflation
     // rotation fired anywhere on this level (the common case) every lane forms ITS fragment
     // entries straight from the merge's vectors -- same expression, same bits -- and F never
@@ -776,7 +810,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
             }
         }
     }
-    __syncthreads();
+    dc_sync(wv);
     // deflation rotations, in reverse: Q G with G = [[c, -s], [s, c]] on sorted columns (p, j)
     for (int r = maxnr - 1; r >= 0; r--) {
         if (r < nr) {
@@ -788,10 +822,10 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 Fg[(size_t) rj * m + cidx] = s * x + cth * y;
             }
         }
-        __syncthreads();
+        dc_sync(wv);
     }
     __threadfence_block();
-    __syncthreads();
+    dc_sync(wv);
     }   // !direct
 
     MG_STAMP(29);
@@ -831,7 +865,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         }
     }
     __threadfence_block();
-    __syncthreads();
+    dc_sync(wv);
     for (int q = ttid; q < m * m; q += TT) {
         const int r = q / m, c = q - r * m;
         Q(a + r, a + c) = Tg[q];
@@ -940,7 +974,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
                 }
             }
         }
-        __syncthreads();
+        dc_sync(wv);
         if (rt < ntile) {
 #pragma unroll
             for (int u = 0; u < NT; u++) {
@@ -955,9 +989,9 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     }
     MG_STAMP(35);
     }   // do_gemm
-    __syncthreads();
+    dc_sync(wv);
     if (ttid < m) dv[a + W.outpos[ttid]] = W.lam[ttid];
-    __syncthreads();
+    dc_sync(wv);
     MG_STAMP(30);
 #undef MG_STAMP
 }
@@ -1404,6 +1438,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         tm.twave = wave - tm.wave0;
         tm.ttid = tid - 64 * tm.wave0;
         tm.tthreads = 64 * wpt;
+        tm.wave_scope = wpt == 1 && !(dbg & 8388608);      // (diagnostic bit: workgroup barriers)
         if (tid == 0) maxnr_s = 0;
         __syncthreads();
         const int q = tm.active ? q0 : 0;
