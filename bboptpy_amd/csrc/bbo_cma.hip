@@ -6,6 +6,7 @@
 // BaseCmaes::setParams (:136-148), optimize (:162-174), solution (:158-160).
 #include "bbo_cma_kernels.hpp"
 #include "bbo_sep_kernels.hpp"
+#include "bbo_eig_mw.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -570,6 +571,19 @@ void CmaEngine::launch_eigen()
         allow_lds((const void*) cma_eigen_g1, 160 * 1024 - 768);
         allow_lds((const void*) cma_eigen_g2, 160 * 1024 - 768);
         allow_lds((const void*) cma_eig_halves, 160 * 1024 - 768);
+        // the reduction: spread over MW_G workgroups per matrix where that pays -- its steps cost the
+        // same ~2.8 us (an exchange between compute units each) whatever n is, the one-workgroup
+        // steps shrink with n: 1.00 against 0.94 ms per decomposition at n = 224, 1.10 against 1.18
+        // at n = 256 -- and while all of a launch's workgroups fit the chip at once (they wait for
+        // each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one workgroup,
+        // 33554432 spreads it for every 128 < n <= 256)
+        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 128
+                && (c.n >= 248 || (d_.dbg & 33554432));
+        if (use_mw) {
+            if (mw_buf_.count != (size_t) c.npop * MW_BUF_DOUBLES) mw_buf_.alloc((size_t) c.npop * MW_BUF_DOUBLES);
+            hipLaunchKernelGGL(cma_tred_mw, dim3(8 * MW_G, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
+                    mw_buf_.p, ++mw_launch_);
+        } else
         hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
         hipLaunchKernelGGL(cma_eig_halves, dim3(2, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,
                 plh, pl.lda);
@@ -736,6 +750,8 @@ bool CmaEngine::all_stopped()
     bool stale = false;
     for (const auto &s : sc) stale = stale || !s.basis_ok;
     basis_maybe_stale_ = stale;
+    for (const auto &s : sc)
+        if (s.eig_mw_fail) mw_disabled_ = true;      // (bbo_eig_mw.hpp: back to the one-workgroup reduction)
     for (const auto &s : sc)
         if (!s.stop) return false;
     return true;
@@ -949,6 +965,8 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "fworst") return one(s.fworst);
     if (k == "eigenlastev") return one(s.eigenlastev);
     if (k == "eigen_done") return one(s.eigen_done);
+    if (k == "eig_mw_fail") return one(s.eig_mw_fail);     // (bbo_eig_mw.hpp: sticky)
+    if (k == "eig_mw_off") return one(mw_disabled_ ? 1 : 0);
     if (k == "best_len") return one(s.hist_len);
     if (k == "best_buffer") return one(s.hist_head);
     if (k == "ibest") return one(s.ibw[0]);

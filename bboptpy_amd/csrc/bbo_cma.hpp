@@ -25,7 +25,7 @@ struct CmaScal {
     int hist_head, hist_len;
     int basis_ok;             // C^-1/2 = B D^-1 B^T for the (B, D) the sampler uses (see cma_whiten128)
     int eig_stage;            // 128 < n <= 256, split decomposition: 1 = tridiagonal form handed to the next kernels
-    int pad_;
+    int eig_mw_fail;          // sticky: a wavefront of cma_tred_mw gave up waiting for its partners (bbo_eig_mw.hpp)
 };
 
 // strategy constants, passed to every kernel by value
@@ -134,6 +134,11 @@ private:
     bool inited_ = false;
     bool keep_bc_ = false;    // B and C survive a re-init of the same object (cmaes.cpp:53-54)
     bool basis_maybe_stale_ = false;   // some population's basis_ok may be 0 (refreshed at every poll)
+    // the Householder reduction spread over several workgroups (128 < n <= 256, few populations):
+    // its exchange buffers, the epoch base of its flags, and 'a wavefront once gave up: do not use it'
+    DevBuf<double> mw_buf_;
+    unsigned long long mw_launch_ = 0;
+    bool mw_disabled_ = false;
     bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;

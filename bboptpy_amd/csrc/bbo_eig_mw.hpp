@@ -1,0 +1,313 @@
+// bbo_eig_mw.hpp -- the Householder reduction of ONE matrix spread over several compute units
+// (round 4; 128 < n <= 256 with few matrices in flight: C5's BIPOP, one population per GPU).
+//
+// The single-workgroup reduction of bbo_eig.hpp is a chain of n - 1 dependent steps on one CU
+// (5.4 us per step with the whole active matrix on chip at n = 256: 0.8 ms of a 1.2 ms
+// decomposition) while 255 CUs idle.  Here MW_G workgroups hold the matrix by rows, CYCLICALLY
+// (row r lives in workgroup r mod MW_G, so the shrinking active block stays spread evenly), full
+// rows in registers: a thread owns 32 entries of one row, eight lanes share a row.  Because the
+// rows are whole, p = A u needs no transposed product and no cross-workgroup reduction: every
+// workgroup forms the entries of p for ITS rows.  What a step has to exchange:
+//   (1) the pieces of p (all-gather: every workgroup needs all of p for the scalar u^T p and w),
+//   (2) the next pivot row.
+// (2) is folded into (1): the owner of row i - 1 publishes that row AS IT STANDS together with
+// its piece of p, and every wavefront of every workgroup forms the updated row itself once it has
+// w (row' = row - u_{i-1} w - w_{i-1} u: three vector operations on four entries per lane).  ONE
+// exchange per step: every wavefront stores its piece with relaxed agent-scope atomics and waits for
+// the stores; the last one of a workgroup to do so raises the workgroup's flag (a monotone epoch:
+// launch * 512 + step; an LDS arrival count, no barrier); every wavefront polls the MW_G flags and
+// then loads the vectors -- no fence, no cache invalidate.  Measured (scripts/hiptests/
+// allgather.hip, pingpong.hip): 1.05 us per such exchange with the workgroups on ONE XCD, 1.7 us
+// on eight; a release / acquire pair costs 2.2 us one way.  All O(n) vector work (norm, root, u,
+// u^T p, w) is done redundantly by every wavefront on a 4-entries-per-lane copy, as in the
+// one-workgroup code; LDS only turns that layout into the row / column layout of the products (a
+// wavefront's own copy).  There is NO workgroup barrier in a step: wavefronts never wait for each
+// other inside a workgroup, so one that gives up (below) cannot leave the others at a barrier.
+//
+// What it buys (round 4, n = 256, one matrix): a step takes ~2.8 us -- ~1.3 us of it the
+// wavefront's own chain (two wavefront reductions, root and reciprocal, two LDS hand-overs, 96
+// FMAs), the rest the exchange -- against 5.4 us (on-chip symmetric steps) and 1.15 us (register
+// tail) of the one-workgroup reduction: 0.71 against 0.82 ms, the decomposition 1.10 against
+// 1.18 ms (+- 4 % from run to run: the exchange is at the mercy of the memory side).  The floor
+// of this design is the exchange: 255 x 1.05 us.  Tried on top and slower, each measured: the
+// flags side by side in one 256-byte line (1.59 ms: 32 pollers and 8 writers on one channel);
+// eight unconditional loads per lane instead of only the active block's (1.17); one wavefront
+// per workgroup polling and loading for all four through LDS and a barrier (1.19); every double
+// as two self-validating {half, tag} words, no flags and no wait for the stores (1.17: twice
+// the requests).  Agent-scope accesses are served on the memory side, and what decides is how
+// few of them a step makes.
+//
+// Same-XCD placement: workgroups are dealt to the 8 XCDs round-robin by their linear index; the
+// grid is (8 MW_G, P) and only the blocks with blockIdx.x % 8 == p % 8 work, the others return.
+//
+// Every spin is bounded (MW_SPIN polls, ~1 s): on a time-out the workgroup raises the sticky
+// CmaScal::eig_mw_fail, skips the hand-over (eig_stage stays 0: this generation keeps its basis,
+// like a generation the lazy schedule skips) and the host stops using this path at its next poll.
+// The host only launches it when all MW_G * P workgroups fit the chip at once.
+//
+// Output (what cma_eigen_g1 leaves): eig_work[3] = [d | e (shifted down) | h], the reflectors
+// V (row i = u_i, zero from column i on) dense n x n in eig_work[1], CmaScal::eig_stage = 1.
+// Conventions of eig_tred_accum_reg128: unscaled reflectors, H(i) = I - u_i u_i^T / h_i.
+#pragma once
+
+#include "bbo_eig.hpp"
+
+namespace bbo {
+
+constexpr int MW_G = 8;                 // workgroups per matrix
+constexpr int MW_T = 256;               // threads per workgroup: 32 rows x 8 lanes
+constexpr int MW_SPIN = 1 << 21;
+constexpr int MW_WAVES = MW_T / 64;
+#ifndef MW_POLL_SLEEP
+#define MW_POLL_SLEEP 1
+#endif
+constexpr int MW_FLAG_STRIDE = 16;      // 64-bit words between two flags (128 bytes: side by side, the polls of 32
+                                        // wavefronts and the flag stores queue up on one channel -- measured, +40 %)
+constexpr int MW_BUF_DOUBLES = MW_G * MW_FLAG_STRIDE + 2 * 256 + 2 * 256;   // per population: flags | e[2][256] | row[2][256]
+
+__device__ inline unsigned long long mw_load(const void *p)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void mw_store(void *p, unsigned long long v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double mw_load_d(const double *p) { return __longlong_as_double((long long) mw_load(p)); }
+__device__ inline void mw_store_d(double *p, double v) { mw_store(p, (unsigned long long) __double_as_longlong(v)); }
+
+// entry `idx` (wavefront-uniform) of a vector held four entries per lane (entry lane + 64 v)
+__device__ inline double mw_entry(const double (&x)[4], int idx)
+{
+    const int l = idx & 63, v = idx >> 6;
+    const double e0 = eig_readlane(x[0], l), e1 = eig_readlane(x[1], l), e2 = eig_readlane(x[2], l),
+            e3 = eig_readlane(x[3], l);
+    return v == 0 ? e0 : v == 1 ? e1 : v == 2 ? e2 : e3;
+}
+
+// sum over the 8 lanes of a row (two quads of one half of a DPP row): quad butterfly, then the
+// mirror image inside the half row brings the other quad's sum
+__device__ inline double mw_row8_sum(double v)
+{
+    v = eig_quad_sum(v);
+    v += eig_dpp<0x141>(v);      // row_half_mirror
+    return v;
+}
+
+// grid (8 * MW_G, P), MW_T threads; mwbuf: MW_BUF_DOUBLES per population, zero at allocation;
+// launch: a counter the host increments per launch (the flags are never reset)
+__global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int force, double *mwbuf,
+        unsigned long long launch)
+{
+    const int p = blockIdx.y;
+    if ((int) (blockIdx.x & 7) != (p & 7)) return;
+    const int g = blockIdx.x >> 3;
+    CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // cmaes.cpp:233: skip until enough evaluations have passed
+    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
+        if (g == 0 && tid == 0) {
+            sc->eigen_done = 0;
+            sc->eig_stage = 0;
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) double ubuf[4][256];
+    __shared__ __attribute__((aligned(16))) double wbuf[4][256];
+    __shared__ unsigned arrived;          // wavefronts that have published, over all steps so far
+    if (tid == 0) arrived = 0u;
+    __syncthreads();
+    const int n = c.n, ld = c.ld;
+    const double *C = d.C + (size_t) p * ld * ld;
+    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld);
+    double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
+    double *mb = mwbuf + (size_t) p * MW_BUF_DOUBLES;
+    unsigned long long *flags = reinterpret_cast<unsigned long long*>(mb);
+    double *ebuf = mb + MW_G * MW_FLAG_STRIDE;          // [2][256], entry of row r at (r % MW_G) * 32 + r / MW_G
+    double *rbuf = ebuf + 2 * 256;                      // [2][256]
+
+    // this thread's row and columns
+    const int q = 8 * wave + (lane >> 3), s = lane & 7;
+    const int r = MW_G * q + g;
+    double2 a2[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int col = 16 * t + 2 * s;
+        a2[t].x = (r < n && col < n) ? C[(size_t) r * ld + col] : 0.;
+        a2[t].y = (r < n && col + 1 < n) ? C[(size_t) r * ld + col + 1] : 0.;
+    }
+    // the pivot row of the first step, four entries per lane (zero from the pivot column on)
+    double av[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const int idx = lane + 64 * v;
+        av[v] = idx < n - 1 ? C[(size_t) (n - 1) * ld + idx] : 0.;
+    }
+    const bool recorder = g == 0 && wave == 0;
+    if (recorder && lane == 0) {
+        tri[n - 1] = C[(size_t) (n - 1) * ld + n - 1];
+        tri[n + n - 1] = 0.;           // (the sub-diagonal is handed over shifted down by one)
+        tri[2 * n] = 0.;
+    }
+    if (recorder)
+        for (int idx = lane; idx < n; idx += 64) Vout[idx] = 0.;      // row 0: no reflector
+    double *ub = ubuf[wave], *wb = wbuf[wave];
+    bool failed = false;
+#ifdef BBO_MW_CLOCKS
+    long long ck[6] = { 0, 0, 0, 0, 0, 0 }, ct = clock64();
+#define MW_CK(k) do { const long long t_ = clock64(); ck[k] += t_ - ct; ct = t_; } while (0)
+#else
+#define MW_CK(k) do { } while (0)
+#endif
+
+    for (int i = n - 1; i >= 1 && !failed; i--) {
+        const unsigned long long epoch = launch * 512ull + (unsigned long long) (n - i);
+        const int par = i & 1;
+        // ---- the reflector of this step, by every wavefront ------------------------------------
+        const double h0 = eig_wave_sum_bf((av[0] * av[0] + av[1] * av[1]) + (av[2] * av[2] + av[3] * av[3]));
+        const double f = mw_entry(av, i - 1);
+        const bool none = h0 == 0.;
+        double gg = 0.;
+        if (!none) {
+            double y = __builtin_amdgcn_rsq(h0);
+            const double err = fma(-h0 * y, y, 1.);
+            y = fma(y * err, fma(err, 0.375, 0.5), y);
+            gg = h0 * y;
+            gg = fma(fma(-gg, gg, h0), 0.5 * y, gg);
+            if (f > 0) gg = -gg;
+        }
+        const double h = none ? 0. : h0 - f * gg;
+        const double rh = none ? 0. : dc_rcp(h);
+        double uvv[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int idx = lane + 64 * v;
+            uvv[v] = (idx < i && !none) ? (idx == i - 1 ? f - gg : av[v]) : 0.;
+            ub[idx] = uvv[v];
+        }
+        dc_wave_sync();
+        MW_CK(0);
+        // ---- p = A u for this thread's row; its piece of e = p / h goes out ----------------------
+        double2 uc[16];
+        double acc0 = 0., acc1 = 0.;
+#pragma unroll
+        for (int t = 0; t < 16; t++) uc[t] = *reinterpret_cast<const double2*>(&ub[16 * t + 2 * s]);
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            acc0 = __builtin_fma(a2[t].x, uc[t].x, acc0);
+            acc1 = __builtin_fma(a2[t].y, uc[t].y, acc1);
+        }
+        const double pr = mw_row8_sum(acc0 + acc1);
+        // (a wavefront's eight entries lie side by side: one 64-byte piece per wavefront)
+        if (s == 0 && r < n) mw_store_d(ebuf + 256 * par + 32 * g + q, r < i ? pr * rh : 0.);
+        // the row that becomes the next pivot, as it stands (its owner: row i - 1) -- turned into
+        // the four-entries-per-lane layout through this wavefront's w buffer (free here), so that
+        // it leaves as four 512-byte stores, not 64 scattered ones
+        if ((i - 1) % MW_G == g && ((i - 1) / MW_G) >> 3 == wave) {
+            if (r == i - 1) {
+#pragma unroll
+                for (int t = 0; t < 16; t++) *reinterpret_cast<double2*>(&wb[16 * t + 2 * s]) = a2[t];
+            }
+            dc_wave_sync();
+#pragma unroll
+            for (int v = 0; v < 4; v++) mw_store_d(rbuf + 256 * par + lane + 64 * v, wb[lane + 64 * v]);
+        }
+        __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores are out (and its loads of
+                                                // the step before: the buffers alternate)
+        // the LAST wavefront of this workgroup to get here raises the workgroup's flag (an LDS
+        // count, no barrier: nobody waits inside the workgroup)
+        if (lane == 0) {
+            const unsigned before = atomicAdd(&arrived, 1u);
+            if (before + 1u == (unsigned) (MW_WAVES * (n - i))) mw_store(flags + MW_FLAG_STRIDE * g, epoch);
+        }
+        MW_CK(1);
+        // ---- every wavefront waits for all pieces ------------------------------------------------
+        {
+            int spins = 0;
+            while (true) {
+                const unsigned long long fl = lane < MW_G ? mw_load(flags + MW_FLAG_STRIDE * lane) : epoch;
+                if (__ballot(fl < epoch) == 0ull) break;
+                if (++spins >= MW_SPIN) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(MW_POLL_SLEEP);
+            }
+        }
+        if (failed) break;
+        MW_CK(2);
+        // (only the lanes inside the active block ask: measured against eight unconditional loads
+        // per lane, 1071 against 1170 us per decomposition -- the requests are served on the memory
+        // side, and fewer of them come back sooner)
+        double ev_[4], ro[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int idx = lane + 64 * v;
+            ev_[v] = idx < i ? mw_load_d(ebuf + 256 * par + 32 * (idx % MW_G) + idx / MW_G) : 0.;
+            ro[v] = idx < i ? mw_load_d(rbuf + 256 * par + idx) : 0.;
+        }
+        MW_CK(3);
+        // ---- w = e - (u^T e / 2h) u ----------------------------------------------------------------
+        const double hh = eig_wave_sum_bf((ev_[0] * uvv[0] + ev_[1] * uvv[1]) + (ev_[2] * uvv[2] + ev_[3] * uvv[3]))
+                * (0.5 * rh);
+        double wvv[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int idx = lane + 64 * v;
+            wvv[v] = idx < i ? ev_[v] - hh * uvv[v] : 0.;
+            wb[idx] = wvv[v];
+        }
+        dc_wave_sync();
+        // ---- A -= u w^T + w u^T on this thread's row (rows and columns >= i see zeros) -------------
+        {
+            const int rc = r < 256 ? r : 0;
+            const double ur = r < n ? ub[rc] : 0., wr = r < n ? wb[rc] : 0.;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const double2 wc = *reinterpret_cast<const double2*>(&wb[16 * t + 2 * s]);
+                a2[t].x -= ur * wc.x + wr * uc[t].x;
+                a2[t].y -= ur * wc.y + wr * uc[t].y;
+            }
+        }
+        MW_CK(4);
+        // ---- the next pivot row, by every wavefront: row' = row - u_{i-1} w - w_{i-1} u ------------
+        const double um = none ? 0. : f - gg, wm = mw_entry(wvv, i - 1);
+        double an[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) an[v] = ro[v] - (um * wvv[v] + wm * uvv[v]);
+        // ---- what this step leaves behind ------------------------------------------------------------
+        if (recorder) {
+            if (lane == 0) {
+                tri[n + i - 1] = none ? f : gg;      // e[i], shifted down by one
+                tri[2 * n + i] = h;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int idx = lane + 64 * v;
+                if (idx < n) Vout[(size_t) i * n + idx] = uvv[v];
+                if (idx == i - 1) tri[i - 1] = an[v];           // diagonal entry of row i - 1: final
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) av[v] = lane + 64 * v < i - 1 ? an[v] : 0.;
+        // (ub / wb are this wavefront's own: the next step's writes follow this step's reads in
+        // program order)
+        dc_wave_sync();
+        MW_CK(5);
+    }
+#ifdef BBO_MW_CLOCKS
+    if (d.stamps && recorder && lane == 0 && p == 0)
+        for (int k = 0; k < 6; k++) d.stamps[40 + k] = ck[k] / (n - 1);
+#endif
+#undef MW_CK
+    if (failed) {
+        if (lane == 0) sc->eig_mw_fail = 1;
+        return;
+    }
+    if (g == 0 && tid == 0) sc->eig_stage = 1;
+}
+
+} // namespace bbo

@@ -42,3 +42,7 @@ for i, name in enumerate(bench.CMA_KERNELS):
         tot += us
         print("   %-18s %8.1f us" % (name, us))
 print("   %-18s %8.1f us" % ("sum", tot))
+try:
+    print("   eig_mw_fail %s, eig_mw_off %s" % (alg.get_state("eig_mw_fail"), alg.get_state("eig_mw_off")))
+except Exception:
+    pass

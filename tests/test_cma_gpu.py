@@ -329,6 +329,68 @@ def test_eigendecomposition_every_dimension_to_130(hip):
     assert not bad, bad[:8]
 
 
+@pytest.mark.parametrize("n", [129, 143, 160, 200, 250, 256])
+def test_eigensolver_forms_for_128_to_256_agree(hip, n):
+    """128 < n <= 256 has three forms of the decomposition: everything in one workgroup (round 3,
+    diagnostic bit 4194304), the split one -- reduction, the two halves of the torn tridiagonal
+    matrix side by side on two workgroups, top merge (bit 16777216 keeps its reduction on one
+    workgroup) -- and the split one with the Householder reduction itself spread over eight
+    workgroups that exchange a vector per step (bbo_eig_mw.hpp; bit 33554432 uses it for every n
+    of the class, by default it starts at n = 248).  Different leaf sizes and summation orders, so
+    not the same bits: the same eigenvalues to rounding, and each form's own residual and
+    orthogonality; the spread reduction must not have given up (its bounded waits)."""
+    from bboptpy_amd import _ffi
+    rng = np.random.default_rng(n)
+    forms = {"one workgroup": 4194304, "split": 16777216, "split, spread reduction": 33554432}
+    for name, Cm in _spd_cases(n, rng):
+        Cm = 0.5 * (Cm + Cm.T)
+        lam = np.linalg.eigvalsh(Cm)
+        sc = np.abs(lam).max()
+        Ds = {}
+        for form, bit in forms.items():
+            g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
+            g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
+            g.set_state("dbg", [float(bit)])
+            g.set_state("C", Cm)
+            g.set_state("fev", [10 ** 6])
+            g.set_state("eigenlastev", [0])
+            g.phase(_ffi.PHASE_EIGEN)
+            assert int(g.get_state("eigen_done")[0]) == 1, (name, form)
+            assert int(g.get_state("eig_mw_fail")[0]) == 0, (name, form)
+            B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+            assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, form)
+            assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm), (name, form)
+            Ds[form] = D * D
+        for form in ("split", "split, spread reduction"):
+            assert np.abs(Ds[form] - Ds["one workgroup"]).max() <= 1e-12 * sc, (name, form)
+
+
+def test_spread_reduction_runs_generation_after_generation(hip):
+    """the multi-workgroup reduction inside whole generations at n = 256 (its flags are epochs that
+    grow from launch to launch, its buffers alternate between steps): 12 generations of two
+    populations against the same run with the reduction on one workgroup -- same trajectory to
+    rounding (lambda = 2 n: with fewer candidates than dimensions the first covariance matrices have
+    a repeated eigenvalue whose eigenvectors rounding decides), and no
+    wavefront ever gave up waiting"""
+    n, lam, P = 256, 512, 2
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(8).uniform(-4, 4, (P, n))
+    out = []
+    for bit in (0, 16777216):
+        g = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=21, populations=P)
+        g.initialize(hip.objectives.ellipsoid, lo, up, guess)
+        if bit:
+            g.set_state("dbg", [float(bit)])
+        g.run(12)
+        out.append([(g.get_state("xmean", p), g.get_state("sigma", p), g.get_state("D", p)) for p in range(P)])
+        assert all(int(g.get_state("eig_mw_fail", p)[0]) == 0 for p in range(P))
+        assert int(g.get_state("eig_mw_off")[0]) == 0
+    for (xa, sa, Da), (xb, sb, Db) in zip(*out):
+        np.testing.assert_allclose(sa, sb, rtol=1e-8)
+        np.testing.assert_allclose(Da, Db, rtol=1e-7)
+        np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("n", [10, 16, 40, 128, 200, 256, 300, 512])
 def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     """The QL leaves stop after 30 sweeps per eigenvalue (ql_produce_reg), so a covariance with
