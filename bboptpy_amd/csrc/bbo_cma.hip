@@ -585,7 +585,7 @@ void CmaEngine::launch_eigen()
                     mw_buf_.p, ++mw_launch_);
         } else
         hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
-        hipLaunchKernelGGL(cma_eig_halves, dim3(2, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,
+        hipLaunchKernelGGL(cma_eig_halves, dim3(3, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,
                 plh, pl.lda);
         hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
     } else if (pl.hybrid)

@@ -1173,7 +1173,10 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             tri[n + i] = ev[i];
             tri[2 * n + i] = hvec[i];
         }
-        if (tid == 0) sc->eig_stage = 1;
+        if (tid == 0) {
+            tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
+            sc->eig_stage = 1;
+        }
         return;
     }
 
@@ -1190,7 +1193,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
             eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
                     !LDSM && !(d.dbg & 2) && !(d.dbg & 1024),   // (hybrid: V already in its place)
-                    nullptr, STAGE == 2 ? 2 : 0);
+                    nullptr, STAGE == 2 ? 2 : 0, STAGE == 2 && tri[4 * n] != 0.);
         } else if (TT == EIG_THREADS && !LDSM) {
             // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
             // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
@@ -1360,6 +1363,22 @@ __global__ __launch_bounds__(512) void cma_eig_halves(CmaDev d, CmaConst c, EigP
     const size_t slab = eig_slab(ld);
     double *base = d.eig_work + (size_t) 4 * p * slab;
     double *tri = base + 3 * slab;
+    if (h == 2) {
+        // a third workgroup, beside the two halves: the T factors of the reflector panels depend on
+        // V and the reflectors' scalars only, and took 26 us of the top-merge kernel that follows.
+        // (even n: for odd n the second half's merge scratch reaches one element into tau)
+        if (n & 1) return;
+        double *taug = base + slab + (size_t) 2 * n * n;
+        for (int i = tid; i < n; i += T) {
+            const double hi = tri[2 * n + i];
+            taug[i] = hi != 0. ? 1. / hi : 0.;
+        }
+        __threadfence_block();
+        __syncthreads();
+        dc_build_T(n, base + slab, taug, taug + n, uv);
+        if (tid == 0) tri[4 * n] = 1.;         // (cma_eigen_g2: built)
+        return;
+    }
     if (tid < 2) {
         dv[-1 - tid] = 0.;
         ev[-1 - tid] = 0.;

@@ -1273,7 +1273,8 @@ __device__ inline void dc_apply_reflectors(const DcMat &Q, int n, const double *
 template<int TT = 512, bool BIG = false, bool WIDE = true>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
-        const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr, int mode = 0)
+        const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr, int mode = 0,
+        bool t_prebuilt = false)     // (mode 2: the reflector panels' T factors are in place already)
 {
     // mode (round 4, 128 < n <= 256 split over workgroups): 0 = the whole decomposition;
     // 1 = a HALF of a torn matrix as a problem of its own (Q in LDS, no reflectors): leaves and all
@@ -1499,7 +1500,7 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
     if (ext_top) {
         // (the products run as separate kernels; with stashed reflectors the second one is
         // cma_eig_wy and needs the panels' T factors: G + 2 n^2 = [tau (n) | T (npanel x 256)])
-        if (hv) {
+        if (hv && !t_prebuilt) {
             __syncthreads();
             dc_build_T(n, Qh, taug, taug + n, scratch);
         }

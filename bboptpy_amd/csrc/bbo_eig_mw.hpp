@@ -151,6 +151,7 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         tri[n - 1] = C[(size_t) (n - 1) * ld + n - 1];
         tri[n + n - 1] = 0.;           // (the sub-diagonal is handed over shifted down by one)
         tri[2 * n] = 0.;
+        tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
     }
     if (recorder)
         for (int idx = lane; idx < n; idx += 64) Vout[idx] = 0.;      // row 0: no reflector
