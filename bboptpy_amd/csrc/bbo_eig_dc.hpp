@@ -247,7 +247,246 @@ __device__ inline double dc_quad_sum(double v)
 {
     if (LPR >= 2) v += eig_quad_xor1(v);
     if (LPR >= 4) v += eig_quad_xor2(v);
+    if (LPR >= 8) v += eig_dpp<0x141>(v);     // row_half_mirror: the other quad of the half row
+    if (LPR >= 16) v += eig_dpp<0x140>(v);    // row_mirror: the other half of the row
     return v;
+}
+
+// ---- the secular equation 1 + rho sum_i w_i / (d_i - lam) = 0: root j by LPR lanes (thread rt of
+// the team: j = rt / LPR), every lane the poles i = sub + LPR t.  Reads W.dl, W.w2 (k kept poles,
+// ascending); writes W.mu[j] (offset from the origin pole), W.org[j], W.lam[j] (the origin pole) and
+// raises W.cnt[3] when a root leaves its interval (non-finite input).  A function of its own since
+// round 4: the top merge of a matrix wider than 128 runs it on several workgroups
+// (cma_eig_secular), the merges inside a workgroup inline it as before.
+template<int LPR>
+__device__ __forceinline__ void dc_secular(const DcWork &W, int k, double rho, int rt, bool on,
+        long long *stamps, bool stamp_here, int width)
+{
+#define SEC_STAMP(slot) do { if (stamps && stamp_here && threadIdx.x == 0) stamps[slot] = wall_clock64(); } while (0)
+    const int j = rt / LPR, sub = rt % LPR;
+    const bool act = on && k > 1 && j < k;
+    const bool last = j == k - 1;
+    double wsum = 0.;
+    if (act && last)
+        for (int i = sub; i < k; i += LPR) wsum += W.w2[i];
+    wsum = dc_quad_sum<LPR>(wsum);
+    const double dj = act ? W.dl[j] : 0.;
+    const double dn = act ? (last ? dj + rho * wsum : W.dl[j + 1]) : 1.;
+    // origin: the sign of f at the midpoint
+    double fm = 0.;
+    {
+        const double midp = 0.5 * (dj + dn);
+        if (act)
+            for (int i = sub; i < k; i += LPR) fm += W.w2[i] * dc_rcp(W.dl[i] - midp);
+        fm = 1. + rho * dc_quad_sum<LPR>(fm);
+    }
+    const bool left = fm > 0. || last;
+    const int o = act ? min(left ? j : j + 1, k - 1) : 0;
+    const double dorg = act ? W.dl[o] : 0.;
+    const double gap = dn - dj;
+    double lo = left ? 0. : -0.5 * gap;
+    double hi = left ? (last ? gap : 0.5 * gap) : 0.;
+    double mu = 0.5 * (lo + hi);
+    if (act) {
+        // first guess: the origin pole with its TRUE weight, all other poles frozen at their
+        // midpoint value: 1 + rho (w_o / (d_o - x) + rest) = 0.  Exact in the limit of a tiny
+        // weight (root glued to its pole -- where the fitted two-pole model below starts
+        // blind and took 10-17 steps), inside the bracket by construction otherwise.
+        const double wo = W.w2[o];
+        const double rest1 = fm + (left ? 2. : -2.) * rho * wo / gap;    // 1 + rho rest
+        const double g0 = rho * wo / rest1;
+        if (g0 == g0 && g0 > lo && g0 < hi) mu = g0;
+    }
+    SEC_STAMP(32);
+    bool done = !act;
+#ifdef BBO_EIG_SECULAR_HIST
+    int hist_it = 0;
+#endif
+    // The poles of a lane, i = sub + LPR t, in REGISTERS for the whole solve when there are at
+    // most 32 of them (LPR = 4: every merge of n <= 128): delta_t = d_i - d_origin and w_t are
+    // loaded once, an evaluation is then a subtraction, a reciprocal and the sums -- no LDS
+    // read, no address, no end-of-list test per pole and iteration (the loop is bound by
+    // vector issue: 31 slots per pole from LDS, 20 from registers).  A pole beyond the list
+    // carries w = 0 and a delta no root comes near.
+    constexpr int NREG = 32;
+    const int npl = (k + LPR - 1) / LPR;
+    const int npl_s = __builtin_amdgcn_readfirstlane(npl);     // (k is the team's: uniform in a wavefront)
+    const bool inreg = LPR >= 4 && npl_s <= NREG;
+    double dreg[NREG], wreg[NREG];
+    if (inreg) {
+#pragma unroll
+        for (int t = 0; t < NREG; t++) {
+            const int i = sub + t * LPR;
+            const bool in = act && i < k;
+            const int ic = in ? i : 0;
+            const double dd = W.dl[ic], wl = W.w2[ic];
+            dreg[t] = in ? dd - dorg : 0x1p+1000;
+            wreg[t] = in ? wl : 0.;
+        }
+    }
+    for (int it = 0; it < 64; it++) {
+        // psi / phi: the terms of the poles up to j / beyond j.  The iterate stays strictly
+        // between d_j and d_j+1, so the first are the NEGATIVE terms and the second the positive
+        // ones: the split is a v_min / v_max with zero (it was two 64-bit selects on the pole's
+        // position), and sum |term| = phi - psi needs no accumulator of its own (round 4).
+        double psi = 0., dpsi = 0., phi = 0., dphi = 0.;
+        if (!done && inreg) {
+            // same terms in the same order as the LDS form below: same bits
+            // (four poles per scalar branch: four independent reciprocal chains in flight; the
+            // padding poles of the last group add exact zeros)
+#pragma unroll
+            for (int t0 = 0; t0 < NREG; t0 += 4) {
+                if (t0 < npl_s) {
+                    double r[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) r[u] = dc_rcp(dreg[t0 + u] - mu);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double tt = wreg[t0 + u] * r[u];
+                        const double tp = fmin(tt, 0.), tq = fmax(tt, 0.);
+                        psi += tp;
+                        dpsi = __builtin_fma(tp, r[u], dpsi);
+                        phi += tq;
+                        dphi = __builtin_fma(tq, r[u], dphi);
+                    }
+                }
+            }
+        } else if (!done) {
+            // the poles up to j feed psi, the rest phi.  ONE loop with a wavefront-uniform trip
+            // count (k is the team's) over this lane's poles, four at a time: unconditional
+            // loads from a clamped index, the psi / phi split and the end of the list by
+            // selects.  (Written as two runs with per-lane bounds -- up to j, beyond j -- the
+            // loop compiled to an exec-mask loop with every load under its own branch and its
+            // own wait.)  Adding the zeros of the other run leaves each sum as it was.
+            for (int t0 = 0; t0 < npl; t0 += 4) {
+                double rr[4], ww[4], dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ic = min(sub + (t0 + u) * LPR, k - 1);
+                    ww[u] = W.w2[ic];
+                    dd[u] = W.dl[ic];
+                }
+                // (all four requests are out before the first value is waited for: left to
+                // itself the scheduler, short of registers in this kernel, reuses one register
+                // quad for all four loads and waits after each)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = sub + (t0 + u) * LPR;
+                    const bool in = i < k;
+                    ww[u] = in ? ww[u] : 0.;
+                    rr[u] = dc_rcp(in ? (dd[u] - dorg) - mu : 1.);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double t = ww[u] * rr[u];
+                    const double tp = fmin(t, 0.), tq = fmax(t, 0.);
+                    psi += tp;
+                    dpsi = __builtin_fma(tp, rr[u], dpsi);
+                    phi += tq;
+                    dphi = __builtin_fma(tq, rr[u], dphi);
+                }
+            }
+        }
+        psi = dc_quad_sum<LPR>(psi);
+        dpsi = dc_quad_sum<LPR>(dpsi);
+        phi = dc_quad_sum<LPR>(phi);
+        dphi = dc_quad_sum<LPR>(dphi);
+        if (!done) {
+            const double fabs_ = phi - psi;
+            psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho;
+            const double f = 1. + psi + phi;
+            const double err = 8. * DC_EPS * (1. + rho * fabs_ * (1. + k));
+            if (fabs(f) <= err) {
+                done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                hist_it = it + 1;
+#endif
+            } else {
+                if (f < 0.) lo = mu;
+                else hi = mu;
+                // two-pole rational model around the bracketing poles (middle way)
+                const double dlp = (dj - dorg) - mu;
+                double nmu = 0.5 * (lo + hi);
+                if (last) {
+                    const double aa = dpsi * dlp * dlp, ss = psi - dpsi * dlp;
+                    const double c0 = 1. + ss + phi;
+                    const double eta = dlp + aa * dc_rcp(c0);
+                    const double cand = mu + eta;
+                    if (eta == eta && cand > lo && cand < hi) nmu = cand;
+                } else {
+                    const double drp = (dn - dorg) - mu;
+                    const double aa = dpsi * dlp * dlp, ss = psi - dpsi * dlp;
+                    const double bb = dphi * drp * drp, rr = phi - dphi * drp;
+                    const double c0 = 1. + ss + rr;
+                    const double A1 = -(c0 * (dlp + drp) + aa + bb);
+                    const double A0 = c0 * dlp * drp + aa * drp + bb * dlp;
+                    // (the model only proposes the next iterate, the bracket and the residual
+                    // test decide: hardware estimates + Newton, not the IEEE sequences)
+                    const double disc = fmax(A1 * A1 - 4. * c0 * A0, 0.);
+                    const double qq = -0.5 * (A1 + (A1 >= 0. ? 1. : -1.) * dc_sqrt(disc));
+                    const double e1 = qq * dc_rcp(c0), e2 = A0 * dc_rcp(qq);
+                    const double c1 = mu + e1, c2 = mu + e2;
+                    if (e1 == e1 && c1 > lo && c1 < hi) nmu = c1;
+                    else if (e2 == e2 && c2 > lo && c2 < hi) nmu = c2;
+                }
+                if (!(hi - lo > 4. * DC_EPS * fmax(fabs(lo), fabs(hi)))) {
+                    done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                    hist_it = it + 1 + 100;      // (ended by the bracket, not the residual)
+#endif
+                } else {
+                    // A model step (not a bisection) shorter than 2^-22 of the distance to the
+                    // nearer pole is the last one: the iteration converges quadratically, the
+                    // step that would follow is below the rounding of mu, and the evaluation
+                    // that would only confirm it is a sixth of the solve (round 4; on the
+                    // merges of scripts/dev_secular_model.py the accepted offset is, bit for
+                    // bit, the one the confirming evaluation accepts).
+                    const double step = fabs(nmu - mu);
+                    const double dist = fmin(fabs((dj - dorg) - nmu), last ? fabs(nmu) : fabs((dn - dorg) - nmu));
+                    if (nmu != 0.5 * (lo + hi) && step <= 0x1p-22 * dist) {
+                        done = true;
+#ifdef BBO_EIG_SECULAR_HIST
+                        hist_it = it + 1;
+#endif
+                    }
+                    mu = nmu;
+                }
+            }
+        }
+        // every wavefront leaves when ITS roots are done (the loop reads the merge's vectors
+        // and writes nothing shared): no workgroup barrier per iteration, and a finished
+        // wavefront leaves its SIMD's issue slots to the one still iterating
+        if (__ballot(!done) == 0ull) {
+            if (stamps && stamp_here && threadIdx.x == 0) stamps[31] = it + 1;
+            break;
+        }
+    }
+    SEC_STAMP(33);
+#ifdef BBO_EIG_SECULAR_HIST
+    // (diagnostic build: histogram of the iterations per root of the widest merge in slots
+    // 34..46, the root with the most in 47 as j * 1000 + iterations)
+    if (stamps && act && sub == 0 && width > 64) {
+        atomicAdd((unsigned long long*) &stamps[34 + min(hist_it, 12)], 1ull);
+        atomicMax((unsigned long long*) &stamps[47], (unsigned long long) hist_it * 1000000ull + j * 1000ull + k);
+    }
+#endif
+    if (act && sub == 0) {
+        W.mu[j] = mu;
+        W.org[j] = o;
+        W.lam[j] = dorg;       // (the origin pole itself, for the Loewner products below)
+        // root j lies in [d_j, d_j+1] -- in floating point too, for finite input -- which is what
+        // puts the roots in ascending order for the output ranking below.  Where it does not
+        // hold (NaN / Inf in the merge) the flag of the sequential deflation scan, consumed
+        // by now, sends that ranking to the form that is a permutation whatever the data.
+        const double lj = dorg + mu;
+        if (!(lj >= dj && lj <= dn)) W.cnt[3] = 1;
+    }
+    if (on && k == 1 && rt == 0) {
+        W.mu[0] = rho * W.w2[0];
+        W.org[0] = 0;
+    }
+#undef SEC_STAMP
 }
 
 // One level of merges: the team `tm` merges the blocks [a, mid) and [mid, b) (inactive teams
@@ -440,232 +679,8 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     dc_sync(wv);
 
     MG_STAMP(26);
-    // ---- secular equation: LPR lanes per root -------------------------------------------
-    {
-        const int j = ttid / LPR, sub = ttid % LPR;
-        const bool act = on && k > 1 && j < k;
-        const bool last = j == k - 1;
-        double wsum = 0.;
-        if (act && last)
-            for (int i = sub; i < k; i += LPR) wsum += W.w2[i];
-        wsum = dc_quad_sum<LPR>(wsum);
-        const double dj = act ? W.dl[j] : 0.;
-        const double dn = act ? (last ? dj + rho * wsum : W.dl[j + 1]) : 1.;
-        // origin: the sign of f at the midpoint
-        double fm = 0.;
-        {
-            const double midp = 0.5 * (dj + dn);
-            if (act)
-                for (int i = sub; i < k; i += LPR) fm += W.w2[i] * dc_rcp(W.dl[i] - midp);
-            fm = 1. + rho * dc_quad_sum<LPR>(fm);
-        }
-        const bool left = fm > 0. || last;
-        const int o = act ? min(left ? j : j + 1, k - 1) : 0;
-        const double dorg = act ? W.dl[o] : 0.;
-        const double gap = dn - dj;
-        double lo = left ? 0. : -0.5 * gap;
-        double hi = left ? (last ? gap : 0.5 * gap) : 0.;
-        double mu = 0.5 * (lo + hi);
-        if (act) {
-            // first guess: the origin pole with its TRUE weight, all other poles frozen at their
-            // midpoint value: 1 + rho (w_o / (d_o - x) + rest) = 0.  Exact in the limit of a tiny
-            // weight (root glued to its pole -- where the fitted two-pole model below starts
-            // blind and took 10-17 steps), inside the bracket by construction otherwise.
-            const double wo = W.w2[o];
-            const double rest1 = fm + (left ? 2. : -2.) * rho * wo / gap;    // 1 + rho rest
-            const double g0 = rho * wo / rest1;
-            if (g0 == g0 && g0 > lo && g0 < hi) mu = g0;
-        }
-        MG_STAMP(32);
-        bool done = !act;
-#ifdef BBO_EIG_SECULAR_HIST
-        int hist_it = 0;
-#endif
-        // The poles of a lane, i = sub + LPR t, in REGISTERS for the whole solve when there are at
-        // most 32 of them (LPR = 4: every merge of n <= 128): delta_t = d_i - d_origin and w_t are
-        // loaded once, an evaluation is then a subtraction, a reciprocal and the sums -- no LDS
-        // read, no address, no end-of-list test per pole and iteration (the loop is bound by
-        // vector issue: 31 slots per pole from LDS, 20 from registers).  A pole beyond the list
-        // carries w = 0 and a delta no root comes near.
-        constexpr int NREG = 32;
-        const int npl = (k + LPR - 1) / LPR;
-        const int npl_s = __builtin_amdgcn_readfirstlane(npl);     // (k is the team's: uniform in a wavefront)
-        const bool inreg = LPR == 4 && npl_s <= NREG;
-        double dreg[NREG], wreg[NREG];
-        if (inreg) {
-#pragma unroll
-            for (int t = 0; t < NREG; t++) {
-                const int i = sub + t * LPR;
-                const bool in = act && i < k;
-                const int ic = in ? i : 0;
-                const double dd = W.dl[ic], wl = W.w2[ic];
-                dreg[t] = in ? dd - dorg : 0x1p+1000;
-                wreg[t] = in ? wl : 0.;
-            }
-        }
-        for (int it = 0; it < 64; it++) {
-            // psi / phi: the terms of the poles up to j / beyond j.  The iterate stays strictly
-            // between d_j and d_j+1, so the first are the NEGATIVE terms and the second the positive
-            // ones: the split is a v_min / v_max with zero (it was two 64-bit selects on the pole's
-            // position), and sum |term| = phi - psi needs no accumulator of its own (round 4).
-            double psi = 0., dpsi = 0., phi = 0., dphi = 0.;
-            if (!done && inreg) {
-                // same terms in the same order as the LDS form below: same bits
-                // (four poles per scalar branch: four independent reciprocal chains in flight; the
-                // padding poles of the last group add exact zeros)
-#pragma unroll
-                for (int t0 = 0; t0 < NREG; t0 += 4) {
-                    if (t0 < npl_s) {
-                        double r[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) r[u] = dc_rcp(dreg[t0 + u] - mu);
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const double tt = wreg[t0 + u] * r[u];
-                            const double tp = fmin(tt, 0.), tq = fmax(tt, 0.);
-                            psi += tp;
-                            dpsi = __builtin_fma(tp, r[u], dpsi);
-                            phi += tq;
-                            dphi = __builtin_fma(tq, r[u], dphi);
-                        }
-                    }
-                }
-            } else if (!done) {
-                // the poles up to j feed psi, the rest phi.  ONE loop with a wavefront-uniform trip
-                // count (k is the team's) over this lane's poles, four at a time: unconditional
-                // loads from a clamped index, the psi / phi split and the end of the list by
-                // selects.  (Written as two runs with per-lane bounds -- up to j, beyond j -- the
-                // loop compiled to an exec-mask loop with every load under its own branch and its
-                // own wait.)  Adding the zeros of the other run leaves each sum as it was.
-                for (int t0 = 0; t0 < npl; t0 += 4) {
-                    double rr[4], ww[4], dd[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int ic = min(sub + (t0 + u) * LPR, k - 1);
-                        ww[u] = W.w2[ic];
-                        dd[u] = W.dl[ic];
-                    }
-                    // (all four requests are out before the first value is waited for: left to
-                    // itself the scheduler, short of registers in this kernel, reuses one register
-                    // quad for all four loads and waits after each)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int i = sub + (t0 + u) * LPR;
-                        const bool in = i < k;
-                        ww[u] = in ? ww[u] : 0.;
-                        rr[u] = dc_rcp(in ? (dd[u] - dorg) - mu : 1.);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const double t = ww[u] * rr[u];
-                        const double tp = fmin(t, 0.), tq = fmax(t, 0.);
-                        psi += tp;
-                        dpsi = __builtin_fma(tp, rr[u], dpsi);
-                        phi += tq;
-                        dphi = __builtin_fma(tq, rr[u], dphi);
-                    }
-                }
-            }
-            psi = dc_quad_sum<LPR>(psi);
-            dpsi = dc_quad_sum<LPR>(dpsi);
-            phi = dc_quad_sum<LPR>(phi);
-            dphi = dc_quad_sum<LPR>(dphi);
-            if (!done) {
-                const double fabs_ = phi - psi;
-                psi *= rho; dpsi *= rho; phi *= rho; dphi *= rho;
-                const double f = 1. + psi + phi;
-                const double err = 8. * DC_EPS * (1. + rho * fabs_ * (1. + k));
-                if (fabs(f) <= err) {
-                    done = true;
-#ifdef BBO_EIG_SECULAR_HIST
-                    hist_it = it + 1;
-#endif
-                } else {
-                    if (f < 0.) lo = mu;
-                    else hi = mu;
-                    // two-pole rational model around the bracketing poles (middle way)
-                    const double dlp = (dj - dorg) - mu;
-                    double nmu = 0.5 * (lo + hi);
-                    if (last) {
-                        const double aa = dpsi * dlp * dlp, ss = psi - dpsi * dlp;
-                        const double c0 = 1. + ss + phi;
-                        const double eta = dlp + aa * dc_rcp(c0);
-                        const double cand = mu + eta;
-                        if (eta == eta && cand > lo && cand < hi) nmu = cand;
-                    } else {
-                        const double drp = (dn - dorg) - mu;
-                        const double aa = dpsi * dlp * dlp, ss = psi - dpsi * dlp;
-                        const double bb = dphi * drp * drp, rr = phi - dphi * drp;
-                        const double c0 = 1. + ss + rr;
-                        const double A1 = -(c0 * (dlp + drp) + aa + bb);
-                        const double A0 = c0 * dlp * drp + aa * drp + bb * dlp;
-                        // (the model only proposes the next iterate, the bracket and the residual
-                        // test decide: hardware estimates + Newton, not the IEEE sequences)
-                        const double disc = fmax(A1 * A1 - 4. * c0 * A0, 0.);
-                        const double qq = -0.5 * (A1 + (A1 >= 0. ? 1. : -1.) * dc_sqrt(disc));
-                        const double e1 = qq * dc_rcp(c0), e2 = A0 * dc_rcp(qq);
-                        const double c1 = mu + e1, c2 = mu + e2;
-                        if (e1 == e1 && c1 > lo && c1 < hi) nmu = c1;
-                        else if (e2 == e2 && c2 > lo && c2 < hi) nmu = c2;
-                    }
-                    if (!(hi - lo > 4. * DC_EPS * fmax(fabs(lo), fabs(hi)))) {
-                        done = true;
-#ifdef BBO_EIG_SECULAR_HIST
-                        hist_it = it + 1 + 100;      // (ended by the bracket, not the residual)
-#endif
-                    } else {
-                        // A model step (not a bisection) shorter than 2^-22 of the distance to the
-                        // nearer pole is the last one: the iteration converges quadratically, the
-                        // step that would follow is below the rounding of mu, and the evaluation
-                        // that would only confirm it is a sixth of the solve (round 4; on the
-                        // merges of scripts/dev_secular_model.py the accepted offset is, bit for
-                        // bit, the one the confirming evaluation accepts).
-                        const double step = fabs(nmu - mu);
-                        const double dist = fmin(fabs((dj - dorg) - nmu), last ? fabs(nmu) : fabs((dn - dorg) - nmu));
-                        if (nmu != 0.5 * (lo + hi) && step <= 0x1p-22 * dist) {
-                            done = true;
-#ifdef BBO_EIG_SECULAR_HIST
-                            hist_it = it + 1;
-#endif
-                        }
-                        mu = nmu;
-                    }
-                }
-            }
-            // every wavefront leaves when ITS roots are done (the loop reads the merge's vectors
-            // and writes nothing shared): no workgroup barrier per iteration, and a finished
-            // wavefront leaves its SIMD's issue slots to the one still iterating
-            if (__ballot(!done) == 0ull) {
-                if (stamps && threadIdx.x == 0 && a == 0) stamps[31] = it + 1;
-                break;
-            }
-        }
-        MG_STAMP(33);
-#ifdef BBO_EIG_SECULAR_HIST
-        // (diagnostic build: histogram of the iterations per root of the widest merge in slots
-        // 34..46, the root with the most in 47 as j * 1000 + iterations)
-        if (stamps && act && sub == 0 && b - a > 64) {
-            atomicAdd((unsigned long long*) &stamps[34 + min(hist_it, 12)], 1ull);
-            atomicMax((unsigned long long*) &stamps[47], (unsigned long long) hist_it * 1000000ull + j * 1000ull + k);
-        }
-#endif
-        if (act && sub == 0) {
-            W.mu[j] = mu;
-            W.org[j] = o;
-            W.lam[j] = dorg;       // (the origin pole itself, for the Loewner products below)
-            // root j lies in [d_j, d_j+1] -- in floating point too, for finite input -- which is what
-            // puts the roots in ascending order for the output ranking below.  Where it does not
-            // hold (NaN / Inf in the merge) the flag of the sequential deflation scan, consumed
-            // by now, sends that ranking to the form that is a permutation whatever the data.
-            const double lj = dorg + mu;
-            if (!(lj >= dj && lj <= dn)) W.cnt[3] = 1;
-        }
-        if (on && k == 1 && ttid == 0) {
-            W.mu[0] = rho * W.w2[0];
-            W.org[0] = 0;
-        }
-    }
+    // ---- secular equation: LPR lanes per root (dc_secular) ---------------------------------
+    dc_secular<LPR>(W, k, rho, ttid, on, stamps, a == 0, b - a);
     dc_sync(wv);
 
     MG_STAMP(27);
