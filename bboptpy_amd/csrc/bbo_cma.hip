@@ -587,6 +587,13 @@ void CmaEngine::launch_eigen()
         hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
         hipLaunchKernelGGL(cma_eig_halves, dim3(3, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,
                 plh, pl.lda);
+        // the top merge: with few matrices in flight its secular equation goes to ceil(n / 32)
+        // workgroups of its own between the two parts (diagnostic bit 67108864: one kernel)
+        if ((long) c.npop * 8 <= 256 && !(d_.dbg & 67108864)) {
+            hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 1);
+            hipLaunchKernelGGL(cma_eig_secular, dim3((c.n + 31) / 32, c.npop), dim3(512), 0, stream_, d_, c_);
+            hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 2);
+        } else
         hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
     } else if (pl.hybrid)
         hipLaunchKernelGGL(cma_eigen_g, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,

@@ -1193,7 +1193,9 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
             eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
                     !LDSM && !(d.dbg & 2) && !(d.dbg & 1024),   // (hybrid: V already in its place)
-                    nullptr, STAGE == 2 ? 2 : 0, STAGE == 2 && tri[4 * n] != 0.);
+                    nullptr, STAGE == 2 ? 2 : 0, STAGE == 2 && tri[4 * n] != 0.,
+                    STAGE == 2 ? force : 0, tri + 4 * n + 8);      // (STAGE 2: `force` = the part)
+            if (STAGE == 2 && force == 1) return;
         } else if (TT == EIG_THREADS && !LDSM) {
             // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
             // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
@@ -1335,9 +1337,29 @@ __global__ __launch_bounds__(512) void cma_eigen_g1(CmaDev d, CmaConst c, EigPla
 {
     cma_eigen_impl<512, false, 1, 1>(d, c, pl, force);
 }
-__global__ __launch_bounds__(512) void cma_eigen_g2(CmaDev d, CmaConst c, EigPlan pl, int force)
+// (`part`: 0 = the whole top merge; 1 = up to the secular equation, 2 = from behind it, with
+// cma_eig_secular in between)
+__global__ __launch_bounds__(512) void cma_eigen_g2(CmaDev d, CmaConst c, EigPlan pl, int part)
 {
-    cma_eigen_impl<512, false, 1, 2>(d, c, pl, force);
+    cma_eigen_impl<512, false, 1, 2>(d, c, pl, part);
+}
+// The secular equation of the top merge of a 128 < n <= 256 matrix on ceil(n / 32) workgroups: 32
+// roots each, 16 lanes per root, the poles of a lane in registers.  On the one workgroup of
+// cma_eigen_g2 it is 82 us of vector issue (two lanes per root, 128 poles per lane from LDS) while
+// the other CUs idle: the loop is bound by that CU's issue rate, not by latency -- 1024 threads
+// there changed nothing.  grid (ceil(n / 32), P), 512 threads.
+__global__ __launch_bounds__(512) void cma_eig_secular(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (sc->eig_stage != 1) return;
+    const int n = c.n;
+    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(c.ld);
+    const DcWork W = dc_work_layout(tri + 4 * n + 8, n + 2, nullptr);
+    const int k = W.cnt[0];
+    const double rho = W.red[14];
+    dc_secular<16>(W, k, rho, 512 * (int) blockIdx.x + (int) threadIdx.x, true, nullptr, false, n);
 }
 
 // grid (2, P), 512 threads, dynamic LDS of the n = 128 plan (plh); lda_work: row stride of the

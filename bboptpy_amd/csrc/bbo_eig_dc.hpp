@@ -252,6 +252,26 @@ __device__ inline double dc_quad_sum(double v)
     return v;
 }
 
+// the work area of the merges at p (LDS inside a workgroup; a global image of it between the
+// kernels of a split top merge): arrays of M entries, see DcWork
+__device__ inline DcWork dc_work_layout(double *p, int M, int *maxnr, size_t *doubles_used = nullptr)
+{
+    DcWork W;
+    double *p0 = p;
+    W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
+    W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
+    W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
+    W.balk = reinterpret_cast<unsigned long long*>(p); p += 8;
+    W.bald = reinterpret_cast<unsigned long long*>(p); p += 8;
+    int *ip = reinterpret_cast<int*>(p);
+    W.srcS = ip; ip += M; W.kp = ip; ip += M; W.dp = ip; ip += M; W.org = ip; ip += M;
+    W.outpos = ip; ip += M; W.rotp = ip; ip += M; W.rotj = ip; ip += M;
+    W.rowmap = ip; ip += M; W.colroot = ip; ip += M; W.cnt = ip; ip += 4 * 8;
+    W.maxnr = maxnr;
+    if (doubles_used) *doubles_used = (size_t) (p - p0) + ((size_t) (ip - reinterpret_cast<int*>(p)) + 1) / 2;
+    return W;
+}
+
 // ---- the secular equation 1 + rho sum_i w_i / (d_i - lam) = 0: root j by LPR lanes (thread rt of
 // the team: j = rt / LPR), every lane the poles i = sub + LPR t.  Reads W.dl, W.w2 (k kept poles,
 // ascending); writes W.mu[j] (offset from the origin pole), W.org[j], W.lam[j] (the origin pole) and
@@ -498,7 +518,8 @@ __device__ __forceinline__ void dc_secular(const DcWork &W, int k, double rho, i
 template<int LPR, bool do_gemm, bool BIG = false, bool WIDE = true>
 __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, int mid, int b,
         double rho_in, double *dv, double *Fg, const DcWork &W0, long long *stamps,
-        int mlevel = 0, double *Tg = nullptr)     // widest merge of this level; m x m global scratch
+        int mlevel = 0, double *Tg = nullptr,     // widest merge of this level; m x m global scratch
+        int part = 0)       // 1: stop before the secular equation, 2: start behind it (cma_eig_secular)
 {
 #define MG_STAMP(slot) do { if (stamps && threadIdx.x == 0 && a == 0) stamps[slot] = wall_clock64(); } while (0)
     MG_STAMP(24);
@@ -517,6 +538,9 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     W.outpos += a; W.rotp += a; W.rotj += a; W.rowmap += a; W.colroot += a;
     W.cnt += 4 * tm.id;
 
+    // (the part of a merge in front of the secular equation, as a unit: the top merge of a matrix
+    // wider than 128 can stop behind it and hand the roots to several workgroups)
+    auto front = [&]() -> double {
     // ---- poles and z, ascending -------------------------------------------------------
     double zi = 0., di = 0.;
     // The binary-search ranking below is a permutation only if EACH input list ascends in dc_key.
@@ -649,10 +673,7 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
         atomicMax(W.maxnr, nr);
     }
     dc_sync(wv);
-    const int k = on ? W.cnt[0] : 0, nd = on ? W.cnt[1] : 0, nr = on ? W.cnt[2] : 0;
-    // (rotations anywhere on this level; a one-wavefront team shares no barrier with the others
-    // and goes by its own count)
-    const int maxnr = wv ? nr : *W.maxnr;
+    const int k = on ? W.cnt[0] : 0, nr = on ? W.cnt[2] : 0;
 
     // kept poles ascending (a rotation may perturb the order by rounding)
     if (ttid < k) {
@@ -677,11 +698,27 @@ __device__ inline void dc_merge_level(const DcMat &Q, const DcTeam &tm, int a, i
     dc_sync(wv);
     if (ttid < k) W.kp[ttid] = W.org[ttid];
     dc_sync(wv);
+    return rho;
+    };     // front
+    double rho = 0.;
+    if (part != 2) rho = front();
+    const int k = on ? W.cnt[0] : 0, nd = on ? W.cnt[1] : 0, nr = on ? W.cnt[2] : 0;
+    // (rotations anywhere on this level; a one-wavefront team shares no barrier with the others
+    // and goes by its own count)
+    const int maxnr = wv ? nr : *W.maxnr;
 
     MG_STAMP(26);
+    if (part == 1) {
+        // (the caller saves the work area; rho travels in a free slot of the reduction scratch)
+        if (on && ttid == 0) W.red[14] = rho;
+        dc_sync(wv);
+        return;
+    }
     // ---- secular equation: LPR lanes per root (dc_secular) ---------------------------------
-    dc_secular<LPR>(W, k, rho, ttid, on, stamps, a == 0, b - a);
-    dc_sync(wv);
+    if (part == 0) {
+        dc_secular<LPR>(W, k, rho, ttid, on, stamps, a == 0, b - a);
+        dc_sync(wv);
+    }
 
     MG_STAMP(27);
     // ---- Loewner z and column norms -------------------------------------------------------
@@ -1289,7 +1326,9 @@ template<int TT = 512, bool BIG = false, bool WIDE = true>
 __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, double *ev, double *G,
         double *Bout, int ldb, double *scratch, long long *stamps, int dbg, int ext_top = 0,
         const double *hv = nullptr, bool qh_ready = false, double *Tscratch = nullptr, int mode = 0,
-        bool t_prebuilt = false)     // (mode 2: the reflector panels' T factors are in place already)
+        bool t_prebuilt = false,     // (mode 2: the reflector panels' T factors are in place already)
+        int top_part = 0, double *Wimg = nullptr)   // (mode 2: 1 = up to the secular equation, the work
+                                                     // area goes to Wimg; 2 = resume from Wimg behind it)
 {
     // mode (round 4, 128 < n <= 256 split over workgroups): 0 = the whole decomposition;
     // 1 = a HALF of a torn matrix as a problem of its own (Q in LDS, no reflectors): leaves and all
@@ -1330,21 +1369,8 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         dc_build_T(n, Q.a, taug, taug + n, scratch, Q.ld);
         __syncthreads();
     }
-    DcWork W;
-    {
-        double *p = scratch;
-        const int M = ext_top ? n + 2 : 130;
-        W.dS = p; p += M; W.zS = p; p += M; W.dl = p; p += M; W.w2 = p; p += M; W.ws = p; p += M;
-        W.mu = p; p += M; W.what = p; p += M; W.lam = p; p += M; W.ninv = p; p += M;
-        W.rotc = p; p += M; W.rots = p; p += M; W.red = p; p += 16;
-        W.balk = reinterpret_cast<unsigned long long*>(p); p += 8;
-        W.bald = reinterpret_cast<unsigned long long*>(p); p += 8;
-        int *ip = reinterpret_cast<int*>(p);
-        W.srcS = ip; ip += M; W.kp = ip; ip += M; W.dp = ip; ip += M; W.org = ip; ip += M;
-        W.outpos = ip; ip += M; W.rotp = ip; ip += M; W.rotj = ip; ip += M;
-        W.rowmap = ip; ip += M; W.colroot = ip; ip += M; W.cnt = ip; ip += 4 * 8;
-        W.maxnr = &maxnr_s;
-    }
+    size_t w_doubles = 0;
+    DcWork W = dc_work_layout(scratch, ext_top ? n + 2 : 130, &maxnr_s, &w_doubles);
     // scale to unit max-norm by a power of two
     double am = 0.;
     for (int i = tid; i < n; i += T) am = fmax(am, fmax(fabs(dv[i]), fabs(ev[i])));
@@ -1466,10 +1492,21 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         const double rho = ev[mid - 1];
         if (ext_top && nc == 2) {
             // the top merge of a matrix wider than 128 (512 threads): scalar part only
+            if (top_part == 2) {
+                for (size_t q = tid; q < w_doubles; q += T) scratch[q] = Wimg[q];
+                __syncthreads();
+                if (tid == 0) maxnr_s = W.cnt[2];
+                __syncthreads();
+            }
             if (2 * m <= tm.tthreads)
-                dc_merge_level<2, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+                dc_merge_level<2, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf, top_part);
             else
-                dc_merge_level<1, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
+                dc_merge_level<1, false, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf, top_part);
+            if (top_part == 1) {
+                __syncthreads();
+                for (size_t q = tid; q < w_doubles; q += T) Wimg[q] = scratch[q];
+                return;
+            }
         } else if (4 * m <= tm.tthreads)
             dc_merge_level<4, true, BIG, WIDE>(Q, tm, a, mid, b, rho, dv, Fg, W, stamps, m, Tbuf);
         else if (2 * m <= tm.tthreads)
