@@ -618,8 +618,15 @@ void CmaEngine::launch_eigen()
         if ((d_.dbg & 2) || !pl.hybrid)     // (n > 256: Q_house was accumulated by the reduction)
             hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
         else
+        {
+            // few matrices: a 16-column tile per WORKGROUP, its rows dealt to the four wavefronts
+            // (diagnostic bit 134217728 keeps a tile per wavefront)
+            if ((long) c.npop * ((c.n + 15) / 16) <= 256 && !(d_.dbg & 134217728))
+                hipLaunchKernelGGL(cma_eig_wy4, dim3((c.n + 15) / 16, c.npop), dim3(256), 0, stream_, d_, c_);
+            else
             hipLaunchKernelGGL(cma_eig_wy, dim3((c.n + 63) / 64, c.npop), dim3(256), 0, stream_, d_,
                     c_);
+        }
         BBO_HIP(hipGetLastError());
     }
     timer_.begin(stream_, K_POST);

@@ -1612,6 +1612,114 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
     }
 }
 
+// The same product for FEW matrices (round 4): cma_eig_wy is 16 wavefronts per matrix, each a chain of
+// ~1100 dependent-issue MFMAs (64 us at n = 256 on an otherwise idle chip).  Here the four
+// wavefronts of a workgroup SHARE one 16-column tile: wavefront w keeps the row tiles rt = w, w + 4,
+// ... (cyclic: the reflectors of panel b reach rows < 16 b + 16 only, so the work stays even),
+// forms its part of W = V_b^T M, the parts are added through LDS (in wavefront order: the sum does
+// not depend on timing), every wavefront forms T_b^T W itself and updates its own row tiles.
+// Per panel 36 MFMAs per wavefront instead of 132, two barriers (the panels alternate between two
+// LDS buffers).  grid (ceil(n / 16), P), 256 threads
+__global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (!sc->eigen_done) return;
+    __shared__ __attribute__((aligned(16))) double Vp[2][16 * WY_LDV];
+    __shared__ __attribute__((aligned(16))) double wpart[4][256];
+    const int n = c.n, ld = c.ld;
+    const size_t slab = eig_slab(ld);
+    const double *base = d.eig_work + (size_t) 4 * p * slab;
+    const double *V = base + slab;
+    const double *tau = base + slab + (size_t) 2 * n * n;
+    const double *Tg = tau + n;
+    const double *M = base + 3 * slab;
+    double *Bp = d.B + (size_t) p * ld * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int npanel = (n + 15) >> 4;
+    const int col = blockIdx.x * 16 + fr;
+    // this wavefront's row tiles: rt = wave + 4 j
+    d4_eig q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * (wave + 4 * j) + fk + 4 * r;
+            q[j][r] = (row < n && col < n) ? M[(size_t) row * n + col] : 0.;
+        }
+    double pre[16];
+    auto fetch = [&](int b) {
+        const int i0 = 16 * b, reach = min(n, i0 + 16);
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            pre[u] = (i0 + u < n && tid < reach) ? V[(size_t) (i0 + u) * n + tid] : 0.;
+    };
+    fetch(0);
+#pragma unroll
+    for (int u = 0; u < 16; u++) Vp[0][u * WY_LDV + tid] = pre[u];
+    if (npanel > 1) fetch(1);
+    __syncthreads();
+    for (int b = 0; b < npanel; b++) {
+        const double *Vb = Vp[b & 1];
+        const int reach = min(n, 16 * b + 16);
+        double tv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int kk = 4 * ks + fk;
+            tv[ks] = kk <= fr ? Tg[(size_t) b * 256 + kk * 16 + fr] : 0.;
+        }
+        // the next panel goes to the other buffer (its last readers passed the barrier at the end of
+        // panel b - 1), the one after it starts its way from L2
+        if (b + 1 < npanel) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) Vp[(b + 1) & 1][u * WY_LDV + tid] = pre[u];
+            if (b + 2 < npanel) fetch(b + 2);
+        }
+        d4_eig w = { 0., 0., 0., 0. };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int rt = wave + 4 * j;
+            if (16 * rt < reach) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Vb[fr * WY_LDV + 16 * rt + 4 * r + fk],
+                            q[j][r], w, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) wpart[wave][64 * r + lane] = w[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            w[r] = ((wpart[0][64 * r + lane] + wpart[1][64 * r + lane]) + wpart[2][64 * r + lane])
+                    + wpart[3][64 * r + lane];
+        d4_eig w2 = { 0., 0., 0., 0. };
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[ks], w[ks], w2, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int rt = wave + 4 * j;
+            if (16 * rt < reach) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+                    q[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            -Vb[(4 * ks + fk) * WY_LDV + 16 * rt + fr], w2[ks], q[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();      // wpart and this panel's buffer are free again; the next panel is staged
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * (wave + 4 * j) + fk + 4 * r;
+            if (row < n && col < n) Bp[(size_t) row * ld + col] = q[j][r];
+        }
+}
+
 // ---------------------------------------------------------------------------
 // n <= 16: the whole decomposition by ONE WAVEFRONT, four matrices per workgroup.  cma_eigen
 // spends a 512-thread workgroup -- the whole register file of a CU -- on a matrix whatever its
