@@ -417,6 +417,10 @@ void CmaEngine::launch_sample_eval()
         dim3 grid(c.lambda_pad / 16, c.npop);
         const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
         allow_lds((const void*) cma_sample_eval<8>, 80 * 1024);   // ld = 512: 65 792 bytes
+        // a handful of row tiles on the whole chip (C5: two): one column tile per wavefront
+        if ((long) grid.x * grid.y <= 32 && c.ld <= 256 && !(d_.dbg & 268435456))
+            hipLaunchKernelGGL((cma_sample_eval<1, 16>), grid, dim3(1024), lds, stream_, d_, c_);
+        else
         switch (pick_maxt(c.ld)) {
         case 1: hipLaunchKernelGGL(cma_sample_eval<1>, grid, dim3(256), lds, stream_, d_, c_); break;
         case 2: hipLaunchKernelGGL(cma_sample_eval<2>, grid, dim3(256), lds, stream_, d_, c_); break;

@@ -127,10 +127,15 @@ __device__ inline double cma_settle_draw(const CmaDev &d, const CmaConst &c, int
 
 // ---------------------------------------------------------------------------
 // sample + evaluate: X = m + sigma * Z (B diag D)^T, f = objective(X)
-// grid (lambda_pad/16, P), 256 threads; dynamic LDS 16*(ld+2) doubles
+// grid (lambda_pad/16, P), 64 NW threads; dynamic LDS 16*(ld+2) doubles
+// NW wavefronts, MAXT column tiles each (NW * MAXT >= ld / 16).  NW = 4 is the form for many row
+// tiles; with a handful of candidates (C5: lambda = 20 at n = 256, two workgroups on the whole
+// chip) the sweep is a chain of L2 round trips for the operand, one per group of k-steps and
+// wavefront, and NW = ld / 16 wavefronts of ONE column tile each put four times the requests in
+// flight (round 4: 60 -> 3x us).  Same products in the same order for every NW.
 // ---------------------------------------------------------------------------
-template<int MAXT>
-__global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
+template<int MAXT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void cma_sample_eval(CmaDev d, CmaConst c)
 {
     const int p = blockIdx.y, mt = blockIdx.x;
     const CmaScal *sc = d.scal + p;
@@ -142,12 +147,12 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
 
     // 1. the standard normals of these 16 candidates (four per Philox call)
     __shared__ double2 ntab[NORMAL_TABLE_N];
-    normal_table_fill(ntab, tid, 256);
+    normal_table_fill(ntab, tid, 64 * NW);
     __syncthreads();
     const int nquads = ld >> 2;
     const uint32_t sw = stream_word(STREAM_CMA_NORMAL, (uint32_t) p);
     uint64_t pend = 0;                       // 4 bits per call this thread draws (<= 16 calls)
-    for (int qi = tid, it = 0; qi < 16 * nquads; qi += 256, it++) {
+    for (int qi = tid, it = 0; qi < 16 * nquads; qi += 64 * NW, it++) {
         const int r = qi / nquads, q = qi - r * nquads;
         double z[4];
         pend |= (uint64_t) cma_draw_quad_fast(d, c, p, mt * 16 + r, q, gen, sw, ntab, z) << (4 * it);
@@ -158,13 +163,13 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     while (pend) {
         const int b = __ffsll((unsigned long long) pend) - 1;
         pend &= pend - 1;
-        const int qi = tid + 256 * (b >> 2), r = qi / nquads, q = qi - r * nquads;
+        const int qi = tid + 64 * NW * (b >> 2), r = qi / nquads, q = qi - r * nquads;
         lds[r * ldz + cma_quad_col0(q) + 4 * (b & 3)] =
                 cma_settle_draw(d, c, p, mt * 16 + r, q, b & 3, gen, sw, ntab);
     }
     __syncthreads();
 
-    // 2. 16 x ld tile of Z (B D)^T on the matrix cores; wave w owns column tiles w, w+4, ...
+    // 2. 16 x ld tile of Z (B D)^T on the matrix cores; wave w owns column tiles w, w + NW, ...
     d4_t acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; t++) acc[t] = d4_t { 0., 0., 0., 0. };
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
             a[u] = lds[ar * ldz + 4 * (ks0 + u) + ak];
 #pragma unroll
             for (int t = 0; t < MAXT; t++) {
-                const int nt = wave + 4 * t;
+                const int nt = wave + NW * t;
                 b[u][t] = nt < NT ? bdp[((size_t) nt * KS + ks0 + u) * 64 + lane] : 0.;
             }
         }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
             zz = __builtin_fma(a[u], a[u], zz);
 #pragma unroll
             for (int t = 0; t < MAXT; t++) {
-                const int nt = wave + 4 * t;
+                const int nt = wave + NW * t;
                 if (nt < NT)
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][t], acc[t], 0, 0, 0);
             }
@@ -215,14 +220,14 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     double xmc[MAXT], loc[MAXT], upc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
-        const int col = min((wave + 4 * t) * 16 + (lane & 15), ld - 1);
+        const int col = min((wave + NW * t) * 16 + (lane & 15), ld - 1);
         xmc[t] = xm[col];
         loc[t] = c.bound ? d.lower[col] : 0.;
         upc[t] = c.bound ? d.upper[col] : 0.;
     }
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
-        const int nt = wave + 4 * t;
+        const int nt = wave + NW * t;
         if (nt < NT) {
             const int col = nt * 16 + (lane & 15);
 #pragma unroll
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void cma_sample_eval(CmaDev d, CmaConst c)
     __syncthreads();
 
     // 4. objective: 16 lanes per candidate
-    if (c.obj >= 0) {
+    if (c.obj >= 0 && tid < 256) {
         const int r = tid >> 4, g = tid & 15;
         double f = eval_row_group<16>(c.obj, c.n, &lds[r * ldz], d.aux, g);
         if (g == 0) {
