@@ -1,12 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats (+ the two PMC passes for the
 # headline workload) of the bench workloads; everything lands in gpurun_out/prof_<tag>/.
-# usage: scripts/profile_all.sh <tag>
+# usage: scripts/profile_all.sh <tag> [workload ...]   (default: all nine)
 TAG=$1
+shift
+ONLY=" $* "
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for spec in "M 256 pmc" "C3 256 pmc" "C2 256 pmc" "C1 4096 nopmc" "C4 1 nopmc" "C5I 1 nopmc" "SEP 64 pmc" "CSO 4 nopmc" "CCPSO 16 nopmc"; do
   set -- $spec
   WL=$1; P=$2; PMC=$3
+  if [ "$ONLY" != "  " ] && [ "${ONLY#* $WL }" = "$ONLY" ]; then continue; fi
   OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
   mkdir -p $OUT
   export TMPDIR=/tmp
