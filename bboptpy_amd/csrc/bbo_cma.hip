@@ -575,18 +575,25 @@ void CmaEngine::launch_eigen()
         allow_lds((const void*) cma_eigen_g1, 160 * 1024 - 768);
         allow_lds((const void*) cma_eigen_g2, 160 * 1024 - 768);
         allow_lds((const void*) cma_eig_halves, 160 * 1024 - 768);
-        // the reduction: spread over MW_G workgroups per matrix where that pays -- its steps cost the
-        // same ~2.8 us (an exchange between compute units each) whatever n is, the one-workgroup
-        // steps shrink with n: 1.00 against 0.94 ms per decomposition at n = 224, 1.10 against 1.18
-        // at n = 256 -- and while all of a launch's workgroups fit the chip at once (they wait for
-        // each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one workgroup,
-        // 33554432 spreads it for every 128 < n <= 256)
-        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 128
-                && (c.n >= 248 || (d_.dbg & 33554432));
+        // the reduction: its first n - 128 steps spread over MW_G workgroups per matrix (2.8 us per
+        // step, an exchange between compute units each, where the one-workgroup step with the whole
+        // active matrix on chip costs ~5), the leading 128 x 128 block then on one workgroup
+        // (1.15 us per step): 0.35 against 0.36 ms per decomposition at n = 132, 0.63 / 0.73 at 200,
+        // 0.83 / 1.04 at 256 -- while all of a launch's workgroups fit the chip at once (they wait
+        // for each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one
+        // workgroup)
+        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 128;
         if (use_mw) {
             if (mw_buf_.count != (size_t) c.npop * MW_BUF_DOUBLES) mw_buf_.alloc((size_t) c.npop * MW_BUF_DOUBLES);
+            // (its steps down to the leading 128 x 128 block; that block on one workgroup: diagnostic
+            // bit 536870912 keeps all steps spread)
+            const int istop = (d_.dbg & 536870912) ? 1 : 128;
             hipLaunchKernelGGL(cma_tred_mw, dim3(8 * MW_G, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
-                    mw_buf_.p, ++mw_launch_);
+                    mw_buf_.p, ++mw_launch_, istop);
+            if (istop > 1) {
+                allow_lds((const void*) cma_tred_tail, 160 * 1024 - 768);
+                hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl);
+            }
         } else
         hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
         hipLaunchKernelGGL(cma_eig_halves, dim3(3, c.npop), dim3(512), plh.lds_bytes, stream_, d_, c_,

@@ -1090,6 +1090,8 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     if (c.honor_stop && sc->stop != 0) return;
     if (STAGE == 2) {
         if (sc->eig_stage != 1) return;
+    } else if (STAGE == 3) {
+        // (cma_tred_mw made the decision and did -- or did not -- its part: checked below)
     } else
     // cmaes.cpp:233: skip until enough evaluations have passed
     if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
@@ -1131,6 +1133,35 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         ev[-1 - tid] = 0.;
     }
     double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld);     // (STAGE 1 / 2 hand-over)
+    if (STAGE == 3) {
+        // the tail of a reduction cma_tred_mw began (bbo_eig_mw.hpp): the leading 128 x 128 block, as
+        // the spread steps left it in eig_work[0], through the register-resident reduction; d, e, h of
+        // rows < 128 and the reflectors' rows < 128 join what cma_tred_mw has written already
+        if (tri[4 * n + 1] != 1. || sc->eig_mw_fail) return;     // (it skipped this generation, or a wavefront gave up)
+        constexpr int LB = 130;
+        EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), LB };
+        const double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(ld);
+        for (int q = tid; q < 128 * 64; q += T) {
+            const int r = q >> 6, c2 = (q & 63) * 2;
+            *reinterpret_cast<double2*>(&Ast.a[r * LB + c2]) =
+                    *reinterpret_cast<const double2*>(&L11[(size_t) r * 128 + c2]);
+        }
+        __syncthreads();
+        eig_tred_accum_reg128(Ast.a, LB, 128, Ast, dv, ev, uv, wv, gv, hvec, td, tid, nullptr, A.a, A.ld,
+                false, false);
+        double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
+        for (int i = tid; i < 128; i += T) {
+            tri[i] = td[i];
+            if (i >= 1) tri[n + i - 1] = ev[i];
+            tri[2 * n + i] = hvec[i];
+        }
+        for (int q = tid; q < 128 * n; q += T) {
+            const int r = q / n, cidx = q - r * n;
+            Vout[q] = cidx < r ? Ast(r, cidx) : 0.;
+        }
+        if (tid == 0) sc->eig_stage = 1;
+        return;
+    }
     if (STAGE == 2) {
         for (int i = tid; i < n; i += T) {
             dv[i] = tri[3 * n + i];
@@ -1336,6 +1367,11 @@ __global__ __launch_bounds__(512) void cma_eigen_b(CmaDev d, CmaConst c, EigPlan
 __global__ __launch_bounds__(512) void cma_eigen_g1(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
     cma_eigen_impl<512, false, 1, 1>(d, c, pl, force);
+}
+// the tail of a reduction that cma_tred_mw began (the leading 128 x 128 block on one workgroup)
+__global__ __launch_bounds__(512) void cma_tred_tail(CmaDev d, CmaConst c, EigPlan pl)
+{
+    cma_eigen_impl<512, false, 1, 3>(d, c, pl, 0);
 }
 // (`part`: 0 = the whole top merge; 1 = up to the secular equation, 2 = from behind it, with
 // cma_eig_secular in between)

@@ -98,8 +98,11 @@ __device__ inline double mw_row8_sum(double v)
 
 // grid (8 * MW_G, P), MW_T threads; mwbuf: MW_BUF_DOUBLES per population, zero at allocation;
 // launch: a counter the host increments per launch (the flags are never reset)
+// istop: the last pivot row this kernel takes (1: the whole reduction; 128: the leading 128 x 128
+// block, updated, goes to eig_work[0] (row stride 128) and cma_tred_tail finishes it on one
+// workgroup, whose steps cost 1.15 us where the steps here cost 2.8)
 __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int force, double *mwbuf,
-        unsigned long long launch)
+        unsigned long long launch, int istop)
 {
     const int p = blockIdx.y;
     if ((int) (blockIdx.x & 7) != (p & 7)) return;
@@ -112,6 +115,9 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         if (g == 0 && tid == 0) {
             sc->eigen_done = 0;
             sc->eig_stage = 0;
+            // (cma_tred_tail must not take what an earlier generation, or the products that have
+            // used this slab since, left in the hand-over flag)
+            d.eig_work[(size_t) (4 * p + 3) * eig_slab(c.ld) + 4 * c.n + 1] = 0.;
         }
         return;
     }
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         tri[n + n - 1] = 0.;           // (the sub-diagonal is handed over shifted down by one)
         tri[2 * n] = 0.;
         tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
+        tri[4 * n + 1] = 0.;           // (this kernel's part of the reduction: not done yet)
     }
     if (recorder)
         for (int idx = lane; idx < n; idx += 64) Vout[idx] = 0.;      // row 0: no reflector
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
 #define MW_CK(k) do { } while (0)
 #endif
 
-    for (int i = n - 1; i >= 1 && !failed; i--) {
+    for (int i = n - 1; i >= istop && !failed; i--) {
         const unsigned long long epoch = launch * 512ull + (unsigned long long) (n - i);
         const int par = i & 1;
         // ---- the reflector of this step, by every wavefront ------------------------------------
@@ -306,6 +313,18 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
 #undef MW_CK
     if (failed) {
         if (lane == 0) sc->eig_mw_fail = 1;
+        return;
+    }
+    if (istop > 1) {
+        // the rest is one workgroup's: this thread's part of the leading block, as it stands
+        double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(ld);
+        if (r < istop) {
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+                if (16 * t + 2 * s < istop)
+                    *reinterpret_cast<double2*>(&L11[(size_t) r * istop + 16 * t + 2 * s]) = a2[t];
+        }
+        if (recorder && lane == 0) tri[4 * n + 1] = 1.;
         return;
     }
     if (g == 0 && tid == 0) sc->eig_stage = 1;

@@ -331,17 +331,18 @@ def test_eigendecomposition_every_dimension_to_130(hip):
 
 @pytest.mark.parametrize("n", [129, 143, 160, 200, 250, 256])
 def test_eigensolver_forms_for_128_to_256_agree(hip, n):
-    """128 < n <= 256 has three forms of the decomposition: everything in one workgroup (round 3,
-    diagnostic bit 4194304), the split one -- reduction, the two halves of the torn tridiagonal
-    matrix side by side on two workgroups, top merge (bit 16777216 keeps its reduction on one
-    workgroup) -- and the split one with the Householder reduction itself spread over eight
-    workgroups that exchange a vector per step (bbo_eig_mw.hpp; bit 33554432 uses it for every n
-    of the class, by default it starts at n = 248).  Different leaf sizes and summation orders, so
-    not the same bits: the same eigenvalues to rounding, and each form's own residual and
-    orthogonality; the spread reduction must not have given up (its bounded waits)."""
+    """128 < n <= 256 has four forms of the decomposition: everything in one workgroup (round 3,
+    diagnostic bit 4194304); the split one -- reduction, the two halves of the torn tridiagonal
+    matrix side by side on two workgroups, the top merge with its secular equation on eight more
+    -- with the reduction on one workgroup (bit 16777216); the default, whose reduction runs its
+    first n - 128 steps spread over eight workgroups that exchange a vector per step
+    (bbo_eig_mw.hpp) and hands the leading 128 x 128 block to one workgroup; and that with ALL
+    steps spread (bit 536870912).  Different leaf sizes and summation orders, so not the same bits:
+    the same eigenvalues to rounding, and each form's own residual and orthogonality; the spread
+    reduction must not have given up (its bounded waits)."""
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
-    forms = {"one workgroup": 4194304, "split": 16777216, "split, spread reduction": 33554432}
+    forms = {"one workgroup": 4194304, "split": 16777216, "default": 0, "all steps spread": 536870912}
     for name, Cm in _spd_cases(n, rng):
         Cm = 0.5 * (Cm + Cm.T)
         lam = np.linalg.eigvalsh(Cm)
@@ -350,7 +351,8 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
         for form, bit in forms.items():
             g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
             g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
-            g.set_state("dbg", [float(bit)])
+            if bit:
+                g.set_state("dbg", [float(bit)])
             g.set_state("C", Cm)
             g.set_state("fev", [10 ** 6])
             g.set_state("eigenlastev", [0])
@@ -361,7 +363,7 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
             assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, form)
             assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm), (name, form)
             Ds[form] = D * D
-        for form in ("split", "split, spread reduction"):
+        for form in ("split", "default", "all steps spread"):
             assert np.abs(Ds[form] - Ds["one workgroup"]).max() <= 1e-12 * sc, (name, form)
 
 
