@@ -579,10 +579,10 @@ void CmaEngine::launch_eigen()
         // step, an exchange between compute units each, where the one-workgroup step with the whole
         // active matrix on chip costs ~5), the leading 128 x 128 block then on one workgroup
         // (1.15 us per step): 0.35 against 0.36 ms per decomposition at n = 132, 0.63 / 0.73 at 200,
-        // 0.83 / 1.04 at 256 -- while all of a launch's workgroups fit the chip at once (they wait
-        // for each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one
+        // 0.83 / 1.04 at 256 -- while all of a launch's workgroups (256 threads, ~100 registers: two
+        // and more fit a CU) are resident at once (they wait for each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one
         // workgroup)
-        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 128;
+        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 256;
         if (use_mw) {
             if (mw_buf_.count != (size_t) c.npop * MW_BUF_DOUBLES) mw_buf_.alloc((size_t) c.npop * MW_BUF_DOUBLES);
             // (its steps down to the leading 128 x 128 block; that block on one workgroup: diagnostic

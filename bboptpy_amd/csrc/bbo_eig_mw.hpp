@@ -121,6 +121,9 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         }
         return;
     }
+    // (diagnostic bit 1073741824: one of the workgroups walks away -- what the others do about a
+    // partner that never publishes is tested, not assumed: tests/test_cma_gpu.py)
+    if ((d.dbg & 1073741824) && g == 3) return;
     __shared__ __attribute__((aligned(16))) double ubuf[4][256];
     __shared__ __attribute__((aligned(16))) double wbuf[4][256];
     __shared__ unsigned arrived;          // wavefronts that have published, over all steps so far
@@ -312,7 +315,10 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
 #endif
 #undef MW_CK
     if (failed) {
-        if (lane == 0) sc->eig_mw_fail = 1;
+        if (lane == 0) {
+            sc->eig_mw_fail = 1;
+            sc->eigen_done = 0;       // (the products that follow must not run on what is half there)
+        }
         return;
     }
     if (istop > 1) {

@@ -393,6 +393,48 @@ def test_spread_reduction_runs_generation_after_generation(hip):
         np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-7)
 
 
+def test_spread_reduction_survives_a_partner_that_never_publishes(hip):
+    """The workgroups of the spread reduction wait for each other; every wait is bounded.  With
+    diagnostic bit 1073741824 one of the eight walks away at the start: the others must give up
+    (about a second), raise the sticky flag, the tail must not run on the partial block (that
+    generation keeps its basis, like a generation the lazy schedule skips), the host must stop
+    using the path at its next poll, and the decompositions that follow -- on one workgroup --
+    are right again."""
+    from bboptpy_amd import _ffi
+    n = 200
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(n, 3 * n))
+    Cm = X @ X.T / (3 * n)
+    Cm = 0.5 * (Cm + Cm.T)
+    g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
+    g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
+    # a good decomposition first (of another matrix), so that there is a basis to lose
+    g.set_state("C", np.diag(np.linspace(1., 2., n)) + 1e-3 * Cm)
+    g.set_state("fev", [10 ** 6])
+    g.set_state("eigenlastev", [0])
+    g.phase(_ffi.PHASE_EIGEN)
+    assert int(g.get_state("eigen_done")[0]) == 1 and int(g.get_state("eig_mw_fail")[0]) == 0
+    g.set_state("dbg", [float(1073741824)])
+    g.set_state("C", Cm)
+    g.set_state("fev", [2 * 10 ** 6])
+    g.set_state("eigenlastev", [0])
+    B0 = g.get_state("B").reshape(n, n).copy()
+    g.phase(_ffi.PHASE_EIGEN)
+    assert int(g.get_state("eig_mw_fail")[0]) == 1
+    assert int(g.get_state("eigen_done")[0]) == 0          # no decomposition this time ...
+    np.testing.assert_array_equal(g.get_state("B").reshape(n, n), B0)      # ... and the basis untouched
+    g.run(1)                                              # a generation: its poll sees the flag
+    assert int(g.get_state("eig_mw_off")[0]) == 1
+    g.set_state("C", Cm)
+    g.set_state("fev", [4 * 10 ** 6])
+    g.set_state("eigenlastev", [0])
+    g.phase(_ffi.PHASE_EIGEN)
+    assert int(g.get_state("eigen_done")[0]) == 1
+    B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+    assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n
+    assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm)
+
+
 @pytest.mark.parametrize("n", [10, 16, 40, 128, 200, 256, 300, 512])
 def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     """The QL leaves stop after 30 sweeps per eigenvalue (ql_produce_reg), so a covariance with
