@@ -9,6 +9,7 @@
 #include "bbo_eig_mw.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 
@@ -543,6 +544,12 @@ void CmaEngine::launch_update()
     }
 }
 
+int CmaEngine::next_mw_xcd()
+{
+    static std::atomic<int> counter { 0 };
+    return counter.fetch_add(1) & 7;
+}
+
 void CmaEngine::launch_eigen()
 {
     const CmaConst &c = c_;
@@ -589,7 +596,7 @@ void CmaEngine::launch_eigen()
             // bit 536870912 keeps all steps spread)
             const int istop = (d_.dbg & 536870912) ? 1 : 128;
             hipLaunchKernelGGL(cma_tred_mw, dim3(8 * MW_G, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
-                    mw_buf_.p, ++mw_launch_, istop);
+                    mw_buf_.p, ++mw_launch_, istop, mw_xcd_);
             if (istop > 1) {
                 allow_lds((const void*) cma_tred_tail, 160 * 1024 - 768);
                 hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl);

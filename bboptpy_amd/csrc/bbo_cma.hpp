@@ -139,6 +139,8 @@ private:
     DevBuf<double> mw_buf_;
     unsigned long long mw_launch_ = 0;
     bool mw_disabled_ = false;
+    int mw_xcd_ = next_mw_xcd();        // this engine's offset into the XCDs
+    static int next_mw_xcd();
     bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;

@@ -38,7 +38,8 @@
 // few of them a step makes.
 //
 // Same-XCD placement: workgroups are dealt to the 8 XCDs round-robin by their linear index; the
-// grid is (8 MW_G, P) and only the blocks with blockIdx.x % 8 == p % 8 work, the others return.
+// grid is (8 MW_G, P) and only the blocks with blockIdx.x % 8 == (p + xcd0) % 8 work, the others
+// return (xcd0: per engine, so that engines sharing a GPU do not all sit on XCD 0).
 //
 // Every spin is bounded (MW_SPIN polls, ~1 s): on a time-out the workgroup raises the sticky
 // CmaScal::eig_mw_fail, skips the hand-over (eig_stage stays 0: this generation keeps its basis,
@@ -101,11 +102,17 @@ __device__ inline double mw_row8_sum(double v)
 // istop: the last pivot row this kernel takes (1: the whole reduction; 128: the leading 128 x 128
 // block, updated, goes to eig_work[0] (row stride 128) and cma_tred_tail finishes it on one
 // workgroup, whose steps cost 1.15 us where the steps here cost 2.8)
+// xcd0: the engine's offset into the XCDs (engines that share a GPU start at different ones).
+// (277 registers per lane: ONE workgroup per CU.  Capped at 256 for two -- __launch_bounds__(MW_T,
+// 2), 3 spilled -- the decomposition took 867 instead of 835 us, and with u's column copy read
+// again from LDS instead of held, 888: the speed of one matrix was kept.  A launch therefore needs
+// a free CU per workgroup; engines that share a GPU start on different XCDs, and whoever does not
+// get its partners in time falls back, see above.)
 __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int force, double *mwbuf,
-        unsigned long long launch, int istop)
+        unsigned long long launch, int istop, int xcd0)
 {
     const int p = blockIdx.y;
-    if ((int) (blockIdx.x & 7) != (p & 7)) return;
+    if ((int) (blockIdx.x & 7) != ((p + xcd0) & 7)) return;
     const int g = blockIdx.x >> 3;
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
