@@ -561,6 +561,9 @@ void CmaEngine::launch_eigen()
     allow_lds((const void*) cma_eigen_256, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_128, 160 * 1024 - 768);
     timer_.begin(stream_, K_EIGEN);
+    // (256 < n <= 512 by the spread reduction: while its 16 workgroups per matrix fit the chip at once)
+    const bool big_spread = c.n > 256 && pl.dc && !pl.hybrid && !mw_disabled_
+            && !(d_.dbg & (2 | 16777216)) && (long) c.npop * 16 <= 256;
     // n <= 16: a wavefront per matrix (dbg bit 4 keeps the big kernel)
     const bool small = c.n <= 16 && c.n >= 2 && c.ld == 16 && !(d_.dbg & 16);
     if (small)    // (does cma_post's work too: one launch less where launches are what costs)
@@ -616,7 +619,20 @@ void CmaEngine::launch_eigen()
     } else if (pl.hybrid)
         hipLaunchKernelGGL(cma_eigen_g, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
-    else
+    else if (big_spread) {
+        // 256 < n <= 512, few matrices: the structure of 128 < n <= 256 -- the reduction's first
+        // n - 128 steps spread over 16 workgroups (cma_tred_mw512), the leading block on one
+        // (cma_tred_tail), the reflectors stashed -- in front of the same divide and conquer
+        const size_t need = (size_t) c.npop * mw_buf_doubles(512);
+        if (mw_buf_.count != need) mw_buf_.alloc(need);
+        hipLaunchKernelGGL(cma_tred_mw512, dim3(8 * 16, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
+                mw_buf_.p, ++mw_launch_, 128, mw_xcd_);
+        const EigPlan plt = eig_plan(256, 256);        // (the tail's LDS: vectors + a 128 x 130 matrix)
+        allow_lds((const void*) cma_tred_tail, 160 * 1024 - 768);
+        hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), plt.lds_bytes, stream_, d_, c_, plt);
+        allow_lds((const void*) cma_eigen_b4, 160 * 1024 - 768);
+        hipLaunchKernelGGL(cma_eigen_b4, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
+    } else
         hipLaunchKernelGGL(cma_eigen_b, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_,
                 pl, 0);
     timer_.end(stream_);
@@ -633,7 +649,9 @@ void CmaEngine::launch_eigen()
             hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 0);
         // second product: the stashed reflectors applied in blocked form (the QL fallback of
         // the diagnostic switch has accumulated Q_house instead)
-        if ((d_.dbg & 2) || !pl.hybrid)     // (n > 256: Q_house was accumulated by the reduction)
+        if (big_spread)
+            hipLaunchKernelGGL(cma_eig_wy4_512, dim3((c.n + 15) / 16, c.npop), dim3(256), 0, stream_, d_, c_);
+        else if ((d_.dbg & 2) || !pl.hybrid)     // (n > 256: Q_house was accumulated by the reduction)
             hipLaunchKernelGGL(cma_eig_gemm, grid, dim3(256), 0, stream_, d_, c_, pl.lda, 1);
         else
         {

@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     const int p = blockIdx.x;
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
-    if (STAGE == 2) {
+    if (STAGE == 2 || STAGE == 4) {
         if (sc->eig_stage != 1) return;
     } else if (STAGE == 3) {
         // (cma_tred_mw made the decision and did -- or did not -- its part: checked below)
@@ -1162,9 +1162,12 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         if (tid == 0) sc->eig_stage = 1;
         return;
     }
-    if (STAGE == 2) {
+    if (STAGE == 2 || STAGE == 4) {
+        // (STAGE 4, 256 < n <= 512: the tridiagonal matrix itself -- the reduction ran as
+        // cma_tred_mw512 + cma_tred_tail and left its reflectors stashed; tri lies where the merges'
+        // scratch begins, so it is read before anything else)
         for (int i = tid; i < n; i += T) {
-            dv[i] = tri[3 * n + i];
+            dv[i] = STAGE == 2 ? tri[3 * n + i] : tri[i];
             ev[i] = tri[n + i];
             hvec[i] = tri[2 * n + i];
         }
@@ -1196,7 +1199,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         if (tid < n) ev[tid] = t;
     }
     __syncthreads();
-    }   // STAGE != 2
+    }   // STAGE != 2, 4
     EIG_STAMP(3);
     if (STAGE == 1) {
         for (int i = tid; i < n; i += T) {
@@ -1231,7 +1234,10 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             // 256 < n <= 512: the streaming reduction has accumulated Q_house, and
             // B = Q_house ((Q_1 (+) Q_2) F) is two cma_eig_gemm launches; merges the
             // register-resident product cannot hold go through the slab the first of them fills
-            eig_dc_phase<TT, true, true>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, 1, nullptr, false,
+            // (STAGE 4: stashed reflectors instead of an accumulated Q_house -- V is in its place,
+            // the panels' T factors are built behind the top merge, cma_eig_wy4_512 applies them)
+            eig_dc_phase<TT, true, true>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, 1,
+                    STAGE == 4 ? hvec : nullptr, STAGE == 4,
                     d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld));
         }
     } else
@@ -1367,6 +1373,13 @@ __global__ __launch_bounds__(512) void cma_eigen_b(CmaDev d, CmaConst c, EigPlan
 __global__ __launch_bounds__(512) void cma_eigen_g1(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
     cma_eigen_impl<512, false, 1, 1>(d, c, pl, force);
+}
+// 256 < n <= 512 behind a spread reduction (cma_tred_mw512 + cma_tred_tail): the divide and conquer
+// on the tridiagonal matrix they left, reflectors stashed (the top merge's products follow as
+// cma_eig_gemm and cma_eig_wy4_512)
+__global__ __launch_bounds__(512) void cma_eigen_b4(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, false, 0, 4>(d, c, pl, force);
 }
 // the tail of a reduction that cma_tred_mw began (the leading 128 x 128 block on one workgroup)
 __global__ __launch_bounds__(512) void cma_tred_tail(CmaDev d, CmaConst c, EigPlan pl)
@@ -1656,13 +1669,17 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
 // not depend on timing), every wavefront forms T_b^T W itself and updates its own row tiles.
 // Per panel 36 MFMAs per wavefront instead of 132, two barriers (the panels alternate between two
 // LDS buffers).  grid (ceil(n / 16), P), 256 threads
-__global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
+template<int NMAX>
+__device__ __forceinline__ void eig_wy4_body(const CmaDev &d, const CmaConst &c)
 {
+    constexpr int NRT = NMAX / 64;          // row tiles per wavefront
+    constexpr int CPT = NMAX / 256;         // columns of a staged panel per thread
+    constexpr int LDV = NMAX + 4;
     const int p = blockIdx.y;
     const CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
     if (!sc->eigen_done) return;
-    __shared__ __attribute__((aligned(16))) double Vp[2][16 * WY_LDV];
+    __shared__ __attribute__((aligned(16))) double Vp[2][16 * LDV];
     __shared__ __attribute__((aligned(16))) double wpart[4][256];
     const int n = c.n, ld = c.ld;
     const size_t slab = eig_slab(ld);
@@ -1677,24 +1694,33 @@ __global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
     const int npanel = (n + 15) >> 4;
     const int col = blockIdx.x * 16 + fr;
     // this wavefront's row tiles: rt = wave + 4 j
-    d4_eig q[4];
+    d4_eig q[NRT];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NRT; j++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * (wave + 4 * j) + fk + 4 * r;
             q[j][r] = (row < n && col < n) ? M[(size_t) row * n + col] : 0.;
         }
-    double pre[16];
+    double pre[16 * CPT];
     auto fetch = [&](int b) {
         const int i0 = 16 * b, reach = min(n, i0 + 16);
 #pragma unroll
         for (int u = 0; u < 16; u++)
-            pre[u] = (i0 + u < n && tid < reach) ? V[(size_t) (i0 + u) * n + tid] : 0.;
+#pragma unroll
+            for (int e = 0; e < CPT; e++) {
+                const int k = tid + 256 * e;
+                pre[CPT * u + e] = (i0 + u < n && k < reach) ? V[(size_t) (i0 + u) * n + k] : 0.;
+            }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) Vp[buf][u * LDV + tid + 256 * e] = pre[CPT * u + e];
     };
     fetch(0);
-#pragma unroll
-    for (int u = 0; u < 16; u++) Vp[0][u * WY_LDV + tid] = pre[u];
+    stage(0);
     if (npanel > 1) fetch(1);
     __syncthreads();
     for (int b = 0; b < npanel; b++) {
@@ -1709,18 +1735,17 @@ __global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
         // the next panel goes to the other buffer (its last readers passed the barrier at the end of
         // panel b - 1), the one after it starts its way from L2
         if (b + 1 < npanel) {
-#pragma unroll
-            for (int u = 0; u < 16; u++) Vp[(b + 1) & 1][u * WY_LDV + tid] = pre[u];
+            stage((b + 1) & 1);
             if (b + 2 < npanel) fetch(b + 2);
         }
         d4_eig w = { 0., 0., 0., 0. };
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NRT; j++) {
             const int rt = wave + 4 * j;
             if (16 * rt < reach) {
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Vb[fr * WY_LDV + 16 * rt + 4 * r + fk],
+                    w = __builtin_amdgcn_mfma_f64_16x16x4f64(Vb[fr * LDV + 16 * rt + 4 * r + fk],
                             q[j][r], w, 0, 0, 0);
             }
         }
@@ -1736,24 +1761,34 @@ __global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
         for (int ks = 0; ks < 4; ks++)
             w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[ks], w[ks], w2, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NRT; j++) {
             const int rt = wave + 4 * j;
             if (16 * rt < reach) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++)
                     q[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                            -Vb[(4 * ks + fk) * WY_LDV + 16 * rt + fr], w2[ks], q[j], 0, 0, 0);
+                            -Vb[(4 * ks + fk) * LDV + 16 * rt + fr], w2[ks], q[j], 0, 0, 0);
             }
         }
         __syncthreads();      // wpart and this panel's buffer are free again; the next panel is staged
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NRT; j++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * (wave + 4 * j) + fk + 4 * r;
             if (row < n && col < n) Bp[(size_t) row * ld + col] = q[j][r];
         }
+}
+
+__global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
+{
+    eig_wy4_body<256>(d, c);
+}
+// 256 < n <= 512 (reflectors stashed by cma_tred_mw512 / cma_tred_tail): eight row tiles per wavefront
+__global__ __launch_bounds__(256) void cma_eig_wy4_512(CmaDev d, CmaConst c)
+{
+    eig_wy4_body<512>(d, c);
 }
 
 // ---------------------------------------------------------------------------

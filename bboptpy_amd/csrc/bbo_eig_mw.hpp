@@ -55,7 +55,7 @@
 
 namespace bbo {
 
-constexpr int MW_G = 8;                 // workgroups per matrix
+constexpr int MW_G = 8;                 // workgroups per matrix of n <= 256 (NMAX / 32 in general: 16 to n = 512)
 constexpr int MW_T = 256;               // threads per workgroup: 32 rows x 8 lanes
 constexpr int MW_SPIN = 1 << 21;
 constexpr int MW_WAVES = MW_T / 64;
@@ -64,7 +64,9 @@ constexpr int MW_WAVES = MW_T / 64;
 #endif
 constexpr int MW_FLAG_STRIDE = 16;      // 64-bit words between two flags (128 bytes: side by side, the polls of 32
                                         // wavefronts and the flag stores queue up on one channel -- measured, +40 %)
-constexpr int MW_BUF_DOUBLES = MW_G * MW_FLAG_STRIDE + 2 * 256 + 2 * 256;   // per population: flags | e[2][256] | row[2][256]
+// per population: flags | e[2][NMAX] | row[2][NMAX]
+constexpr int mw_buf_doubles(int nmax) { return (nmax / 32) * MW_FLAG_STRIDE + 4 * nmax; }
+constexpr int MW_BUF_DOUBLES = mw_buf_doubles(256);
 
 __device__ inline unsigned long long mw_load(const void *p)
 {
@@ -80,12 +82,28 @@ __device__ inline double mw_load_d(const double *p) { return __longlong_as_doubl
 __device__ inline void mw_store_d(double *p, double v) { mw_store(p, (unsigned long long) __double_as_longlong(v)); }
 
 // entry `idx` (wavefront-uniform) of a vector held four entries per lane (entry lane + 64 v)
-__device__ inline double mw_entry(const double (&x)[4], int idx)
+template<int NV>
+__device__ inline double mw_entry(const double (&x)[NV], int idx)
 {
     const int l = idx & 63, v = idx >> 6;
-    const double e0 = eig_readlane(x[0], l), e1 = eig_readlane(x[1], l), e2 = eig_readlane(x[2], l),
-            e3 = eig_readlane(x[3], l);
-    return v == 0 ? e0 : v == 1 ? e1 : v == 2 ? e2 : e3;
+    double e = eig_readlane(x[0], l);
+#pragma unroll
+    for (int u = 1; u < NV; u++) {
+        const double eu = eig_readlane(x[u], l);
+        e = v == u ? eu : e;
+    }
+    return e;
+}
+
+// sum_v x_v y_v over a lane's entries, four at a time in the association ((0 + 1) + (2 + 3))
+template<int NV>
+__device__ inline double mw_dot(const double (&x)[NV], const double (&y)[NV])
+{
+    double s = (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+#pragma unroll
+    for (int u = 4; u < NV; u += 4)
+        s += (x[u] * y[u] + x[u + 1] * y[u + 1]) + (x[u + 2] * y[u + 2] + x[u + 3] * y[u + 3]);
+    return s;
 }
 
 // sum over the 8 lanes of a row (two quads of one half of a DPP row): quad butterfly, then the
@@ -108,9 +126,11 @@ __device__ inline double mw_row8_sum(double v)
 // again from LDS instead of held, 888: the speed of one matrix was kept.  A launch therefore needs
 // a free CU per workgroup; engines that share a GPU start on different XCDs, and whoever does not
 // get its partners in time falls back, see above.)
-__global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int force, double *mwbuf,
+template<int NMAX>
+__device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c, int force, double *mwbuf,
         unsigned long long launch, int istop, int xcd0)
 {
+    constexpr int G = NMAX / 32, NT = NMAX / 16, NV = NMAX / 64;
     const int p = blockIdx.y;
     if ((int) (blockIdx.x & 7) != ((p + xcd0) & 7)) return;
     const int g = blockIdx.x >> 3;
@@ -131,8 +151,8 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
     // (diagnostic bit 1073741824: one of the workgroups walks away -- what the others do about a
     // partner that never publishes is tested, not assumed: tests/test_cma_gpu.py)
     if ((d.dbg & 1073741824) && g == 3) return;
-    __shared__ __attribute__((aligned(16))) double ubuf[4][256];
-    __shared__ __attribute__((aligned(16))) double wbuf[4][256];
+    __shared__ __attribute__((aligned(16))) double ubuf[4][NMAX];
+    __shared__ __attribute__((aligned(16))) double wbuf[4][NMAX];
     __shared__ unsigned arrived;          // wavefronts that have published, over all steps so far
     if (tid == 0) arrived = 0u;
     __syncthreads();
@@ -140,25 +160,25 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
     const double *C = d.C + (size_t) p * ld * ld;
     double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld);
     double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
-    double *mb = mwbuf + (size_t) p * MW_BUF_DOUBLES;
+    double *mb = mwbuf + (size_t) p * mw_buf_doubles(NMAX);
     unsigned long long *flags = reinterpret_cast<unsigned long long*>(mb);
-    double *ebuf = mb + MW_G * MW_FLAG_STRIDE;          // [2][256], entry of row r at (r % MW_G) * 32 + r / MW_G
-    double *rbuf = ebuf + 2 * 256;                      // [2][256]
+    double *ebuf = mb + G * MW_FLAG_STRIDE;             // [2][NMAX], entry of row r at (r % G) * 32 + r / G
+    double *rbuf = ebuf + 2 * NMAX;                     // [2][NMAX]
 
     // this thread's row and columns
     const int q = 8 * wave + (lane >> 3), s = lane & 7;
-    const int r = MW_G * q + g;
-    double2 a2[16];
+    const int r = G * q + g;
+    double2 a2[NT];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < NT; t++) {
         const int col = 16 * t + 2 * s;
         a2[t].x = (r < n && col < n) ? C[(size_t) r * ld + col] : 0.;
         a2[t].y = (r < n && col + 1 < n) ? C[(size_t) r * ld + col + 1] : 0.;
     }
     // the pivot row of the first step, four entries per lane (zero from the pivot column on)
-    double av[4];
+    double av[NV];
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < NV; v++) {
         const int idx = lane + 64 * v;
         av[v] = idx < n - 1 ? C[(size_t) (n - 1) * ld + idx] : 0.;
     }
@@ -182,10 +202,10 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
 #endif
 
     for (int i = n - 1; i >= istop && !failed; i--) {
-        const unsigned long long epoch = launch * 512ull + (unsigned long long) (n - i);
+        const unsigned long long epoch = launch * 1024ull + (unsigned long long) (n - i);
         const int par = i & 1;
         // ---- the reflector of this step, by every wavefront ------------------------------------
-        const double h0 = eig_wave_sum_bf((av[0] * av[0] + av[1] * av[1]) + (av[2] * av[2] + av[3] * av[3]));
+        const double h0 = eig_wave_sum_bf(mw_dot<NV>(av, av));
         const double f = mw_entry(av, i - 1);
         const bool none = h0 == 0.;
         double gg = 0.;
@@ -199,9 +219,9 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         }
         const double h = none ? 0. : h0 - f * gg;
         const double rh = none ? 0. : dc_rcp(h);
-        double uvv[4];
+        double uvv[NV];
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < NV; v++) {
             const int idx = lane + 64 * v;
             uvv[v] = (idx < i && !none) ? (idx == i - 1 ? f - gg : av[v]) : 0.;
             ub[idx] = uvv[v];
@@ -209,29 +229,29 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         dc_wave_sync();
         MW_CK(0);
         // ---- p = A u for this thread's row; its piece of e = p / h goes out ----------------------
-        double2 uc[16];
+        double2 uc[NT];
         double acc0 = 0., acc1 = 0.;
 #pragma unroll
-        for (int t = 0; t < 16; t++) uc[t] = *reinterpret_cast<const double2*>(&ub[16 * t + 2 * s]);
+        for (int t = 0; t < NT; t++) uc[t] = *reinterpret_cast<const double2*>(&ub[16 * t + 2 * s]);
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
+        for (int t = 0; t < NT; t++) {
             acc0 = __builtin_fma(a2[t].x, uc[t].x, acc0);
             acc1 = __builtin_fma(a2[t].y, uc[t].y, acc1);
         }
         const double pr = mw_row8_sum(acc0 + acc1);
         // (a wavefront's eight entries lie side by side: one 64-byte piece per wavefront)
-        if (s == 0 && r < n) mw_store_d(ebuf + 256 * par + 32 * g + q, r < i ? pr * rh : 0.);
+        if (s == 0 && r < n) mw_store_d(ebuf + NMAX * par + 32 * g + q, r < i ? pr * rh : 0.);
         // the row that becomes the next pivot, as it stands (its owner: row i - 1) -- turned into
         // the four-entries-per-lane layout through this wavefront's w buffer (free here), so that
         // it leaves as four 512-byte stores, not 64 scattered ones
-        if ((i - 1) % MW_G == g && ((i - 1) / MW_G) >> 3 == wave) {
+        if ((i - 1) % G == g && ((i - 1) / G) >> 3 == wave) {
             if (r == i - 1) {
 #pragma unroll
-                for (int t = 0; t < 16; t++) *reinterpret_cast<double2*>(&wb[16 * t + 2 * s]) = a2[t];
+                for (int t = 0; t < NT; t++) *reinterpret_cast<double2*>(&wb[16 * t + 2 * s]) = a2[t];
             }
             dc_wave_sync();
 #pragma unroll
-            for (int v = 0; v < 4; v++) mw_store_d(rbuf + 256 * par + lane + 64 * v, wb[lane + 64 * v]);
+            for (int v = 0; v < NV; v++) mw_store_d(rbuf + NMAX * par + lane + 64 * v, wb[lane + 64 * v]);
         }
         __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores are out (and its loads of
                                                 // the step before: the buffers alternate)
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         {
             int spins = 0;
             while (true) {
-                const unsigned long long fl = lane < MW_G ? mw_load(flags + MW_FLAG_STRIDE * lane) : epoch;
+                const unsigned long long fl = lane < G ? mw_load(flags + MW_FLAG_STRIDE * lane) : epoch;
                 if (__ballot(fl < epoch) == 0ull) break;
                 if (++spins >= MW_SPIN) {
                     failed = true;
@@ -260,20 +280,19 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         // (only the lanes inside the active block ask: measured against eight unconditional loads
         // per lane, 1071 against 1170 us per decomposition -- the requests are served on the memory
         // side, and fewer of them come back sooner)
-        double ev_[4], ro[4];
+        double ev_[NV], ro[NV];
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < NV; v++) {
             const int idx = lane + 64 * v;
-            ev_[v] = idx < i ? mw_load_d(ebuf + 256 * par + 32 * (idx % MW_G) + idx / MW_G) : 0.;
-            ro[v] = idx < i ? mw_load_d(rbuf + 256 * par + idx) : 0.;
+            ev_[v] = idx < i ? mw_load_d(ebuf + NMAX * par + 32 * (idx % G) + idx / G) : 0.;
+            ro[v] = idx < i ? mw_load_d(rbuf + NMAX * par + idx) : 0.;
         }
         MW_CK(3);
         // ---- w = e - (u^T e / 2h) u ----------------------------------------------------------------
-        const double hh = eig_wave_sum_bf((ev_[0] * uvv[0] + ev_[1] * uvv[1]) + (ev_[2] * uvv[2] + ev_[3] * uvv[3]))
-                * (0.5 * rh);
-        double wvv[4];
+        const double hh = eig_wave_sum_bf(mw_dot<NV>(ev_, uvv)) * (0.5 * rh);
+        double wvv[NV];
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < NV; v++) {
             const int idx = lane + 64 * v;
             wvv[v] = idx < i ? ev_[v] - hh * uvv[v] : 0.;
             wb[idx] = wvv[v];
@@ -281,10 +300,10 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         dc_wave_sync();
         // ---- A -= u w^T + w u^T on this thread's row (rows and columns >= i see zeros) -------------
         {
-            const int rc = r < 256 ? r : 0;
+            const int rc = r < NMAX ? r : 0;
             const double ur = r < n ? ub[rc] : 0., wr = r < n ? wb[rc] : 0.;
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
+            for (int t = 0; t < NT; t++) {
                 const double2 wc = *reinterpret_cast<const double2*>(&wb[16 * t + 2 * s]);
                 a2[t].x -= ur * wc.x + wr * uc[t].x;
                 a2[t].y -= ur * wc.y + wr * uc[t].y;
@@ -293,9 +312,9 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         MW_CK(4);
         // ---- the next pivot row, by every wavefront: row' = row - u_{i-1} w - w_{i-1} u ------------
         const double um = none ? 0. : f - gg, wm = mw_entry(wvv, i - 1);
-        double an[4];
+        double an[NV];
 #pragma unroll
-        for (int v = 0; v < 4; v++) an[v] = ro[v] - (um * wvv[v] + wm * uvv[v]);
+        for (int v = 0; v < NV; v++) an[v] = ro[v] - (um * wvv[v] + wm * uvv[v]);
         // ---- what this step leaves behind ------------------------------------------------------------
         if (recorder) {
             if (lane == 0) {
@@ -303,14 +322,14 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
                 tri[2 * n + i] = h;
             }
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int v = 0; v < NV; v++) {
                 const int idx = lane + 64 * v;
                 if (idx < n) Vout[(size_t) i * n + idx] = uvv[v];
                 if (idx == i - 1) tri[i - 1] = an[v];           // diagonal entry of row i - 1: final
             }
         }
 #pragma unroll
-        for (int v = 0; v < 4; v++) av[v] = lane + 64 * v < i - 1 ? an[v] : 0.;
+        for (int v = 0; v < NV; v++) av[v] = lane + 64 * v < i - 1 ? an[v] : 0.;
         // (ub / wb are this wavefront's own: the next step's writes follow this step's reads in
         // program order)
         dc_wave_sync();
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(ld);
         if (r < istop) {
 #pragma unroll
-            for (int t = 0; t < 16; t++)
+            for (int t = 0; t < NT; t++)
                 if (16 * t + 2 * s < istop)
                     *reinterpret_cast<double2*>(&L11[(size_t) r * istop + 16 * t + 2 * s]) = a2[t];
         }
@@ -341,6 +360,18 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         return;
     }
     if (g == 0 && tid == 0) sc->eig_stage = 1;
+}
+
+__global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int force, double *mwbuf,
+        unsigned long long launch, int istop, int xcd0)
+{
+    tred_mw_body<256>(d, c, force, mwbuf, launch, istop, xcd0);
+}
+// 256 < n <= 512: 16 workgroups, 64 entries of a row per thread (grid (8 * 16, P))
+__global__ __launch_bounds__(MW_T) void cma_tred_mw512(CmaDev d, CmaConst c, int force, double *mwbuf,
+        unsigned long long launch, int istop, int xcd0)
+{
+    tred_mw_body<512>(d, c, force, mwbuf, launch, istop, xcd0);
 }
 
 } // namespace bbo
