@@ -435,6 +435,37 @@ def test_spread_reduction_survives_a_partner_that_never_publishes(hip):
     assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm)
 
 
+@pytest.mark.parametrize("n", [257, 300, 384, 512])
+def test_eigensolver_forms_above_256_agree(hip, n):
+    """256 < n <= 512: the default for few matrices -- reduction spread over 16 workgroups down to
+    the leading 128 x 128 block, that block on one, reflectors stashed and applied in blocked form
+    (cma_tred_mw512, cma_tred_tail, cma_eigen_b4, cma_eig_wy4_512) -- against the one-workgroup
+    streaming reduction with an accumulated Q_house (diagnostic bit 16777216): the same eigenvalues
+    to rounding, each form's own residual and orthogonality."""
+    from bboptpy_amd import _ffi
+    rng = np.random.default_rng(n)
+    for name, Cm in _spd_cases(n, rng):
+        Cm = 0.5 * (Cm + Cm.T)
+        sc = np.abs(np.linalg.eigvalsh(Cm)).max()
+        Ds = []
+        for bit in (0, 16777216):
+            g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
+            g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
+            if bit:
+                g.set_state("dbg", [float(bit)])
+            g.set_state("C", Cm)
+            g.set_state("fev", [10 ** 6])
+            g.set_state("eigenlastev", [0])
+            g.phase(_ffi.PHASE_EIGEN)
+            assert int(g.get_state("eigen_done")[0]) == 1, (name, bit)
+            assert int(g.get_state("eig_mw_fail")[0]) == 0, (name, bit)
+            B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+            assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, bit)
+            assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm), (name, bit)
+            Ds.append(D * D)
+        assert np.abs(Ds[0] - Ds[1]).max() <= 1e-12 * sc, name
+
+
 @pytest.mark.parametrize("n", [10, 16, 40, 128, 200, 256, 300, 512])
 def test_eigensolver_terminates_on_non_finite_and_subnormal_input(hip, n):
     """The QL leaves stop after 30 sweeps per eigenvalue (ql_produce_reg), so a covariance with
