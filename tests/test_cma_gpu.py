@@ -435,6 +435,40 @@ def test_spread_reduction_survives_a_partner_that_never_publishes(hip):
     assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm)
 
 
+@pytest.mark.parametrize("n,P", [(144, 20), (256, 9), (300, 5)])
+def test_spread_reduction_with_many_populations(hip, n, P):
+    """several matrices per launch (their workgroup groups sit on XCD (p + offset) mod 8: more than
+    eight populations wrap around): every population's decomposition of ITS covariance against the
+    same handle run with the reduction on one workgroup"""
+    from bboptpy_amd import _ffi
+    rng = np.random.default_rng(n + P)
+    Cs = []
+    for p in range(P):
+        X = rng.normal(size=(n, 2 * n)) * np.logspace(0, -2 - p % 3, n)[:, None]
+        Cs.append(X @ X.T / (2 * n) + 1e-6 * np.eye(n))
+    out = []
+    for bit in (0, 16777216):
+        g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1, populations=P)
+        g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros((P, n)))
+        if bit:
+            g.set_state("dbg", [float(bit)])
+        for p in range(P):
+            g.set_state("C", Cs[p], p)
+            g.set_state("fev", [10 ** 6], p)
+            g.set_state("eigenlastev", [0], p)
+        g.phase(_ffi.PHASE_EIGEN)
+        res = []
+        for p in range(P):
+            assert int(g.get_state("eigen_done", p)[0]) == 1 and int(g.get_state("eig_mw_fail", p)[0]) == 0
+            B, D = g.get_state("B", p).reshape(n, n), g.get_state("D", p)
+            assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, p
+            assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cs[p]) <= 1e-11 * np.linalg.norm(Cs[p]), p
+            res.append(D * D)
+        out.append(res)
+    for p in range(P):
+        assert np.abs(out[0][p] - out[1][p]).max() <= 1e-12 * out[1][p].max(), p
+
+
 @pytest.mark.parametrize("n", [257, 300, 384, 512])
 def test_eigensolver_forms_above_256_agree(hip, n):
     """256 < n <= 512: the default for few matrices -- reduction spread over 16 workgroups down to
