@@ -15,7 +15,7 @@
 // w (row' = row - u_{i-1} w - w_{i-1} u: three vector operations on four entries per lane).  ONE
 // exchange per step: every wavefront stores its piece with relaxed agent-scope atomics and waits for
 // the stores; the last one of a workgroup to do so raises the workgroup's flag (a monotone epoch:
-// launch * 512 + step; an LDS arrival count, no barrier); every wavefront polls the MW_G flags and
+// launch * 1024 + step; an LDS arrival count, no barrier); every wavefront polls the MW_G flags and
 // then loads the vectors -- no fence, no cache invalidate.  Measured (scripts/hiptests/
 // allgather.hip, pingpong.hip): 1.05 us per such exchange with the workgroups on ONE XCD, 1.7 us
 // on eight; a release / acquire pair costs 2.2 us one way.  All O(n) vector work (norm, root, u,
@@ -24,13 +24,18 @@
 // wavefront's own copy).  There is NO workgroup barrier in a step: wavefronts never wait for each
 // other inside a workgroup, so one that gives up (below) cannot leave the others at a barrier.
 //
-// What it buys (round 4, n = 256, one matrix): a step takes ~2.8 us -- ~1.3 us of it the
+// What it buys (round 4, one matrix).  A spread step takes ~2.8 us at n <= 256 -- ~1.3 us of it the
 // wavefront's own chain (two wavefront reductions, root and reciprocal, two LDS hand-overs, 96
-// FMAs), the rest the exchange -- against 5.4 us (on-chip symmetric steps) and 1.15 us (register
-// tail) of the one-workgroup reduction: 0.71 against 0.82 ms, the decomposition 1.10 against
-// 1.18 ms (+- 4 % from run to run: the exchange is at the mercy of the memory side).  The floor
-// of this design is the exchange: 255 x 1.05 us.  Tried on top and slower, each measured: the
-// flags side by side in one 256-byte line (1.59 ms: 32 pollers and 8 writers on one channel);
+// FMAs), the rest the exchange -- whatever the size of the active block; the one-workgroup steps
+// cost 5.4 us with the whole active matrix on chip (n = 256) and 1.15 us once it is 128 x 128 and
+// lives in registers.  With ALL steps spread the n = 256 decomposition took 1.10 against 1.18 ms
+// (and lost below n = 240).  Hence istop: the spread steps stop at the leading 128 x 128 block,
+// which goes to ONE workgroup (cma_tred_tail, the register-resident reduction): 0.83 against
+// 1.04 ms at n = 256, ahead for every n > 128.  For 256 < n <= 512 (16 workgroups, rows of 512
+// entries, 5.5 us per step) it replaces a one-workgroup reduction that streams the matrix from L2
+// and accumulates Q_house: 41 -> 5 ms at n = 512.  The floor of the design is the exchange,
+// (n - 128) x 1.05 us.  Tried on top and slower, each measured at n = 256 with all steps spread:
+// the flags side by side in one 256-byte line (1.59 ms: 32 pollers and 8 writers on one channel);
 // eight unconditional loads per lane instead of only the active block's (1.17); one wavefront
 // per workgroup polling and loading for all four through LDS and a barrier (1.19); every double
 // as two self-validating {half, tag} words, no flags and no wait for the stores (1.17: twice
