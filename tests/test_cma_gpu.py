@@ -336,13 +336,15 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
     matrix side by side on two workgroups, the top merge with its secular equation on eight more
     -- with the reduction on one workgroup (bit 16777216); the default, whose reduction runs its
     first n - 128 steps spread over eight workgroups that exchange a vector per step
-    (bbo_eig_mw.hpp) and hands the leading 128 x 128 block to one workgroup; and that with ALL
-    steps spread (bit 536870912).  Different leaf sizes and summation orders, so not the same bits:
+    (bbo_eig_mw.hpp) and hands the leading 128 x 128 block to one workgroup; that with ALL
+    steps spread (bit 536870912); and the kernels a launch of many matrices gets (reduction on one
+    workgroup, the top merge in one kernel, a column tile per wavefront in the reflector product).  Different leaf sizes and summation orders, so not the same bits:
     the same eigenvalues to rounding, and each form's own residual and orthogonality; the spread
     reduction must not have given up (its bounded waits)."""
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
-    forms = {"one workgroup": 4194304, "split": 16777216, "default": 0, "all steps spread": 536870912}
+    forms = {"one workgroup": 4194304, "split": 16777216, "default": 0, "all steps spread": 536870912,
+             "split, as for many matrices": 16777216 | 67108864 | 134217728}
     for name, Cm in _spd_cases(n, rng):
         Cm = 0.5 * (Cm + Cm.T)
         lam = np.linalg.eigvalsh(Cm)
@@ -363,7 +365,7 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
             assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, form)
             assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm), (name, form)
             Ds[form] = D * D
-        for form in ("split", "default", "all steps spread"):
+        for form in ("split", "default", "all steps spread", "split, as for many matrices"):
             assert np.abs(Ds[form] - Ds["one workgroup"]).max() <= 1e-12 * sc, (name, form)
 
 
