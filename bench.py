@@ -473,6 +473,16 @@ def bipop_leg(bb, world, rank, local_rank, use_dist, budget_per_rank, barrier=No
         barrier()
     if use_dist:
         dt = max_over_ranks(dt)
+    # the engines' own word on the multi-workgroup reduction (bbo_eig_mw.hpp): a wavefront that gave
+    # up waiting for its partners sends its engine back to the one-workgroup kernel
+    try:
+        algs = list(getattr(drv, "_algs", {}).values())
+        drv.state.spread_reduction = {
+            "engines": len(algs),
+            "gave_up": int(sum(int(a.get_state("eig_mw_fail")[0]) for a in algs)),
+            "switched_off": int(sum(int(a.get_state("eig_mw_off")[0]) for a in algs))}
+    except Exception:
+        drv.state.spread_reduction = None
     return drv.state, dt, budget
 
 
@@ -668,9 +678,10 @@ def main():
                  "n_gpus": world, "value": st.fev / bdt, "unit": "candidate-evals/s",
                  "wall_s": bdt, "rounds": st.round, "restarts": len(st.history),
                  "large_restarts": st.largerestarts, "small_restarts": st.smallrestarts,
-                 "evaluations": st.fev, "best_f": st.fxbest, "scaling": "weak"}
-        # the same with 8 concurrent restart populations PACKED on every GPU (an inner run keeps
-        # about one compute unit busy: the n = 256 eigensolver is one workgroup)
+                 "evaluations": st.fev, "best_f": st.fxbest, "scaling": "weak",
+                 "spread_reduction": getattr(st, "spread_reduction", None)}
+        # the same with 8 concurrent restart populations PACKED on every GPU (an inner run keeps a
+        # dozen compute units busy at most: the n = 256 eigensolver's widest kernel is 8 workgroups)
         st8, bdt8, _ = bipop_leg(bb, world, rank, local_rank, use_dist, C5_LEG_BUDGET, barrier,
                                  slots=8, tol=C5_LEG_TOL)
         bipop["packed_8_per_gpu"] = {"value": st8.fev / bdt8, "unit": "candidate-evals/s",
@@ -678,7 +689,8 @@ def main():
                                      "restarts": len(st8.history),
                                      "large_restarts": st8.largerestarts,
                                      "small_restarts": st8.smallrestarts,
-                                     "evaluations": st8.fev, "best_f": st8.fxbest}
+                                     "evaluations": st8.fev, "best_f": st8.fxbest,
+                                     "spread_reduction": getattr(st8, "spread_reduction", None)}
         if rank == 0 and world == 1:
             # what an inner run is made of (ActiveCMAES n = 256, lambda = lambda_def): per-kernel
             # device time and the roofline of its dominant kernel; and the reference's own
