@@ -206,32 +206,43 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
 #define MW_CK(k) do { } while (0)
 #endif
 
-    for (int i = n - 1; i >= istop && !failed; i--) {
-        const unsigned long long epoch = launch * 1024ull + (unsigned long long) (n - i);
-        const int par = i & 1;
-        // ---- the reflector of this step, by every wavefront ------------------------------------
-        const double h0 = eig_wave_sum_bf(mw_dot<NV>(av, av));
-        const double f = mw_entry(av, i - 1);
-        const bool none = h0 == 0.;
-        double gg = 0.;
-        if (!none) {
+    // the reflector of step i from its pivot row, by every wavefront: h, 1 / h, the corner value
+    // f, the root gg, u in the four-entries-per-lane layout.  Formed at the END of the step before
+    // (software-pipelined): its chain of dependent operations -- a wavefront reduction, a root, a
+    // reciprocal -- then shares the instruction stream with that step's rank-2 update, 64 independent
+    // FMAs, instead of standing alone in front of the product.
+    double f = 0., gg = 0., h = 0., rh = 0., uvv[NV];
+    bool none = true;
+    auto reflector = [&](int i, const double (&a)[NV], double &f_, double &gg_, double &h_, double &rh_,
+            bool &none_, double (&u)[NV]) {
+        const double h0 = eig_wave_sum_bf(mw_dot<NV>(a, a));
+        f_ = mw_entry(a, i - 1);
+        none_ = h0 == 0.;
+        gg_ = 0.;
+        if (!none_) {
             double y = __builtin_amdgcn_rsq(h0);
             const double err = fma(-h0 * y, y, 1.);
             y = fma(y * err, fma(err, 0.375, 0.5), y);
-            gg = h0 * y;
-            gg = fma(fma(-gg, gg, h0), 0.5 * y, gg);
-            if (f > 0) gg = -gg;
+            gg_ = h0 * y;
+            gg_ = fma(fma(-gg_, gg_, h0), 0.5 * y, gg_);
+            if (f_ > 0) gg_ = -gg_;
         }
-        const double h = none ? 0. : h0 - f * gg;
-        const double rh = none ? 0. : dc_rcp(h);
-        double uvv[NV];
+        h_ = none_ ? 0. : h0 - f_ * gg_;
+        rh_ = none_ ? 0. : dc_rcp(h_);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
             const int idx = lane + 64 * v;
-            uvv[v] = (idx < i && !none) ? (idx == i - 1 ? f - gg : av[v]) : 0.;
-            ub[idx] = uvv[v];
+            u[v] = (idx < i && !none_) ? (idx == i - 1 ? f_ - gg_ : a[v]) : 0.;
         }
-        dc_wave_sync();
+    };
+    reflector(n - 1, av, f, gg, h, rh, none, uvv);
+#pragma unroll
+    for (int v = 0; v < NV; v++) ub[lane + 64 * v] = uvv[v];
+    dc_wave_sync();
+
+    for (int i = n - 1; i >= istop && !failed; i--) {
+        const unsigned long long epoch = launch * 1024ull + (unsigned long long) (n - i);
+        const int par = i & 1;
         MW_CK(0);
         // ---- p = A u for this thread's row; its piece of e = p / h goes out ----------------------
         double2 uc[NT];
@@ -303,18 +314,6 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
             wb[idx] = wvv[v];
         }
         dc_wave_sync();
-        // ---- A -= u w^T + w u^T on this thread's row (rows and columns >= i see zeros) -------------
-        {
-            const int rc = r < NMAX ? r : 0;
-            const double ur = r < n ? ub[rc] : 0., wr = r < n ? wb[rc] : 0.;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const double2 wc = *reinterpret_cast<const double2*>(&wb[16 * t + 2 * s]);
-                a2[t].x -= ur * wc.x + wr * uc[t].x;
-                a2[t].y -= ur * wc.y + wr * uc[t].y;
-            }
-        }
-        MW_CK(4);
         // ---- the next pivot row, by every wavefront: row' = row - u_{i-1} w - w_{i-1} u ------------
         const double um = none ? 0. : f - gg, wm = mw_entry(wvv, i - 1);
         double an[NV];
@@ -335,8 +334,32 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) av[v] = lane + 64 * v < i - 1 ? an[v] : 0.;
-        // (ub / wb are this wavefront's own: the next step's writes follow this step's reads in
-        // program order)
+        // ---- the reflector of the NEXT step (its dependent chain runs under the update below) ----------
+        // (unconditionally -- behind a test it would be a basic block of its own and the scheduler
+        // could not mix it with the update; after the last step it is formed once for nothing)
+        double f2, gg2, h2, rh2, u2[NV];
+        bool none2;
+        reflector(max(i - 1, 1), av, f2, gg2, h2, rh2, none2, u2);
+        // ---- A -= u w^T + w u^T on this thread's row (rows and columns >= i see zeros) -------------
+        {
+            const int rc = r < NMAX ? r : 0;
+            const double ur = r < n ? ub[rc] : 0., wr = r < n ? wb[rc] : 0.;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const double2 wc = *reinterpret_cast<const double2*>(&wb[16 * t + 2 * s]);
+                a2[t].x -= ur * wc.x + wr * uc[t].x;
+                a2[t].y -= ur * wc.y + wr * uc[t].y;
+            }
+        }
+        MW_CK(4);
+        // (ub / wb are this wavefront's own: u of the next step replaces this step's, whose reads --
+        // u_r above, the columns in registers since the product -- precede the write in program order)
+        f = f2; gg = gg2; h = h2; rh = rh2; none = none2;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            uvv[v] = u2[v];
+            ub[lane + 64 * v] = u2[v];
+        }
         dc_wave_sync();
         MW_CK(5);
     }
