@@ -15,10 +15,14 @@ python3 - <<PY
 import csv, glob, collections
 for dbg in (12, 4, 8192, 16384, 0):
     f = glob.glob("$OUT/d%d/**/*counter_collection.csv" % dbg, recursive=True)
-    acc = collections.defaultdict(float); n = 0
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(f[0])):
         if row["Kernel_Name"].startswith("bbo::cma_eigen("):
-            acc[row["Counter_Name"]] += float(row["Counter_Value"])
-            n += row["Counter_Name"] == "SQ_INSTS_LDS"
-    print("dbg %6d: per launch of 256 matrices:" % dbg, {c: "%.4g" % (v / max(n, 1)) for c, v in sorted(acc.items())}, "launches", n)
+            per[int(row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
+    ids = sorted(per)[-4:]          # the four launches made under the diagnostic bits
+    acc = collections.defaultdict(float)
+    for i in ids:
+        for c, v in per[i].items():
+            acc[c] += v / len(ids)
+    print("bits %6d: " % dbg + "  ".join("%s %.4g" % (c, v) for c, v in sorted(acc.items())))
 PY
