@@ -602,7 +602,7 @@ void CmaEngine::launch_eigen()
                     mw_buf_.p, ++mw_launch_, istop, mw_xcd_);
             if (istop > 1) {
                 allow_lds((const void*) cma_tred_tail, 160 * 1024 - 768);
-                hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl);
+                hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
             }
         } else
         hipLaunchKernelGGL(cma_eigen_g1, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
@@ -623,13 +623,22 @@ void CmaEngine::launch_eigen()
         // 256 < n <= 512, few matrices: the structure of 128 < n <= 256 -- the reduction's first
         // n - 128 steps spread over 16 workgroups (cma_tred_mw512), the leading block on one
         // (cma_tred_tail), the reflectors stashed -- in front of the same divide and conquer
-        const size_t need = (size_t) c.npop * mw_buf_doubles(512);
+        // (two spread kernels: rows of 512 on 16 workgroups down to pivot row 256, 5.5 us per step,
+        // then rows of 256 on 8, 2.9 us per step -- each with exchange buffers of its own: a value
+        // one of them publishes must never sit where the other looks for a flag; diagnostic bit
+        // 536870912 keeps the first one down to row 128)
+        const bool chain = !(d_.dbg & 536870912);
+        const size_t need = (size_t) c.npop * (mw_buf_doubles(512) + mw_buf_doubles(256));
         if (mw_buf_.count != need) mw_buf_.alloc(need);
         hipLaunchKernelGGL(cma_tred_mw512, dim3(8 * 16, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
-                mw_buf_.p, ++mw_launch_, 128, mw_xcd_);
+                mw_buf_.p, ++mw_launch_, chain ? 256 : 128, mw_xcd_);
+        if (chain)
+            hipLaunchKernelGGL(cma_tred_mw_chain, dim3(8 * MW_G, c.npop), dim3(MW_T), 0, stream_, d_, c_,
+                    mw_buf_.p + (size_t) c.npop * mw_buf_doubles(512), ++mw_launch_, 128, mw_xcd_);
         const EigPlan plt = eig_plan(256, 256);        // (the tail's LDS: vectors + a 128 x 130 matrix)
         allow_lds((const void*) cma_tred_tail, 160 * 1024 - 768);
-        hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), plt.lds_bytes, stream_, d_, c_, plt);
+        hipLaunchKernelGGL(cma_tred_tail, dim3(c.npop), dim3(512), plt.lds_bytes, stream_, d_, c_, plt,
+                chain ? 1 : 0);
         allow_lds((const void*) cma_eigen_b4, 160 * 1024 - 768);
         hipLaunchKernelGGL(cma_eigen_b4, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
     } else

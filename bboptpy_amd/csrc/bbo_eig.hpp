@@ -1137,7 +1137,9 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         // the tail of a reduction cma_tred_mw began (bbo_eig_mw.hpp): the leading 128 x 128 block, as
         // the spread steps left it in eig_work[0], through the register-resident reduction; d, e, h of
         // rows < 128 and the reflectors' rows < 128 join what cma_tred_mw has written already
-        if (tri[4 * n + 1] != 1. || sc->eig_mw_fail) return;     // (it skipped this generation, or a wavefront gave up)
+        // (the hand-over flag: 1 behind one spread kernel, 2 behind two -- `force` says which; anything
+        // else: it skipped this generation, or a wavefront gave up)
+        if (tri[4 * n + 1] != (force ? 2. : 1.) || sc->eig_mw_fail) return;
         constexpr int LB = 130;
         EigMat Ast { reinterpret_cast<double*>(ibuf + 2 * EIG_MAXSEQ * 3 + 8), LB };
         const double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(ld);
@@ -1382,9 +1384,9 @@ __global__ __launch_bounds__(512) void cma_eigen_b4(CmaDev d, CmaConst c, EigPla
     cma_eigen_impl<512, false, 0, 4>(d, c, pl, force);
 }
 // the tail of a reduction that cma_tred_mw began (the leading 128 x 128 block on one workgroup)
-__global__ __launch_bounds__(512) void cma_tred_tail(CmaDev d, CmaConst c, EigPlan pl)
+__global__ __launch_bounds__(512) void cma_tred_tail(CmaDev d, CmaConst c, EigPlan pl, int chained)
 {
-    cma_eigen_impl<512, false, 1, 3>(d, c, pl, 0);
+    cma_eigen_impl<512, false, 1, 3>(d, c, pl, chained);
 }
 // (`part`: 0 = the whole top merge; 1 = up to the secular equation, 2 = from behind it, with
 // cma_eig_secular in between)

@@ -131,10 +131,17 @@ __device__ inline double mw_row8_sum(double v)
 // again from LDS instead of held, 888: the speed of one matrix was kept.  A launch therefore needs
 // a free CU per workgroup; engines that share a GPU start on different XCDs, and whoever does not
 // get its partners in time falls back, see above.)
+// chained (nact > 0): the SECOND spread kernel of a 256 < n <= 512 reduction -- cma_tred_mw512 has
+// taken the steps down to pivot row `nact` (= 256: its steps cost 5.5 us, 64 wavefronts exchanging
+// rows of 512), left the leading nact x nact block in eig_work[0] (row stride nact) and the value 1
+// in the hand-over flag; this kernel (rows of 256, 2.9 us per step) takes that block down to istop
+// and leaves 2 there.  The flag is only read at the start (workgroups start at different times:
+// nobody may reset it under a late one's feet).
 template<int NMAX>
 __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c, int force, double *mwbuf,
-        unsigned long long launch, int istop, int xcd0)
+        unsigned long long launch, int istop, int xcd0, int nact = 0)
 {
+    const bool chained = nact > 0;
     constexpr int G = NMAX / 32, NT = NMAX / 16, NV = NMAX / 64;
     const int p = blockIdx.y;
     if ((int) (blockIdx.x & 7) != ((p + xcd0) & 7)) return;
@@ -142,6 +149,9 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (chained) {
+        if (d.eig_work[(size_t) (4 * p + 3) * eig_slab(c.ld) + 4 * c.n + 1] != 1. || sc->eig_mw_fail) return;
+    } else
     // cmaes.cpp:233: skip until enough evaluations have passed
     if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
         if (g == 0 && tid == 0) {
@@ -161,10 +171,12 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     __shared__ unsigned arrived;          // wavefronts that have published, over all steps so far
     if (tid == 0) arrived = 0u;
     __syncthreads();
-    const int n = c.n, ld = c.ld;
-    const double *C = d.C + (size_t) p * ld * ld;
-    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(ld);
-    double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
+    const int n = c.n;
+    // (the matrix this kernel starts from: the covariance, or the block the kernel before it left)
+    const int na = chained ? nact : n, ld = chained ? nact : c.ld;
+    const double *C = chained ? d.eig_work + (size_t) (4 * p) * eig_slab(c.ld) : d.C + (size_t) p * c.ld * c.ld;
+    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(c.ld);
+    double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(c.ld);
     double *mb = mwbuf + (size_t) p * mw_buf_doubles(NMAX);
     unsigned long long *flags = reinterpret_cast<unsigned long long*>(mb);
     double *ebuf = mb + G * MW_FLAG_STRIDE;             // [2][NMAX], entry of row r at (r % G) * 32 + r / G
@@ -177,25 +189,25 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int col = 16 * t + 2 * s;
-        a2[t].x = (r < n && col < n) ? C[(size_t) r * ld + col] : 0.;
-        a2[t].y = (r < n && col + 1 < n) ? C[(size_t) r * ld + col + 1] : 0.;
+        a2[t].x = (r < na && col < na) ? C[(size_t) r * ld + col] : 0.;
+        a2[t].y = (r < na && col + 1 < na) ? C[(size_t) r * ld + col + 1] : 0.;
     }
     // the pivot row of the first step, four entries per lane (zero from the pivot column on)
     double av[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int idx = lane + 64 * v;
-        av[v] = idx < n - 1 ? C[(size_t) (n - 1) * ld + idx] : 0.;
+        av[v] = idx < na - 1 ? C[(size_t) (na - 1) * ld + idx] : 0.;
     }
     const bool recorder = g == 0 && wave == 0;
-    if (recorder && lane == 0) {
+    if (recorder && lane == 0 && !chained) {
         tri[n - 1] = C[(size_t) (n - 1) * ld + n - 1];
         tri[n + n - 1] = 0.;           // (the sub-diagonal is handed over shifted down by one)
         tri[2 * n] = 0.;
         tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
         tri[4 * n + 1] = 0.;           // (this kernel's part of the reduction: not done yet)
     }
-    if (recorder)
+    if (recorder && !chained)
         for (int idx = lane; idx < n; idx += 64) Vout[idx] = 0.;      // row 0: no reflector
     double *ub = ubuf[wave], *wb = wbuf[wave];
     bool failed = false;
@@ -235,13 +247,13 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
             u[v] = (idx < i && !none_) ? (idx == i - 1 ? f_ - gg_ : a[v]) : 0.;
         }
     };
-    reflector(n - 1, av, f, gg, h, rh, none, uvv);
+    reflector(na - 1, av, f, gg, h, rh, none, uvv);
 #pragma unroll
     for (int v = 0; v < NV; v++) ub[lane + 64 * v] = uvv[v];
     dc_wave_sync();
 
-    for (int i = n - 1; i >= istop && !failed; i--) {
-        const unsigned long long epoch = launch * 1024ull + (unsigned long long) (n - i);
+    for (int i = na - 1; i >= istop && !failed; i--) {
+        const unsigned long long epoch = launch * 1024ull + (unsigned long long) (na - i);
         const int par = i & 1;
         MW_CK(0);
         // ---- p = A u for this thread's row; its piece of e = p / h goes out ----------------------
@@ -275,7 +287,7 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
         // count, no barrier: nobody waits inside the workgroup)
         if (lane == 0) {
             const unsigned before = atomicAdd(&arrived, 1u);
-            if (before + 1u == (unsigned) (MW_WAVES * (n - i))) mw_store(flags + MW_FLAG_STRIDE * g, epoch);
+            if (before + 1u == (unsigned) (MW_WAVES * (na - i))) mw_store(flags + MW_FLAG_STRIDE * g, epoch);
         }
         MW_CK(1);
         // ---- every wavefront waits for all pieces ------------------------------------------------
@@ -331,6 +343,8 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
                 if (idx < n) Vout[(size_t) i * n + idx] = uvv[v];
                 if (idx == i - 1) tri[i - 1] = an[v];           // diagonal entry of row i - 1: final
             }
+            // (a row of V is n entries: beyond this kernel's NMAX they are zero)
+            for (int idx = NMAX + lane; idx < n; idx += 64) Vout[(size_t) i * n + idx] = 0.;
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) av[v] = lane + 64 * v < i - 1 ? an[v] : 0.;
@@ -377,14 +391,14 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     }
     if (istop > 1) {
         // the rest is one workgroup's: this thread's part of the leading block, as it stands
-        double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(ld);
+        double *L11 = d.eig_work + (size_t) (4 * p) * eig_slab(c.ld);
         if (r < istop) {
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 if (16 * t + 2 * s < istop)
                     *reinterpret_cast<double2*>(&L11[(size_t) r * istop + 16 * t + 2 * s]) = a2[t];
         }
-        if (recorder && lane == 0) tri[4 * n + 1] = 1.;
+        if (recorder && lane == 0) tri[4 * n + 1] = chained ? 2. : 1.;
         return;
     }
     if (g == 0 && tid == 0) sc->eig_stage = 1;
@@ -394,6 +408,12 @@ __global__ __launch_bounds__(MW_T) void cma_tred_mw(CmaDev d, CmaConst c, int fo
         unsigned long long launch, int istop, int xcd0)
 {
     tred_mw_body<256>(d, c, force, mwbuf, launch, istop, xcd0);
+}
+// the second spread kernel of a 256 < n <= 512 reduction (see `chained` above)
+__global__ __launch_bounds__(MW_T) void cma_tred_mw_chain(CmaDev d, CmaConst c, double *mwbuf,
+        unsigned long long launch, int istop, int xcd0)
+{
+    tred_mw_body<256>(d, c, 0, mwbuf, launch, istop, xcd0, 256);
 }
 // 256 < n <= 512: 16 workgroups, 64 entries of a row per thread (grid (8 * 16, P))
 __global__ __launch_bounds__(MW_T) void cma_tred_mw512(CmaDev d, CmaConst c, int force, double *mwbuf,
