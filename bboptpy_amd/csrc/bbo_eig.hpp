@@ -1525,7 +1525,16 @@ __device__ __forceinline__ void eig_gemm_body(const CmaDev &d, const CmaConst &c
 #pragma unroll
     for (int t = 0; t < CT; t++) acc[t] = d4_eig { 0., 0., 0., 0. };
     const int ksteps = (n + 3) >> 2;
-    for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {
+    // which = 0: the left factor is BLOCK DIAGONAL (Q_1 on [0, n/2), Q_2 on [n/2, n), zeros
+    // elsewhere): a workgroup whose 64 rows lie inside one block contracts over that block's columns
+    // only (the other k-steps multiply stored zeros: x + 0 f = x, the same sums)
+    int klo = 0, khi = ksteps;
+    if (which == 0) {
+        const int mid = n / 2, r0 = blockIdx.y * 64, r1 = min(r0 + 64, n);
+        if (r1 <= mid) khi = (mid + 3) >> 2;
+        else if (r0 >= mid) klo = (mid >> 2) & ~3;
+    }
+    for (int ks0 = klo; ks0 < khi; ks0 += 4) {
         double av[4], bv[4][CT];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
