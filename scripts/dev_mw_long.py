@@ -3,6 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from bboptpy_amd import _ffi
+if os.environ.get("BBO_LIB"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["BBO_LIB"])
 import bboptpy_amd as bb
 n, P, gens = (int(a) for a in sys.argv[1:4])
 alg = bb.ActiveCMAES(mfev=2 ** 31 - 1, tol=0., np=20, seed=1, populations=P, poll_every=50)
