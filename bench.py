@@ -587,6 +587,67 @@ def kernel_report(names, costs, prof, workload, P):
     return kernels, roofline
 
 
+def costs_for(wl, P):
+    """(timer-slot names, algorithmic work per launch) of workload `wl` at P populations"""
+    a = wl["algo"]
+    if a == "ActiveCMAES":
+        return CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], P)
+    if a == "SepCMAES":
+        return CMA_KERNELS, sep_kernel_costs(wl["n"], wl["np"], P)
+    if a in ("SHADE", "JADE", "SANSDE"):
+        costs = de_kernel_costs(wl["n"], wl["np"], P)
+        if a == "SANSDE":   # x_i, best, three partners read, one row written
+            costs["de_generation"] = ("hbm", P * wl["np"] * (48 * wl["n"] + 24))
+        return DE_KERNELS, costs
+    if a == "CSO":
+        return CSO_KERNELS, cso_kernel_costs(wl["n"], wl["np"], P)
+    if a == "CCPSO":
+        # the candidate count changes with the subset size drawn: no fixed per-launch work;
+        # ccp_eval is bound by the objective (2 (n/s) np full-dimension evaluations per
+        # generation, no matrix instruction, hardly any HBM): the HBM figure -- X and Y read
+        # once, the two fitness tables written -- only shows how far from a stream it is
+        n_, np_ = wl["n"], wl["np"]
+        costs = {k: ("hbm", None) for k in CCPSO_KERNELS}
+        costs["ccp_eval"] = ("hbm", P * (2 * np_ * n_ * 8 + 2 * np_ * n_ * 8 // min(wl["pps"])))
+        costs["ccp_position"] = ("hbm", P * 3 * np_ * n_ * 8)
+        return CCPSO_KERNELS, costs
+    return PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
+
+
+# the other BASELINE.json configs, measured inside every default (M) line so that the driver's
+# own run carries them (review of round 4, item 1): key -> generations timed.  C4 is ~35 ms a
+# generation (its O(np^2 n) evolutionary-state estimate), the others 0.5 - 3 ms.
+CONFIG_LEGS = {"C2": 20, "C3": 20, "C4": 8, "SEP": 20}
+
+
+def config_leg(bb, key, device, cpu=True, cpu_budget_s=5.0):
+    """one BASELINE config as its own bench line: warm-up, `steps` timed generations (timers
+    off, one host poll), the same again with the per-kernel HIP-event timers on -> roofline of
+    the kernel with the largest share; the reference on one host core beside it"""
+    wl = WORKLOADS[key]
+    P = wl["P"]
+    steps = CONFIG_LEGS[key]
+    warm = 3 if key == "C4" else 5
+    dt, prof, fev_pop, alg = measure(bb, wl, P, steps, warm, 2000, device, profile=True)
+    del alg
+    names, costs = costs_for(wl, P)
+    kernels, roofline = kernel_report(names, costs, prof, key, P)
+    out = {"workload": "%s n=%d np=%d %s, %d independent population%s per GPU" % (
+               wl["algo"], wl["n"], wl["np"], wl["objective"], P, "s" if P > 1 else ""),
+           "value": P * fev_pop / dt, "unit": "candidate-evals/s", "steps": steps,
+           "warmup": warm, "ms_per_step": 1e3 * dt / steps, "roofline": roofline,
+           "kernels": {k: {"avg_us": v["avg_us"], "share": v["share"], "bound": v["bound"],
+                           "frac": v["frac"]} for k, v in kernels.items()}}
+    if cpu:
+        r = _cpu_run(wl, 1, cpu_budget_s)
+        out["cpu_baseline"] = {
+            "value": r["evals"] / r["dt"], "unit": "candidate-evals/s", "cores": 1,
+            "kind": r["kind"],
+            "sample": "%d generations of %s n=%d np=%d %s, 1 thread, %.1f s%s" % (
+                r["gens"], wl["algo"], wl["n"], r["np"], wl["objective"], r["dt"], r["note"])}
+    return out
+
+
 def spawn_ranks(n_gpus):
     """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree before
     this process has touched the GPU (never exec after HIP init), pass their output through"""
@@ -615,6 +676,8 @@ def main():
                     help="skip the single-population legs (profiling runs: keeps rocprofv3's "
                          "per-kernel averages to the P-population launches)")
     ap.add_argument("--no-bipop", action="store_true", help="skip the bipop_scaling leg")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the C2 / C3 / C4 / SEP legs of the default line")
     ap.add_argument("--cpu-replica", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--slots", type=int, default=1,
                     help="C5: concurrent restart populations per GPU (default 1, as configured)")
@@ -706,28 +769,7 @@ def main():
 
     if rank == 0:
         # per-kernel device time (HIP events on the engine's stream) -> roofline
-        if wl["algo"] == "ActiveCMAES":
-            names, costs = CMA_KERNELS, cma_kernel_costs(wl["n"], wl["np"], P)
-        elif wl["algo"] == "SepCMAES":
-            names, costs = CMA_KERNELS, sep_kernel_costs(wl["n"], wl["np"], P)
-        elif wl["algo"] in ("SHADE", "JADE", "SANSDE"):
-            names, costs = DE_KERNELS, de_kernel_costs(wl["n"], wl["np"], P)
-            if wl["algo"] == "SANSDE":   # x_i, best, three partners read, one row written
-                costs["de_generation"] = ("hbm", P * wl["np"] * (48 * wl["n"] + 24))
-        elif wl["algo"] == "CSO":
-            names, costs = CSO_KERNELS, cso_kernel_costs(wl["n"], wl["np"], P)
-        elif wl["algo"] == "CCPSO":
-            # the candidate count changes with the subset size drawn: no fixed per-launch work;
-            # ccp_eval is bound by the objective (2 (n/s) np full-dimension evaluations per
-            # generation, no matrix instruction, hardly any HBM): the HBM figure -- X and Y read
-            # once, the two fitness tables written -- only shows how far from a stream it is
-            n_, np_ = wl["n"], wl["np"]
-            costs = {k: ("hbm", None) for k in CCPSO_KERNELS}
-            costs["ccp_eval"] = ("hbm", P * (2 * np_ * n_ * 8 + 2 * np_ * n_ * 8 // min(wl["pps"])))
-            costs["ccp_position"] = ("hbm", P * 3 * np_ * n_ * 8)
-            names = CCPSO_KERNELS
-        else:
-            names, costs = PSO_KERNELS, pso_kernel_costs(wl["n"], wl["np"], P)
+        names, costs = costs_for(wl, P)
         kernels, roofline = kernel_report(names, costs, prof, args.workload, P)
         single = None
         singles = None
@@ -755,6 +797,10 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(wl, key=args.workload)
+        configs = None
+        if world == 1 and args.workload == "M" and not args.no_configs:
+            configs = {key: config_leg(bb, key, local_rank, cpu=not args.no_cpu_baseline)
+                       for key in CONFIG_LEGS}
         out = {
             "metric": "candidate-evals/sec", "value": value, "unit": "candidate-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -770,6 +816,7 @@ def main():
             "generations_to_tol": conv,
             "generations_to_ftarget": ftar,
             "bipop_scaling": bipop,
+            "configs": configs,
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

@@ -14,8 +14,8 @@ for spec in "M 256 pmc" "C3 256 pmc" "C2 256 pmc" "C1 4096 nopmc" "C4 1 nopmc" "
   mkdir -p $OUT
   export TMPDIR=/tmp
   cd /tmp
-  ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 20 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence"
-  [ "$WL" = "C4" ] && ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 5 --warmup 2 --no-cpu-baseline --no-single --no-bipop --no-convergence"
+  ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 20 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence --no-configs"
+  [ "$WL" = "C4" ] && ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 5 --warmup 2 --no-cpu-baseline --no-single --no-bipop --no-convergence --no-configs"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
   echo "$WL trace rc=$?"
   if [ "$PMC" = "pmc" ]; then

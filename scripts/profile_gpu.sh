@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 20 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence"
+ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 20 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence --no-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/bench_trace.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 $ARGS > $OUT/bench_fetch.json
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 $ARGS > $OUT/bench_write.json

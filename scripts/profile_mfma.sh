@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 10 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence"
+ARGS="$ROOT/bench.py --workload $WL --populations $P --steps 10 --warmup 3 --no-cpu-baseline --no-single --no-bipop --no-convergence --no-configs"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     --output-format csv -d $OUT/sq -o sq -- python3 $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
 echo "sq pass rc=$?"
