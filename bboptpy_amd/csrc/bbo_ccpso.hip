@@ -468,7 +468,10 @@ void CcpsoEngine::after_generation(int gen_before)
         CcpScal s;
         BBO_HIP(hipStreamSynchronize(stream_));
         scal_.download(&s, 1, 0);
-        if (!s.stop) local_search();
+        // the reference's iterate() searches BEFORE optimize() tests the budget and the spread
+        // (ccpso.cpp:112-147): a generation that has just raised the stop flag still gets its
+        // search; one that did not run at all (the flag was up before it) does not
+        if (s.gen != gen_before) local_search();
     }
 }
 

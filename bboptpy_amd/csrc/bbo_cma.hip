@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace bbo {
@@ -58,13 +59,103 @@ CmaEngine::CmaEngine(const bbo_params &p) :
     BBO_REQUIRE(p.device >= 0 && p.device < ndev, "device ordinal out of range");
     BBO_HIP(hipSetDevice(p.device));
     BBO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    BBO_HIP(hipHostMalloc((void**) &stop_host_, sizeof(int) * p.populations));
+    BBO_HIP(hipHostMalloc((void**) &mw_fail_host_, sizeof(int)));
+    *mw_fail_host_ = 0;
 }
 
 CmaEngine::~CmaEngine()
 {
+    mw_release();
     if (stream_) (void) hipStreamDestroy(stream_);
-    if (stop_host_) (void) hipHostFree(stop_host_);
+    if (mw_fail_host_) (void) hipHostFree(mw_fail_host_);
+}
+
+// ---- the spread reduction's share of the device (bbo_eig_mw.hpp) -----------------------------------
+// Its workgroups wait for each other, so all of them -- of every engine of this process that may
+// have such a kernel in flight on the device -- must be resident at once.  Capacity: compute units
+// (hipDeviceProp) x workgroups of cma_tred_mw512 a compute unit holds (the occupancy API; 1 on
+// gfx950: 277 / 512 registers per lane), minus a margin of a sixteenth for whatever else runs.  An
+// engine reserves its count before its first spread launch and gives it back when it dies, changes
+// shape or falls back; who gets no reservation uses the one-workgroup reduction.  Other PROCESSES
+// on the device are not seen: against them stands the bounded wait and the fallback.
+namespace {
+struct MwBudget {
+    static constexpr int MAXDEV = 64;
+    std::mutex m;
+    long cap[MAXDEV] = {};
+    long used[MAXDEV] = {};
+    bool known[MAXDEV] = {};
+    static MwBudget &get()
+    {
+        static MwBudget b;
+        return b;
+    }
+    long capacity(int dev)
+    {
+        if (!known[dev]) {
+            hipDeviceProp_t prop;
+            int per_cu = 0;
+            long cus = 0;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*) cma_tred_mw512, MW_T, 0)
+                    != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            cap[dev] = cus * per_cu - std::max(1L, cus / 16);
+            known[dev] = true;
+        }
+        return cap[dev];
+    }
+    bool reserve(int dev, long wgs)
+    {
+        if (dev < 0 || dev >= MAXDEV) return false;
+        std::lock_guard<std::mutex> lock(m);
+        if (used[dev] + wgs > capacity(dev)) return false;
+        used[dev] += wgs;
+        return true;
+    }
+    void release(int dev, long wgs)
+    {
+        if (dev < 0 || dev >= MAXDEV) return;
+        std::lock_guard<std::mutex> lock(m);
+        used[dev] -= wgs;
+    }
+};
+} // namespace
+
+// fault injection for the tests of the spread reduction: the ENVIRONMENT of this process only
+// (read when an engine is initialised and on the phase-by-phase path the tests drive; bbo_set
+// cannot reach it)
+static int mw_fault_from_env()
+{
+    const char *e = std::getenv("BBO_MW_FAULT_STEP");
+    return e && *e ? std::atoi(e) : -1;
+}
+
+bool CmaEngine::mw_reserve(long workgroups)
+{
+    if (mw_reserved_ == workgroups) return true;
+    mw_release();
+    if (!MwBudget::get().reserve(params_.device, workgroups)) return false;
+    mw_reserved_ = workgroups;
+    return true;
+}
+
+void CmaEngine::mw_release()
+{
+    if (mw_reserved_ > 0) MwBudget::get().release(params_.device, mw_reserved_);
+    mw_reserved_ = 0;
+}
+
+// after a synchronisation of the stream: did a spread reduction launched since the last look give up?
+bool CmaEngine::mw_check_failed()
+{
+    if (!mw_launched_) return false;
+    mw_launched_ = false;
+    if (!*mw_fail_host_) return false;
+    *mw_fail_host_ = 0;
+    mw_disabled_ = true;
+    mw_release();
+    return true;
 }
 
 void CmaEngine::set_params(int np, double sigma, int mfev)
@@ -289,6 +380,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
     d.weights = weights_.p; d.lower = lower_.p; d.upper = upper_.p; d.aux = aux_.p;
     d.zinject = nullptr; d.zrecord = nullptr; d.scal = scal_.p;
     d.stamps = stamps_.p;
+    d.mw_fail_host = mw_fail_host_;
+    d.mw_fault = mw_fault_from_env();
+    mw_release();          // (the shape may have changed: reserved again at the first spread launch)
 
     // packed operands of the initial B, D, C^-1/2
     c.honor_stop = 0;
@@ -563,7 +657,7 @@ void CmaEngine::launch_eigen()
     timer_.begin(stream_, K_EIGEN);
     // (256 < n <= 512 by the spread reduction: while its 16 workgroups per matrix fit the chip at once)
     const bool big_spread = c.n > 256 && pl.dc && !pl.hybrid && !mw_disabled_
-            && !(d_.dbg & (2 | 16777216)) && (long) c.npop * 16 <= 256;
+            && !(d_.dbg & (2 | 16777216)) && mw_reserve((long) c.npop * 16);
     // n <= 16: a wavefront per matrix (dbg bit 4 keeps the big kernel)
     const bool small = c.n <= 16 && c.n >= 2 && c.ld == 16 && !(d_.dbg & 16);
     if (small)    // (does cma_post's work too: one launch less where launches are what costs)
@@ -589,11 +683,13 @@ void CmaEngine::launch_eigen()
         // step, an exchange between compute units each, where the one-workgroup step with the whole
         // active matrix on chip costs ~5), the leading 128 x 128 block then on one workgroup
         // (1.15 us per step): 0.35 against 0.36 ms per decomposition at n = 132, 0.63 / 0.73 at 200,
-        // 0.83 / 1.04 at 256 -- while all of a launch's workgroups (256 threads, ~100 registers: two
-        // and more fit a CU) are resident at once (they wait for each other: bbo_eig_mw.hpp; diagnostic bit 16777216 keeps the reduction on one
-        // workgroup)
-        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && (long) c.npop * MW_G <= 256;
+        // 0.83 / 1.04 at 256 -- while all of a launch's workgroups (256 threads, 277 registers per
+        // lane: ONE per compute unit) can be resident at once next to those of the process's other
+        // engines (they wait for each other: MwBudget above, bbo_eig_mw.hpp; diagnostic bit 16777216
+        // keeps the reduction on one workgroup)
+        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && mw_reserve((long) c.npop * MW_G);
         if (use_mw) {
+            mw_launched_ = true;
             if (mw_buf_.count != (size_t) c.npop * MW_BUF_DOUBLES) mw_buf_.alloc((size_t) c.npop * MW_BUF_DOUBLES);
             // (its steps down to the leading 128 x 128 block; that block on one workgroup: diagnostic
             // bit 536870912 keeps all steps spread)
@@ -628,6 +724,7 @@ void CmaEngine::launch_eigen()
         // one of them publishes must never sit where the other looks for a flag; diagnostic bit
         // 536870912 keeps the first one down to row 128)
         const bool chain = !(d_.dbg & 536870912);
+        mw_launched_ = true;
         const size_t need = (size_t) c.npop * (mw_buf_doubles(512) + mw_buf_doubles(256));
         if (mw_buf_.count != need) mw_buf_.alloc(need);
         hipLaunchKernelGGL(cma_tred_mw512, dim3(8 * 16, c.npop), dim3(MW_T), 0, stream_, d_, c_, 0,
@@ -757,6 +854,7 @@ void CmaEngine::phase(int which)
     BBO_REQUIRE(inited_, "phase before init");
     BBO_HIP(hipSetDevice(params_.device));
     c_.honor_stop = 0;
+    d_.mw_fault = mw_fault_from_env();
     switch (which) {
     case BBO_PHASE_SAMPLE_EVALUATE:
         launch_sample_eval();
@@ -769,12 +867,18 @@ void CmaEngine::phase(int which)
     default: throw Error(BBO_ERR_ARG, "unknown CMA phase");
     }
     BBO_HIP(hipStreamSynchronize(stream_));
+    if (mw_check_failed() && which == BBO_PHASE_EIGEN) {
+        // the spread reduction gave up: this generation's decomposition by the one-workgroup path
+        launch_eigen();
+        BBO_HIP(hipStreamSynchronize(stream_));
+    }
     timer_.collect();
 }
 
 void CmaEngine::inject_normals(const double *z, int count)
 {
     BBO_REQUIRE(inited_, "inject_normals before init");
+    rank_wrote_norms_ = false;
     if (!z) {
         d_.zinject = nullptr;
         return;
@@ -792,6 +896,12 @@ void CmaEngine::iterate()
     BBO_HIP(hipSetDevice(params_.device));
     generation(false);
     BBO_HIP(hipStreamSynchronize(stream_));
+    if (mw_check_failed()) {
+        // the spread reduction gave up (bbo_eig_mw.hpp): the decomposition this generation was due
+        // is not lost -- eigenlastev has not moved, the one-workgroup kernels take it now
+        launch_eigen();
+        BBO_HIP(hipStreamSynchronize(stream_));
+    }
     timer_.collect();
 }
 
@@ -809,8 +919,14 @@ bool CmaEngine::all_stopped()
     bool stale = false;
     for (const auto &s : sc) stale = stale || !s.basis_ok;
     basis_maybe_stale_ = stale;
+    // (bbo_eig_mw.hpp: back to the one-workgroup reduction; the generations since the time-out
+    // returned from the spread kernel at entry, the next one decomposes -- eigenlastev stood still)
+    mw_check_failed();
     for (const auto &s : sc)
-        if (s.eig_mw_fail) mw_disabled_ = true;      // (bbo_eig_mw.hpp: back to the one-workgroup reduction)
+        if (s.eig_mw_fail && !mw_disabled_) {
+            mw_disabled_ = true;
+            mw_release();
+        }
     for (const auto &s : sc)
         if (!s.stop) return false;
     return true;
@@ -1026,6 +1142,12 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "eigen_done") return one(s.eigen_done);
     if (k == "eig_mw_fail") return one(s.eig_mw_fail);     // (bbo_eig_mw.hpp: sticky)
     if (k == "eig_mw_off") return one(mw_disabled_ ? 1 : 0);
+    if (k == "eig_mw_reserved") return one((double) mw_reserved_);       // this engine's share of the device's ...
+    if (k == "eig_mw_capacity") {                                        // ... budget of spread workgroups
+        MwBudget &b = MwBudget::get();
+        std::lock_guard<std::mutex> lock(b.m);
+        return one((double) b.capacity(params_.device));
+    }
     if (k == "best_len") return one(s.hist_len);
     if (k == "best_buffer") return one(s.hist_head);
     if (k == "ibest") return one(s.ibw[0]);
@@ -1058,6 +1180,7 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
     BBO_HIP(hipSetDevice(params_.device));
     BBO_HIP(hipStreamSynchronize(stream_));
+    rank_wrote_norms_ = false;      // (S of a ranking before this call may not match the new state)
     const CmaConst &c = c_;
     const size_t ld = c.ld, n = c.n;
     auto vec = [&](DevBuf<double> &b) {

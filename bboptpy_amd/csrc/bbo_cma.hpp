@@ -77,6 +77,8 @@ struct CmaDev {
     CmaScal *scal;                    // [P]
     long long *stamps;                // [16] eigensolver phase clocks (diagnostic) or null
     int dbg;                          // diagnostic switches (0 in production)
+    int mw_fault;                     // fault injection of bbo_eig_mw.hpp (-1: none; environment only)
+    int *mw_fail_host;                // pinned host word: a spread reduction of this engine timed out
 };
 
 class CmaEngine: public Optimizer {
@@ -152,7 +154,12 @@ private:
     DevBuf<int> rank_, order_;
     DevBuf<long long> stamps_;
     DevBuf<CmaScal> scal_;
-    int *stop_host_ = nullptr;   // pinned
+    int *mw_fail_host_ = nullptr;   // pinned, device-visible: raised by a spread reduction that timed out
+    long mw_reserved_ = 0;          // workgroups this engine holds of the device's MwBudget
+    bool mw_launched_ = false;      // a spread kernel went out since the flag was last read
+    bool mw_reserve(long workgroups);
+    void mw_release();
+    bool mw_check_failed();         // after a synchronisation: true once when the flag went up
     KernelTimer timer_;
 };
 

@@ -46,10 +46,25 @@
 // grid is (8 MW_G, P) and only the blocks with blockIdx.x % 8 == (p + xcd0) % 8 work, the others
 // return (xcd0: per engine, so that engines sharing a GPU do not all sit on XCD 0).
 //
-// Every spin is bounded (MW_SPIN polls, ~1 s): on a time-out the workgroup raises the sticky
-// CmaScal::eig_mw_fail, skips the hand-over (eig_stage stays 0: this generation keeps its basis,
-// like a generation the lazy schedule skips) and the host stops using this path at its next poll.
-// The host only launches it when all MW_G * P workgroups fit the chip at once.
+// Every wait is bounded by the constant-rate wall clock (MW_TIMEOUT_TICKS of wall_clock64(), 100 MHz
+// on gfx950: 50 ms whatever the shader clock does; the clock is only read every 1024th poll, so a
+// step that gets its pieces pays nothing): on a time-out the wavefront raises the sticky
+// CmaScal::eig_mw_fail and the engine's pinned host flag, skips the hand-over (eig_stage stays 0:
+// this generation keeps its basis, like a generation the lazy schedule skips), and every later
+// launch of these kernels returns at entry (nobody spins twice).  The host reads the flag after
+// every synchronisation (iterate / phase / run's poll), stops using this path and runs the
+// one-workgroup decomposition for the generation that lost its own.  The host only launches it when
+// all workgroups of all engines of this process on the device fit the chip at once
+// (MwBudget, bbo_cma.hip).
+//
+// Ordering.  A piece is published as: data stores (relaxed, agent scope) -> s_waitcnt 0 -> LDS
+// arrival count -> flag store; it is consumed as: flag loads until all are there -> data loads.
+// The hardware keeps that order for one wavefront (the stores are acknowledged before the count
+// goes up; a load issued after the poll's result is used cannot be served before it), what could
+// move them is the compiler: __builtin_amdgcn_s_waitcnt carries no memory semantics.  So the two
+// places are pinned with __atomic_signal_fence(SEQ_CST) -- a compiler-only fence, no cache
+// operation, no instruction -- and tests/test_isa_mw.py disassembles the shipped library and checks
+// the order of the instructions themselves.
 //
 // Output (what cma_eigen_g1 leaves): eig_work[3] = [d | e (shifted down) | h], the reflectors
 // V (row i = u_i, zero from column i on) dense n x n in eig_work[1], CmaScal::eig_stage = 1.
@@ -62,7 +77,7 @@ namespace bbo {
 
 constexpr int MW_G = 8;                 // workgroups per matrix of n <= 256 (NMAX / 32 in general: 16 to n = 512)
 constexpr int MW_T = 256;               // threads per workgroup: 32 rows x 8 lanes
-constexpr int MW_SPIN = 1 << 21;
+constexpr long long MW_TIMEOUT_TICKS = 5000000;     // of wall_clock64() (100 MHz): 50 ms
 constexpr int MW_WAVES = MW_T / 64;
 #ifndef MW_POLL_SLEEP
 #define MW_POLL_SLEEP 1
@@ -149,11 +164,14 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     CmaScal *sc = d.scal + p;
     if (c.honor_stop && sc->stop != 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a wavefront of an earlier launch gave up (the host has not looked yet): nobody waits again, and
+    // the kernels behind this one see a generation without a decomposition
+    const bool gave_up = sc->eig_mw_fail != 0;
     if (chained) {
-        if (d.eig_work[(size_t) (4 * p + 3) * eig_slab(c.ld) + 4 * c.n + 1] != 1. || sc->eig_mw_fail) return;
+        if (gave_up || d.eig_work[(size_t) (4 * p + 3) * eig_slab(c.ld) + 4 * c.n + 1] != 1.) return;
     } else
     // cmaes.cpp:233: skip until enough evaluations have passed
-    if (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq)) {
+    if (gave_up || (!force && !((double) (sc->fev - sc->eigenlastev) > c.eigenfreq))) {
         if (g == 0 && tid == 0) {
             sc->eigen_done = 0;
             sc->eig_stage = 0;
@@ -163,9 +181,12 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
         }
         return;
     }
-    // (diagnostic bit 1073741824: one of the workgroups walks away -- what the others do about a
-    // partner that never publishes is tested, not assumed: tests/test_cma_gpu.py)
-    if ((d.dbg & 1073741824) && g == 3) return;
+    // (fault injection, BBO_MW_FAULT_STEP in the environment of the process that creates the engine
+    // -- not reachable through bbo_set: workgroup 3 walks away, at entry (0) or after taking part in
+    // k steps (k > 0) -- what the others do about a partner that stops publishing is tested, not
+    // assumed: tests/test_cma_gpu.py)
+    const int fault_step = g == 3 ? d.mw_fault : -1;
+    if (fault_step == 0) return;
     __shared__ __attribute__((aligned(16))) double ubuf[4][NMAX];
     __shared__ __attribute__((aligned(16))) double wbuf[4][NMAX];
     __shared__ unsigned arrived;          // wavefronts that have published, over all steps so far
@@ -255,6 +276,7 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     for (int i = na - 1; i >= istop && !failed; i--) {
         const unsigned long long epoch = launch * 1024ull + (unsigned long long) (na - i);
         const int par = i & 1;
+        if (fault_step > 0 && na - 1 - i == fault_step) return;
         MW_CK(0);
         // ---- p = A u for this thread's row; its piece of e = p / h goes out ----------------------
         double2 uc[NT];
@@ -281,8 +303,10 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
 #pragma unroll
             for (int v = 0; v < NV; v++) mw_store_d(rbuf + NMAX * par + lane + 64 * v, wb[lane + 64 * v]);
         }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores are out (and its loads of
                                                 // the step before: the buffers alternate)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         // the LAST wavefront of this workgroup to get here raises the workgroup's flag (an LDS
         // count, no barrier: nobody waits inside the workgroup)
         if (lane == 0) {
@@ -293,17 +317,23 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
         // ---- every wavefront waits for all pieces ------------------------------------------------
         {
             int spins = 0;
+            long long t_wait = 0;
             while (true) {
                 const unsigned long long fl = lane < G ? mw_load(flags + MW_FLAG_STRIDE * lane) : epoch;
                 if (__ballot(fl < epoch) == 0ull) break;
-                if (++spins >= MW_SPIN) {
-                    failed = true;
-                    break;
+                if ((++spins & 1023) == 0) {
+                    const long long now = (long long) wall_clock64();
+                    if (t_wait == 0) t_wait = now;
+                    else if (now - t_wait > MW_TIMEOUT_TICKS) {
+                        failed = true;
+                        break;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(MW_POLL_SLEEP);
             }
         }
         if (failed) break;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);      // (the data loads stay behind the poll)
         MW_CK(2);
         // (only the lanes inside the active block ask: measured against eight unconditional loads
         // per lane, 1071 against 1170 us per decomposition -- the requests are served on the memory
@@ -386,6 +416,7 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
         if (lane == 0) {
             sc->eig_mw_fail = 1;
             sc->eigen_done = 0;       // (the products that follow must not run on what is half there)
+            if (d.mw_fail_host) __hip_atomic_store(d.mw_fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }

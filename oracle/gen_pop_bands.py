@@ -12,6 +12,17 @@ evaluation checkpoints (a convergence curve per run), and stores per checkpoint 
 log10(best f) over the K runs.  tests/test_pop_bands_gpu.py runs the device on the same problems
 (`populations=K`) and holds its medians against these bands.
 
+APSO and the reference's out-of-bounds read.  `APSOSearch::nextState` indexes its rule table with
+the state 1..4 (apso.cpp:384: `_rulebase[r][_state]`, rows of four ints), so state 4 reads one int
+past the row: undefined behaviour.  In a fresh heap that word is 0 (SURVEY appendix A.10 -- the
+value the oracle and the device pin), in a recycled one it is whatever an earlier allocation left,
+and the run continues with a garbage state or dies (seen here: the second APSO run of one process
+segfaults at iteration 6; AddressSanitizer names apso.cpp:384).  Every APSO seed therefore runs in
+a process of its own; a seed whose process dies is recorded under `reference_crashed_seeds` and
+the next seed takes its place; and every curve that goes into the fixture is compared with the
+oracle's reference mode (async, mt19937, out-of-bounds word = 0): `equals_oracle` says whether
+they agree to the last bit, i.e. whether that reference run read a 0 there.
+
 A fixture is data: seeds, configuration, checkpoints and the reference's outputs.  Nothing of the
 reference's text goes into it.  Run in the development container only:
 
@@ -19,6 +30,7 @@ reference's text goes into it.  Run in the development container only:
 """
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -100,11 +112,25 @@ def curve(lib, c, seed):
     return out, fevs
 
 
+def curve_in_child(name, seed):
+    """the same in a process of its own (APSO: see the header); None when the child died"""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", name, str(seed)],
+                       capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[")]
+    if r.returncode != 0 or not lines:
+        return None
+    return [float.fromhex(v) for v in json.loads(lines[-1])]
+
+
 def main():
     lib = po.reference()
     if lib is None:
         sys.exit("oracle/_ref/libbbo_ref.so is not built: run `make -C oracle ref` where "
                  "/root/reference exists")
+    if len(sys.argv) == 4 and sys.argv[1] == "--one":
+        f, _ = curve(lib, CASES[sys.argv[2]], int(sys.argv[3]))
+        print(json.dumps([float(v).hex() for v in f]))
+        return
     only = sys.argv[1:]
     doc = {"generator": "oracle/gen_pop_bands.py", "library": "oracle/_ref (compiled reference)",
            "runs_per_case": K, "seed_base": 9000, "cases": {}}
@@ -115,12 +141,27 @@ def main():
         if only and name not in only:
             continue
         t0 = time.time()
-        curves = []
-        for r in range(K):
-            f, fevs = curve(lib, c, 9000 + 100 * list(CASES).index(name) + r)
+        curves, seeds, crashed, equal = [], [], [], []
+        seed = 9000 + 100 * list(CASES).index(name)
+        while len(curves) < K and len(crashed) < 3 * K:
+            if c["algo"] == "apso":
+                f = curve_in_child(name, seed)
+            else:
+                f, _ = curve(lib, c, seed)
+            if f is None:
+                crashed.append(seed)
+                print(name, "seed", seed, "the reference's process died (apso.cpp:384)", flush=True)
+                seed += 1
+                continue
+            # the oracle's reference mode on the same seed (all APSO curves; one per DE case)
+            if c["algo"] == "apso" or not curves:
+                fo, _ = curve(po.oracle(), c, seed)
+                equal.append(bool(np.array_equal(np.array(f), np.array(fo))))
             curves.append(f)
-            print(name, "seed", r, "%.1f s" % (time.time() - t0), "final f %.6g" % f[-1],
-                  flush=True)
+            seeds.append(seed)
+            print(name, "seed", seed, "%.1f s" % (time.time() - t0), "final f %.6g" % f[-1],
+                  "equals oracle:", equal[-1] if equal else None, flush=True)
+            seed += 1
         lg = np.log10(np.maximum(np.array(curves), 1e-300))
         q = np.percentile(lg, [0, 25, 50, 75, 100], axis=0)
         doc["cases"][name] = {
@@ -129,6 +170,7 @@ def main():
             "log10_best_f": {"min": q[0].tolist(), "q1": q[1].tolist(), "median": q[2].tolist(),
                              "q3": q[3].tolist(), "max": q[4].tolist()},
             "runs_log10_best_f": lg.tolist(),
+            "seeds": seeds, "reference_crashed_seeds": crashed, "equals_oracle": equal,
             "reference_seconds_one_core": time.time() - t0,
         }
     with open(OUT, "w") as fh:

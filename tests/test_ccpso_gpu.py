@@ -203,6 +203,41 @@ def test_local_search_inside_the_library_equals_the_python_driven_one(hip, oracl
     L.bbo_destroy(hc)
 
 
+def test_run_searches_locally_in_the_generation_that_spends_the_budget(hip, oracle_lib):
+    """(advisor, round 4) the reference's iterate() runs localSearch before optimize() looks at the
+    budget (ccpso.cpp:112-147); bbo_run used to skip the search of the generation that raised the
+    stop flag, so run() / optimize() and an iterate()-driven loop could end at different points
+    whenever the last generation was a local-search generation.  Both are held together here for
+    budgets that end on either kind of generation."""
+    n, npp, cps, lf = 24, 8, 4, 2
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    kinds = set()
+    for mfev in (150, 250, 350, 450, 560, 700):
+        out = []
+        for driver in ("iterate", "run"):
+            loc = hip.ActiveCMAES(mfev=60, tol=1e-9, np=8, seed=77)
+            g = hip.CCPSO(mfev=mfev, sigmatol=1e-300, np=npp, pps=[cps], localfreq=lf, seed=31,
+                          local=loc)
+            assert g._local_native
+            g.initialize(hip.objectives.ellipsoid, lo, up, np.zeros(n))
+            if driver == "iterate":
+                gens = 0
+                while True:                      # the reference's optimize() loop
+                    g.iterate()
+                    gens += 1
+                    if int(g.get_state("fev")[0]) >= mfev:
+                        break
+                kinds.add((gens - 1) % lf == 0)
+            else:
+                g.run(10 ** 6)
+            out.append((int(g.get_state("fev")[0]), float(g.get_state("fyhat")[0]),
+                        g.get_state("yhat").copy(), int(g.get_state("it")[0])))
+        a, b = out
+        assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3], (mfev, a[0], b[0], a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    assert kinds == {True, False}, kinds         # both kinds of last generation were exercised
+
+
 def test_local_optimizer_whole_run(hip):
     """optimize() with a local optimizer: the reference's loop (generation, local search every
     localfreq generations, budget test, spread test) driven from the Python class"""

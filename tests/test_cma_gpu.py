@@ -395,19 +395,25 @@ def test_spread_reduction_runs_generation_after_generation(hip):
         np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-7)
 
 
-def test_spread_reduction_survives_a_partner_that_never_publishes(hip):
-    """The workgroups of the spread reduction wait for each other; every wait is bounded.  With
-    diagnostic bit 1073741824 one of the eight walks away at the start: the others must give up
-    (about a second), raise the sticky flag, the tail must not run on the partial block (that
-    generation keeps its basis, like a generation the lazy schedule skips), the host must stop
-    using the path at its next poll, and the decompositions that follow -- on one workgroup --
-    are right again."""
-    from bboptpy_amd import _ffi
-    n = 200
-    rng = np.random.default_rng(3)
+def _spd(n, seed):
+    rng = np.random.default_rng(seed)
     X = rng.normal(size=(n, 3 * n))
     Cm = X @ X.T / (3 * n)
-    Cm = 0.5 * (Cm + Cm.T)
+    return 0.5 * (Cm + Cm.T)
+
+
+@pytest.mark.parametrize("n,step", [(200, 0), (200, 37), (256, 100), (300, 0), (300, 60)])
+def test_spread_reduction_survives_a_partner_that_stops_publishing(hip, monkeypatch, n, step):
+    """The workgroups of the spread reduction wait for each other; every wait is bounded by the wall
+    clock (50 ms).  With BBO_MW_FAULT_STEP in the environment one of them walks away -- at the start
+    (0) or after `step` steps, with the exchange buffers of the step before still holding a valid
+    older epoch: the others must give up, raise the sticky flag and the engine's pinned host word,
+    the kernels behind must not run on the partial block, and the host -- which looks at the word
+    after every synchronisation -- must fall back to the one-workgroup reduction and deliver THIS
+    decomposition with it."""
+    import time
+    from bboptpy_amd import _ffi
+    Cm = _spd(n, 3)
     g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1)
     g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
     # a good decomposition first (of another matrix), so that there is a basis to lose
@@ -416,25 +422,118 @@ def test_spread_reduction_survives_a_partner_that_never_publishes(hip):
     g.set_state("eigenlastev", [0])
     g.phase(_ffi.PHASE_EIGEN)
     assert int(g.get_state("eigen_done")[0]) == 1 and int(g.get_state("eig_mw_fail")[0]) == 0
-    g.set_state("dbg", [float(1073741824)])
+    assert int(g.get_state("eig_mw_off")[0]) == 0
+    monkeypatch.setenv("BBO_MW_FAULT_STEP", str(step))
     g.set_state("C", Cm)
     g.set_state("fev", [2 * 10 ** 6])
     g.set_state("eigenlastev", [0])
-    B0 = g.get_state("B").reshape(n, n).copy()
+    t0 = time.perf_counter()
     g.phase(_ffi.PHASE_EIGEN)
-    assert int(g.get_state("eig_mw_fail")[0]) == 1
-    assert int(g.get_state("eigen_done")[0]) == 0          # no decomposition this time ...
-    np.testing.assert_array_equal(g.get_state("B").reshape(n, n), B0)      # ... and the basis untouched
-    g.run(1)                                              # a generation: its poll sees the flag
-    assert int(g.get_state("eig_mw_off")[0]) == 1
-    g.set_state("C", Cm)
-    g.set_state("fev", [4 * 10 ** 6])
-    g.set_state("eigenlastev", [0])
-    g.phase(_ffi.PHASE_EIGEN)
-    assert int(g.get_state("eigen_done")[0]) == 1
+    dt = time.perf_counter() - t0
+    assert int(g.get_state("eig_mw_fail")[0]) == 1          # sticky, as the kernel left it
+    assert int(g.get_state("eig_mw_off")[0]) == 1           # the host saw it in this very call ...
+    assert int(g.get_state("eigen_done")[0]) == 1           # ... and decomposed on one workgroup
+    assert dt < 0.5, dt                                     # 50 ms of waiting, not seconds
     B, D = g.get_state("B").reshape(n, n), g.get_state("D")
     assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n
     assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm)
+    # and the engine keeps working without the path
+    monkeypatch.delenv("BBO_MW_FAULT_STEP")
+    C2 = _spd(n, 4)
+    g.set_state("C", C2)
+    g.set_state("fev", [4 * 10 ** 6])
+    g.set_state("eigenlastev", [0])
+    g.phase(_ffi.PHASE_EIGEN)
+    B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+    assert np.linalg.norm(B @ np.diag(D * D) @ B.T - C2) <= 1e-11 * np.linalg.norm(C2)
+
+
+@pytest.mark.parametrize("driver", ["iterate", "run"])
+def test_spread_reduction_failure_under_iterate_and_run(hip, monkeypatch, driver):
+    """(advisor, round 4) iterate() never polled the sticky flag: after one time-out every due
+    decomposition spun again and the basis froze for the rest of the run.  Now the kernels return at
+    entry once the flag is up, iterate() reads the pinned word after its synchronisation and
+    re-launches the decomposition on one workgroup for that same generation; run() does the same at
+    its poll (the generations between the time-out and the poll keep their basis, like
+    generations the lazy schedule skips).  A faulted handle must end where a handle that never
+    used the spread path ends: bit for bit under iterate(), and with a valid decomposition of its
+    own covariance under run()."""
+    import time
+    n, lam = 200, 24
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(8).uniform(-4, 4, n)
+    monkeypatch.setenv("BBO_MW_FAULT_STEP", "11")
+    g = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=21, poll_every=4)
+    g.initialize(hip.objectives.ellipsoid, lo, up, guess)
+    monkeypatch.delenv("BBO_MW_FAULT_STEP")
+    h = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=21, poll_every=4)
+    h.initialize(hip.objectives.ellipsoid, lo, up, guess)
+    h.set_state("dbg", [float(16777216)])          # the reduction on one workgroup throughout
+    t0 = time.perf_counter()
+    if driver == "iterate":
+        for _ in range(6):
+            g.iterate()
+            h.iterate()
+    else:
+        assert g.run(8) == 8
+        assert h.run(8) == 8
+    assert time.perf_counter() - t0 < 2.0
+    assert int(g.get_state("eig_mw_fail")[0]) == 1 and int(g.get_state("eig_mw_off")[0]) == 1
+    assert int(h.get_state("eig_mw_fail")[0]) == 0
+    assert int(g.get_state("eigen_done")[0]) == 1
+    if driver == "iterate":
+        # no decomposition was lost: the same trajectory as the handle that never spread
+        for key in ("xmean", "sigma", "D", "B", "C"):
+            np.testing.assert_array_equal(g.get_state(key), h.get_state(key), err_msg=key)
+    else:
+        Cg = g.get_state("C").reshape(n, n)
+        B, D = g.get_state("B").reshape(n, n), g.get_state("D")
+        assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n
+        assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cg) <= 1e-10 * np.linalg.norm(Cg)
+        assert np.isfinite(g.get_state("xmean")).all()
+
+
+def test_spread_reduction_budget_is_shared_by_the_engines_of_a_process(hip):
+    """The spread workgroups of ALL engines of a process on one device must fit the chip at once
+    (they wait for each other).  The budget comes from hipDeviceProp (compute units) and the
+    occupancy of the kernel, minus a sixteenth; an engine that gets no share runs the one-workgroup
+    reduction -- same results -- instead of risking a time-out."""
+    from bboptpy_amd import _ffi
+    n = 144
+    Cm = _spd(n, 9)
+    probe = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=8, seed=1)
+    probe.initialize(hip.objectives.sphere, -np.ones(4), np.ones(4), np.zeros(4))
+    cap = int(probe.get_state("eig_mw_capacity")[0])      # compute units x occupancy - margin
+    assert 64 <= cap < 1024, cap
+    per_engine = 8 * 8                     # P = 8 populations x MW_G workgroups
+    fit = cap // per_engine
+    gs = []
+    for k in range(fit + 2):
+        g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1 + k, populations=8)
+        g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros((8, n)))
+        for p in range(8):
+            g.set_state("C", Cm, p)
+            g.set_state("fev", [10 ** 6], p)
+            g.set_state("eigenlastev", [0], p)
+        g.phase(_ffi.PHASE_EIGEN)
+        gs.append(g)
+    used = [int(g.get_state("eig_mw_reserved")[0]) for g in gs]
+    assert used[:fit] == [per_engine] * fit, used
+    assert used[fit:] == [0, 0], used       # no share left: one-workgroup path, no time-out
+    ref = gs[0].get_state("D")
+    for g in gs:
+        assert int(g.get_state("eig_mw_fail")[0]) == 0 and int(g.get_state("eigen_done")[0]) == 1
+        np.testing.assert_allclose(g.get_state("D"), ref, rtol=1e-9)
+    # a share comes back when its engine goes away
+    del gs[0]
+    import gc
+    gc.collect()
+    g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=77, populations=8)
+    g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros((8, n)))
+    for p in range(8):
+        g.set_state("fev", [10 ** 6], p)
+    g.phase(_ffi.PHASE_EIGEN)
+    assert int(g.get_state("eig_mw_reserved")[0]) == per_engine
 
 
 @pytest.mark.parametrize("n,P", [(144, 20), (256, 9), (300, 5)])
