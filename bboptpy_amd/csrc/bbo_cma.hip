@@ -648,7 +648,14 @@ void CmaEngine::launch_eigen()
 {
     const CmaConst &c = c_;
     if (c.variant == 2) return;        // diagonal covariance: d = sqrt(c) is part of sep_paths
-    const EigPlan pl = eig_plan(c.n, c.ld);
+    // 64 < n <= 128 with few matrices in flight (one optimisation run at a time): the reduction on
+    // one workgroup, the divide and conquer and the reflectors over many -- the structure of
+    // 128 < n <= 256 (diagnostic bit 4194304: everything on the reducing workgroup, as for a batch)
+    const EigPlan pl_lds = eig_plan(c.n, c.ld);
+    const bool split128 = pl_lds.use_lds && pl_lds.threads == 512 && pl_lds.dc && c.npop <= split_maxp_
+            && !(d_.dbg & (2 | 4 | 8 | 1024 | 4194304));
+    const EigPlan pl = split128 ? eig_plan_split(c.n, c.ld) : pl_lds;
+    bool wy4_packs = false;
     allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_g, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_b, 160 * 1024 - 768);
@@ -687,8 +694,12 @@ void CmaEngine::launch_eigen()
         // lane: ONE per compute unit) can be resident at once next to those of the process's other
         // engines (they wait for each other: MwBudget above, bbo_eig_mw.hpp; diagnostic bit 16777216
         // keeps the reduction on one workgroup)
-        const bool use_mw = !mw_disabled_ && !(d_.dbg & 16777216) && mw_reserve((long) c.npop * MW_G);
-        if (use_mw) {
+        const bool use_mw = !split128 && !mw_disabled_ && !(d_.dbg & 16777216) && mw_reserve((long) c.npop * MW_G);
+        if (split128) {
+            allow_lds((const void*) cma_eigen_r1, 160 * 1024 - 768);
+            hipLaunchKernelGGL(cma_eigen_r1, dim3(c.npop), dim3(512), pl_lds.lds_bytes, stream_, d_, c_,
+                    pl_lds, 0);
+        } else if (use_mw) {
             mw_launched_ = true;
             if (mw_buf_.count != (size_t) c.npop * MW_BUF_DOUBLES) mw_buf_.alloc((size_t) c.npop * MW_BUF_DOUBLES);
             // (its steps down to the leading 128 x 128 block; that block on one workgroup: diagnostic
@@ -763,9 +774,12 @@ void CmaEngine::launch_eigen()
         {
             // few matrices: a 16-column tile per WORKGROUP, its rows dealt to the four wavefronts
             // (diagnostic bit 134217728 keeps a tile per wavefront)
-            if ((long) c.npop * ((c.n + 15) / 16) <= 256 && !(d_.dbg & 134217728))
-                hipLaunchKernelGGL(cma_eig_wy4, dim3((c.n + 15) / 16, c.npop), dim3(256), 0, stream_, d_, c_);
-            else
+            if ((long) c.npop * ((c.n + 15) / 16) <= 256 && !(d_.dbg & 134217728)) {
+                // (under lazy_isc the packed operand B D leaves with B: no cma_post launch)
+                wy4_packs = c.lazy_isc != 0;
+                hipLaunchKernelGGL(cma_eig_wy4, dim3((c.n + 15) / 16, c.npop), dim3(256), 0, stream_, d_, c_,
+                        wy4_packs ? 1 : 0);
+            } else
             hipLaunchKernelGGL(cma_eig_wy, dim3((c.n + 63) / 64, c.npop), dim3(256), 0, stream_, d_,
                     c_);
         }
@@ -774,7 +788,7 @@ void CmaEngine::launch_eigen()
     timer_.begin(stream_, K_POST);
     // (lazy_isc: the eigensolver has written the packed B D itself and C^-1/2 is not formed)
     const bool packed_by_eigen = c.lazy_isc && pl.dc && pl.reg_path && !(d_.dbg & 2);
-    if (!small && !packed_by_eigen) launch_post(0);
+    if (!small && !packed_by_eigen && !wy4_packs) launch_post(0);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
 }
@@ -1069,6 +1083,19 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
         }
         return mat(isc_, n, ld, n, p * ld * ld);
     }
+    if (k == "BD") {
+        // the sampler's operand B diag(D) as the kernels hold it (MFMA B-fragment order), unpacked to
+        // n x n row-major: element (i, j) sits at tile i >> 4, k-step j >> 2, lane (j & 3, i & 15)
+        if (out && cap >= (int) (n * n)) {
+            std::vector<double> pk(ld * ld);
+            BDp_.download(pk.data(), ld * ld, p * ld * ld);
+            const size_t KS = ld >> 2;
+            for (size_t i = 0; i < n; i++)
+                for (size_t j = 0; j < n; j++)
+                    out[i * n + j] = pk[((i >> 4) * KS + (j >> 2)) * 64 + ((j & 3) << 4) + (i & 15)];
+        }
+        return (int) (n * n);
+    }
     if (k == "arx") return mat(X_, c.lambda, ld, n, (size_t) p * c.lambda_pad * ld);
     if (k == "weights") {
         if (out && cap >= c.mu) weights_.download(out, c.mu);
@@ -1140,8 +1167,11 @@ int CmaEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "fworst") return one(s.fworst);
     if (k == "eigenlastev") return one(s.eigenlastev);
     if (k == "eigen_done") return one(s.eigen_done);
+    if (k == "basis_ok") return one(s.basis_ok);
+    if (k == "eig_stage") return one(s.eig_stage);
     if (k == "eig_mw_fail") return one(s.eig_mw_fail);     // (bbo_eig_mw.hpp: sticky)
     if (k == "eig_mw_off") return one(mw_disabled_ ? 1 : 0);
+    if (k == "eig_split_maxp") return one(split_maxp_);
     if (k == "eig_mw_reserved") return one((double) mw_reserved_);       // this engine's share of the device's ...
     if (k == "eig_mw_capacity") {                                        // ... budget of spread workgroups
         MwBudget &b = MwBudget::get();
@@ -1242,6 +1272,10 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     }
     if (k == "dbg") {
         d_.dbg = (int) in[0];
+        return 1;
+    }
+    if (k == "eig_split_maxp") {   // (tuning: at most this many populations take the split 64 < n <= 128 decomposition)
+        split_maxp_ = (int) in[0];
         return 1;
     }
     if (k == "stop_off") {     // (extension) bit k silences the stop test with flag k

@@ -143,6 +143,7 @@ private:
     bool mw_disabled_ = false;
     int mw_xcd_ = next_mw_xcd();        // this engine's offset into the XCDs
     static int next_mw_xcd();
+    int split_maxp_ = 16;              // 64 < n <= 128: at most this many populations take the split decomposition
     bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;

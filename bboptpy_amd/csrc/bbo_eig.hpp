@@ -103,6 +103,26 @@ inline EigPlan eig_plan(int n, int ld)
     return pl;
 }
 
+// 64 < n <= 128 with FEW matrices in flight (round 5): the plan of the kernels BEHIND the reduction
+// when the decomposition is split over workgroups the way 128 < n <= 256 is -- the work matrix in
+// global memory (L2), the top merge external, reflectors stashed.  The reduction itself keeps the
+// LDS plan (eig_plan): its matrix lives in registers and its stash in LDS.
+inline EigPlan eig_plan_split(int n, int ld)
+{
+    EigPlan pl = eig_plan(n, ld);
+    pl.threads = EIG_THREADS;
+    pl.vl = 128 + 2;
+    pl.reg_path = 0;
+    pl.hybrid = 1;
+    pl.use_lds = 0;
+    pl.lda = (n + 31) & ~31;
+    pl.rc = 0;
+    const size_t ints = (size_t) (2 * EIG_MAXSEQ * 3 + 8) * sizeof(int);
+    const size_t vecs = ((size_t) EIG_NVEC * pl.vl + eig_part_doubles(pl.vl, false, true)) * sizeof(double);
+    pl.lds_bytes = vecs + ints + (size_t) 128 * 130 * sizeof(double);
+    return pl;
+}
+
 // Straight-line pieces of the register-resident tred2, specialised on how many 32-column
 // groups the active block still covers (a guard inside the unrolled loops would split them into
 // basic blocks and serialise the LDS reads they issue).
@@ -1203,11 +1223,20 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
     __syncthreads();
     }   // STAGE != 2, 4
     EIG_STAMP(3);
-    if (STAGE == 1) {
+    if (STAGE == 1 || STAGE == 5) {
         for (int i = tid; i < n; i += T) {
             tri[i] = dv[i];
             tri[n + i] = ev[i];
             tri[2 * n + i] = hvec[i];
+        }
+        if (STAGE == 5) {
+            // (64 < n <= 128, few matrices: the reflectors leave the LDS stash -- row i = u_i, zero
+            // from column i on -- for the place cma_eig_halves' third workgroup and cma_eig_wy4 read)
+            double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
+            for (int q = tid; q < n * n; q += T) {
+                const int r = q / n, cidx = q - r * n;
+                Vout[q] = A(r, cidx);
+            }
         }
         if (tid == 0) {
             tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
@@ -1375,6 +1404,15 @@ __global__ __launch_bounds__(512) void cma_eigen_b(CmaDev d, CmaConst c, EigPlan
 __global__ __launch_bounds__(512) void cma_eigen_g1(CmaDev d, CmaConst c, EigPlan pl, int force)
 {
     cma_eigen_impl<512, false, 1, 1>(d, c, pl, force);
+}
+// 64 < n <= 128 with few matrices in flight (round 5): the reduction alone -- matrix in registers,
+// reflector stash in LDS, 1.15 us per step: nothing spread over compute units beats it -- and the
+// hand-over to cma_eig_halves / cma_eigen_g2 / cma_eig_secular / cma_eig_gemm1 / cma_eig_wy4, which
+// put the divide and conquer and the reflectors of ONE matrix on 2, 1, n / 32, 16 and n / 16
+// workgroups where cma_eigen keeps them on the workgroup that reduced
+__global__ __launch_bounds__(512) void cma_eigen_r1(CmaDev d, CmaConst c, EigPlan pl, int force)
+{
+    cma_eigen_impl<512, true, 1, 5>(d, c, pl, force);
 }
 // 256 < n <= 512 behind a spread reduction (cma_tred_mw512 + cma_tred_tail): the divide and conquer
 // on the tridiagonal matrix they left, reflectors stashed (the top merge's products follow as
@@ -1680,8 +1718,11 @@ __global__ __launch_bounds__(256) void cma_eig_wy(CmaDev d, CmaConst c)
 // not depend on timing), every wavefront forms T_b^T W itself and updates its own row tiles.
 // Per panel 36 MFMAs per wavefront instead of 132, two barriers (the panels alternate between two
 // LDS buffers).  grid (ceil(n / 16), P), 256 threads
+// pack != 0 (lazy_isc: C^-1/2 is not formed): the sampler's packed operand B diag(D) leaves with B
+// -- element (i, j) -> column tile i >> 4, k-step j >> 2, lane (j & 3, i & 15), what cma_post would
+// re-read B for in a launch of its own
 template<int NMAX>
-__device__ __forceinline__ void eig_wy4_body(const CmaDev &d, const CmaConst &c)
+__device__ __forceinline__ void eig_wy4_body(const CmaDev &d, const CmaConst &c, int pack)
 {
     constexpr int NRT = NMAX / 64;          // row tiles per wavefront
     constexpr int CPT = NMAX / 256;         // columns of a staged panel per thread
@@ -1783,23 +1824,32 @@ __device__ __forceinline__ void eig_wy4_body(const CmaDev &d, const CmaConst &c)
         }
         __syncthreads();      // wpart and this panel's buffer are free again; the next panel is staged
     }
+    const double dcol = (pack && col < n) ? d.D[(size_t) p * ld + col] : 0.;
+    double *BDp = d.BDp + (size_t) p * ld * ld;
+    const int KS = ld >> 2;
 #pragma unroll
     for (int j = 0; j < NRT; j++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * (wave + 4 * j) + fk + 4 * r;
-            if (row < n && col < n) Bp[(size_t) row * ld + col] = q[j][r];
+            if (row < n && col < n) {
+                Bp[(size_t) row * ld + col] = q[j][r];
+                if (pack)
+                    BDp[((size_t) (row >> 4) * KS + (col >> 2)) * 64 + ((col & 3) << 4) + (row & 15)] =
+                            q[j][r] * dcol;
+            }
         }
+    if (pack && tid == 0 && blockIdx.x == 0) d.scal[p].basis_ok = 1;
 }
 
-__global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c)
+__global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c, int pack)
 {
-    eig_wy4_body<256>(d, c);
+    eig_wy4_body<256>(d, c, pack);
 }
 // 256 < n <= 512 (reflectors stashed by cma_tred_mw512 / cma_tred_tail): eight row tiles per wavefront
 __global__ __launch_bounds__(256) void cma_eig_wy4_512(CmaDev d, CmaConst c)
 {
-    eig_wy4_body<512>(d, c);
+    eig_wy4_body<512>(d, c, 0);
 }
 
 // ---------------------------------------------------------------------------

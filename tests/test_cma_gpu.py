@@ -369,6 +369,70 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
             assert np.abs(Ds[form] - Ds["one workgroup"]).max() <= 1e-12 * sc, (name, form)
 
 
+@pytest.mark.parametrize("n", [65, 66, 80, 96, 111, 127, 128])
+def test_eigensolver_forms_for_64_to_128_agree(hip, n):
+    """64 < n <= 128 has two forms (round 5): everything on the workgroup that reduced (what a batch
+    of matrices gets; diagnostic bit 4194304) and -- for a handful of matrices, one optimisation run
+    at a time -- the reduction on one workgroup, then the two halves of the torn tridiagonal matrix
+    on two, the top merge's secular equation on n / 32, its product on 2 n / 16 and the reflectors
+    on n / 16 workgroups (the kernels of 128 < n <= 256).  Different block patterns and summation
+    orders, so not the same bits: the same eigenvalues to rounding, each form's own residual and
+    orthogonality, and the sampler's packed operand B diag(D) equal to the form's own B and D bit for
+    bit (the split form packs it in the reflector kernel, the other in the eigensolver)."""
+    from bboptpy_amd import _ffi
+    rng = np.random.default_rng(n)
+    forms = {"one workgroup": 4194304, "split": 0}
+    for name, Cm in _spd_cases(n, rng):
+        Cm = 0.5 * (Cm + Cm.T)
+        sc = np.abs(np.linalg.eigvalsh(Cm)).max()
+        Ds = {}
+        for form, bit in forms.items():
+            for P in (1, 3):
+                g = hip.ActiveCMAES(mfev=10 ** 6, tol=1e-12, np=2 * n, seed=1, populations=P)
+                g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros((P, n)))
+                if bit:
+                    g.set_state("dbg", [float(bit)])
+                for p in range(P):
+                    g.set_state("C", Cm * (1. + p), p)
+                    g.set_state("fev", [10 ** 6], p)
+                    g.set_state("eigenlastev", [0], p)
+                g.phase(_ffi.PHASE_EIGEN)
+                for p in range(P):
+                    assert int(g.get_state("eigen_done", p)[0]) == 1, (name, form)
+                    assert int(g.get_state("basis_ok", p)[0]) == 1, (name, form)
+                    B, D = g.get_state("B", p).reshape(n, n), g.get_state("D", p)
+                    assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, form)
+                    assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm * (1. + p)) \
+                        <= 1e-11 * np.linalg.norm(Cm) * (1. + p), (name, form)
+                    np.testing.assert_array_equal(g.get_state("BD", p).reshape(n, n), B * D[None, :],
+                                                  err_msg="%s %s" % (name, form))
+                    if p == 0:
+                        Ds[(form, P)] = D * D
+        for key, v in Ds.items():
+            assert np.abs(v - Ds[("one workgroup", 1)]).max() <= 1e-12 * sc, (name, key)
+
+
+def test_split_decomposition_runs_generation_after_generation(hip):
+    """whole generations of ONE ActiveCMAES run at n = 128 (the single-run reading of BASELINE's
+    configs) with the split decomposition against the same run with everything on one workgroup:
+    the same trajectory to rounding, generation after generation"""
+    n, lam = 128, 256
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(8).uniform(-4, 4, n)
+    out = []
+    for bit in (0, 4194304):
+        g = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=21)
+        g.initialize(hip.objectives.ellipsoid, lo, up, guess)
+        if bit:
+            g.set_state("dbg", [float(bit)])
+        g.run(25)
+        out.append((g.get_state("xmean"), g.get_state("sigma"), g.get_state("D")))
+    (xa, sa, Da), (xb, sb, Db) = out
+    np.testing.assert_allclose(sa, sb, rtol=1e-8)
+    np.testing.assert_allclose(Da, Db, rtol=1e-7)
+    np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-7)
+
+
 def test_spread_reduction_runs_generation_after_generation(hip):
     """the multi-workgroup reduction inside whole generations at n = 256 (its flags are epochs that
     grow from launch to launch, its buffers alternate between steps): 12 generations of two
