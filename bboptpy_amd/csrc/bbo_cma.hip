@@ -551,8 +551,14 @@ void CmaEngine::launch_rank()
         // has the ranking in LDS -- a launch less per generation (10 us of the M step)
         rank_wrote_norms_ = c.variant == 1 && c.use_zn && !basis_maybe_stale_;
     } else {
-        dim3 grid((c.lambda + 31) / 32, c.npop);
-        hipLaunchKernelGGL(cma_rank, grid, dim3(256), 0, stream_, d_, c_);
+        // few candidates in flight: 8 per workgroup, 32 slices each (a quarter of the 64-bit compares
+        // per thread; diagnostic bit 128 keeps the 32-candidate form -- the same counts)
+        if ((long) c.npop * ((c.lambda + 31) / 32) <= 512 && c.lambda >= 512 && !(d_.dbg & 128))
+            hipLaunchKernelGGL(cma_rank32, dim3((c.lambda + 7) / 8, c.npop), dim3(256), 0, stream_, d_, c_);
+        else
+            hipLaunchKernelGGL(cma_rank, dim3((c.lambda + 31) / 32, c.npop), dim3(256), 0, stream_, d_, c_);
+        // (the whitened norms leave with the ranking here too: see cma_rank_body)
+        rank_wrote_norms_ = c.variant == 1 && c.use_zn && !basis_maybe_stale_;
     }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());

@@ -583,19 +583,25 @@ __global__ __launch_bounds__(512, 1) void cma_sample_eval128(CmaDev d, CmaConst 
 
 // ---------------------------------------------------------------------------
 // rank: rank[i] = #{ j : f_j < f_i  or (f_j == f_i and j < i) }, order[rank[i]] = i
-// grid (ceil(lambda/32), P), 256 threads = 32 candidates x 8 slices of the population
+// grid (ceil(lambda SL / 256), P), 256 threads = 256 / SL candidates x SL slices of the population
+// Active CMA-ES with unclamped samples and a consistent basis: the whitened norms of the worst mu
+// are the sampler's sigma^2 ||z||^2 (cma_whiten128's shortcut) and leave with the ranking -- every
+// candidate knows its rank here -- instead of through a launch of cma_whiten (round 5: 5 us of a
+// single-population generation)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
+template<int SL>
+__device__ __forceinline__ void cma_rank_body(const CmaDev &d, const CmaConst &c)
 {
     const int p = blockIdx.y;
     CmaScal *sc = d.scal + p;
     if (pop_frozen(c, sc)) return;
     __shared__ __attribute__((aligned(16))) double tile[RANK_TILE];
     const int tid = threadIdx.x;
-    const int cand = blockIdx.x * 32 + (tid >> 3), slice = tid & 7;
+    const int cand = blockIdx.x * (256 / SL) + tid / SL, slice = tid % SL;
     const double *f = d.f + (size_t) p * c.lambda_pad;
     const bool live = cand < c.lambda;
-    const int cnt = rank_by_counting(f, c.lambda, cand, slice, tile);
+    const int cnt = rank_by_counting<SL>(f, c.lambda, cand, slice, tile);
+    const bool norms = c.variant == 1 && c.use_zn && sc->basis_ok;
     if (live && slice == 0) {
         const double fi = f[cand];
         d.rank[(size_t) p * c.lambda_pad + cand] = cnt;
@@ -604,8 +610,22 @@ __global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
         if (cnt == 1) { sc->ibw[1] = cand; sc->ybw[1] = fi; }
         if (cnt == c.lambda - 2) { sc->ibw[2] = cand; sc->ybw[2] = fi; }
         if (cnt == c.lambda - 1) { sc->ibw[3] = cand; sc->ybw[3] = fi; }
+        if (norms && cnt >= c.lambda - c.mu)
+            d.S[(size_t) p * c.mu_pad + cnt - (c.lambda - c.mu)] =
+                    sc->sigma * sc->sigma * d.zn2[(size_t) p * c.lambda_pad + cand];
     }
+    if (norms && blockIdx.x == 0)
+        for (int wr = c.mu + tid; wr < c.mu_pad; wr += 256) d.S[(size_t) p * c.mu_pad + wr] = 0.;
     if (blockIdx.x == 0 && tid == 0) sc->fev += c.lambda;   // base_cmaes.cpp:218
+}
+
+__global__ __launch_bounds__(256) void cma_rank(CmaDev d, CmaConst c)
+{
+    cma_rank_body<8>(d, c);
+}
+__global__ __launch_bounds__(256) void cma_rank32(CmaDev d, CmaConst c)
+{
+    cma_rank_body<32>(d, c);
 }
 
 // the same ranking by one in-LDS sort per population (lambda <= SORT_LDS_MAX): merge sort by

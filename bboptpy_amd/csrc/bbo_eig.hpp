@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
         // per-population global scratch: [work matrix | Q_house | F | Q F], eig_slab(ld) each
         double *Gp = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
         double *Bp_ = d.B + (size_t) p * ld * ld;
-        long long *st_ = (d.stamps && p == 0) ? d.stamps : nullptr;
+        long long *st_ = (d.stamps && p == 0 && !(STAGE == 2 && (d.dbg & 2048))) ? d.stamps : nullptr;
         if (LDSM || HYB || TT != EIG_THREADS) {
             // n <= 256: the reflectors are stashed (hv = 1 / their scalars)
             eig_dc_phase<TT, false, !LDSM>(Qm, n, dv, ev, Gp, Bp_, ld, scr, st_, d.dbg, LDSM ? 0 : 1, hvec,
@@ -1510,7 +1510,10 @@ __global__ __launch_bounds__(512) void cma_eig_halves(CmaDev d, CmaConst c, EigP
     const size_t mm = (size_t) (n - mid) * (n - mid);
     double *G = base + slab + (size_t) n * n + (size_t) h * 2 * mm;
     double *Bout = base + (size_t) off * lda_work + off;
-    eig_dc_phase<512, false, false>(Qm, m, dv, ev, G, Bout, lda_work, uv, nullptr, d.dbg, 0, nullptr,
+    // (diagnostic bit 2048: the phase clocks show the FIRST HALF's leaves and merges, the top merge
+    // behind it keeps its hands off them)
+    eig_dc_phase<512, false, false>(Qm, m, dv, ev, G, Bout, lda_work, uv,
+            (d.stamps && p == 0 && h == 0 && (d.dbg & 2048)) ? d.stamps : nullptr, d.dbg, 0, nullptr,
             true, nullptr, 1);
     // the rest of this half's rows of the work matrix: the other half's columns are zero
     const int c0 = h ? 0 : mid, cw = h ? mid : n - mid;

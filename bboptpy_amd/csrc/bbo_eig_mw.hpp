@@ -79,6 +79,12 @@ constexpr int MW_G = 8;                 // workgroups per matrix of n <= 256 (NM
 constexpr int MW_T = 256;               // threads per workgroup: 32 rows x 8 lanes
 constexpr long long MW_TIMEOUT_TICKS = 5000000;     // of wall_clock64() (100 MHz): 50 ms
 constexpr int MW_WAVES = MW_T / 64;
+// (variant builds for A/B timing: scripts/build_variant.sh)
+#ifdef MW_NO_FENCE
+#define MW_CFENCE() do { } while (0)
+#else
+#define MW_CFENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
+#endif
 #ifndef MW_POLL_SLEEP
 #define MW_POLL_SLEEP 1
 #endif
@@ -185,7 +191,11 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
     // -- not reachable through bbo_set: workgroup 3 walks away, at entry (0) or after taking part in
     // k steps (k > 0) -- what the others do about a partner that stops publishing is tested, not
     // assumed: tests/test_cma_gpu.py)
+#ifdef MW_NO_FAULT
+    const int fault_step = -1;
+#else
     const int fault_step = g == 3 ? d.mw_fault : -1;
+#endif
     if (fault_step == 0) return;
     __shared__ __attribute__((aligned(16))) double ubuf[4][NMAX];
     __shared__ __attribute__((aligned(16))) double wbuf[4][NMAX];
@@ -303,10 +313,10 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
 #pragma unroll
             for (int v = 0; v < NV; v++) mw_store_d(rbuf + NMAX * par + lane + 64 * v, wb[lane + 64 * v]);
         }
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        MW_CFENCE();
         __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores are out (and its loads of
                                                 // the step before: the buffers alternate)
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        MW_CFENCE();
         // the LAST wavefront of this workgroup to get here raises the workgroup's flag (an LDS
         // count, no barrier: nobody waits inside the workgroup)
         if (lane == 0) {
@@ -321,7 +331,15 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
             while (true) {
                 const unsigned long long fl = lane < G ? mw_load(flags + MW_FLAG_STRIDE * lane) : epoch;
                 if (__ballot(fl < epoch) == 0ull) break;
+#ifdef MW_OLD_SPIN
+                if (++spins >= (1 << 21)) {
+                    failed = true;
+                    break;
+                }
+                if (false) {
+#else
                 if ((++spins & 1023) == 0) {
+#endif
                     const long long now = (long long) wall_clock64();
                     if (t_wait == 0) t_wait = now;
                     else if (now - t_wait > MW_TIMEOUT_TICKS) {
@@ -333,7 +351,7 @@ __device__ __forceinline__ void tred_mw_body(const CmaDev &d, const CmaConst &c,
             }
         }
         if (failed) break;
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);      // (the data loads stay behind the poll)
+        MW_CFENCE();                                  // (the data loads stay behind the poll)
         MW_CK(2);
         // (only the lanes inside the active block ask: measured against eight unconditional loads
         // per lane, 1071 against 1170 us per decomposition -- the requests are served on the memory

@@ -13,8 +13,12 @@ namespace bbo {
 constexpr int RANK_TILE = 2048;   // doubles per LDS tile (16 KiB)
 
 // f: fitness of `count` candidates; cand: this thread's candidate (may be >= count);
-// slice: 0..7; tile: __shared__ double[RANK_TILE].  Returns the rank in every lane of the
-// 8-lane group (valid when cand < count).  All 256 threads of the workgroup must call it.
+// slice: 0..SL-1; tile: __shared__ double[RANK_TILE].  Returns the rank in every lane of the
+// SL-lane group (valid when cand < count).  All 256 threads of the workgroup must call it.
+// SL = 8: 32 candidates per workgroup; SL = 32 (one population at a time, round 5: the compares are
+// 64-bit and one wavefront per SIMD issues them -- 512 per thread took 29 us at lambda = 4096 while
+// most of the chip idled): 8 candidates per workgroup, a quarter of the compares per thread.
+template<int SL = 8>
 __device__ inline int rank_by_counting(const double *f, int count, int cand, int slice,
         double *tile)
 {
@@ -27,10 +31,10 @@ __device__ inline int rank_by_counting(const double *f, int count, int cand, int
         for (int q = tid; q < RANK_TILE; q += 256)
             tile[q] = q < len ? f[base + q] : __builtin_huge_val();
         __syncthreads();
-        // lane `slice` reads the pairs (2 slice, 2 slice + 1) + 16 t: 8 lanes cover 16
-        // consecutive doubles, the 8 candidate groups of a wavefront read the same addresses
-        const int lenp = (len + 15) & ~15;
-        for (int q = 2 * slice; q < lenp; q += 16) {
+        // lane `slice` reads the pairs (2 slice, 2 slice + 1) + 2 SL t: the SL lanes of a group cover
+        // 2 SL consecutive doubles, the candidate groups of a wavefront read the same addresses
+        const int lenp = (len + 2 * SL - 1) & ~(2 * SL - 1);
+        for (int q = 2 * slice; q < lenp; q += 2 * SL) {
             const double2 v = *reinterpret_cast<const double2*>(&tile[q]);
             const int j = base + q;
             cnt += (v.x < fi) || (v.x == fi && j < cand);
@@ -38,7 +42,7 @@ __device__ inline int rank_by_counting(const double *f, int count, int cand, int
         }
     }
 #pragma unroll
-    for (int off = 4; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 8);
+    for (int off = SL / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, SL);
     return cnt;
 }
 

@@ -7,6 +7,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bboptpy_amd import _ffi   # noqa: E402
+if os.environ.get("BBO_LIB"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["BBO_LIB"])
 import bboptpy_amd as bb   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
