@@ -481,7 +481,7 @@ void CmaEngine::launch_sample_eval()
         c_.use_zn = 0;
         return;
     }
-    if (c.ld == 128 && (long) c.npop * c.lambda_pad >= 256 * 128
+    if (c.ld == 128 && (long) c.npop * c.lambda_pad >= sample128_min_rows_
             && (c.obj < 0 || frag_objective_ok(c.obj))) {
         // whole populations in flight: packed operand in LDS, normals drawn into the A fragments
         // one workgroup per CU when the populations allow it: long tile loops amortise the fill
@@ -494,6 +494,14 @@ void CmaEngine::launch_sample_eval()
                 && !d_.zrecord && !(d_.dbg & 256)) ? 1 : 0;
         hipLaunchKernelGGL(cma_sample_eval128, grid, dim3(512), 128 * 1024, stream_, d_, c_, rw,
                 full);
+        zn_valid = true;
+    } else if (c.ld == 128 && (long) c.npop * (c.lambda_pad / 16) <= sample_wide_max_tiles_) {
+        // one population at a time: a 16-row tile per WORKGROUP, one column tile per wavefront (the
+        // form C5's handful of candidates takes at n = 256) -- a wavefront's chain is 32 MFMAs and
+        // one Philox call instead of 256 and eight
+        const size_t lds = (size_t) 16 * (c.ld + 2) * sizeof(double);
+        hipLaunchKernelGGL((cma_sample_eval<1, 8>), dim3(c.lambda_pad / 16, c.npop), dim3(512), lds, stream_,
+                d_, c_);
         zn_valid = true;
     } else if (c.ld <= 128) {
         // 64 candidates per workgroup, packed operand held in registers
@@ -1278,6 +1286,14 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
     }
     if (k == "dbg") {
         d_.dbg = (int) in[0];
+        return 1;
+    }
+    if (k == "sample_wide_max") {  // (tuning: at most this many 16-row tiles take the tile-per-workgroup sampler)
+        sample_wide_max_tiles_ = (long) in[0];
+        return 1;
+    }
+    if (k == "sample128_min") {    // (tuning: candidates in flight from which cma_sample_eval128 draws)
+        sample128_min_rows_ = (long) in[0];
         return 1;
     }
     if (k == "eig_split_maxp") {   // (tuning: at most this many populations take the split 64 < n <= 128 decomposition)

@@ -143,6 +143,8 @@ private:
     bool mw_disabled_ = false;
     int mw_xcd_ = next_mw_xcd();        // this engine's offset into the XCDs
     static int next_mw_xcd();
+    long sample_wide_max_tiles_ = 512;       // n = 128: at most this many 16-row tiles take cma_sample_eval<1, 8>
+    long sample128_min_rows_ = 256 * 128;   // candidates in flight from which cma_sample_eval128 is used
     int split_maxp_ = 16;              // 64 < n <= 128: at most this many populations take the split decomposition
     bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;

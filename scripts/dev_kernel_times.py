@@ -27,6 +27,9 @@ g = np.random.default_rng(0).uniform(-10, 10, (P, n))
 alg.initialize(getattr(bb.objectives, obj), -10 * np.ones(n), 10 * np.ones(n), g)
 if dbg:
     alg.set_state("dbg", [float(dbg)])
+for kv in os.environ.get("BBO_SET", "").split(","):      # e.g. BBO_SET=sample128_min=1024,eig_split_maxp=4
+    if "=" in kv:
+        alg.set_state(kv.split("=")[0], [float(kv.split("=")[1])])
 alg.run(10)
 t = time.perf_counter()
 d = alg.run(gens)

@@ -412,6 +412,34 @@ def test_eigensolver_forms_for_64_to_128_agree(hip, n):
             assert np.abs(v - Ds[("one workgroup", 1)]).max() <= 1e-12 * sc, (name, key)
 
 
+@pytest.mark.parametrize("lam,obj", [(256, "rosenbrock"), (1024, "ellipsoid"), (200, "rastrigin")])
+def test_single_run_sampler_and_ranking_equal_the_batch_kernels(hip, lam, obj):
+    """one population at a time (round 5) takes kernels of its own at n = 128: a 16-row tile per
+    workgroup in the sampler (one column tile per wavefront) and 32 slices per candidate in the
+    counting rank, which also hands down the whitened norms.  Same normals, same products in the
+    same order, same counts: X, f, ||z||^2-derived S and the ranking equal the other kernels' bit
+    for bit (tuning keys sample_wide_max = 0 and diagnostic bit 128 select those)."""
+    from bboptpy_amd import _ffi
+    n = 128
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    guess = np.random.default_rng(5).uniform(-4, 4, n)
+    out = []
+    for wide in (True, False):
+        g = hip.ActiveCMAES(mfev=10 ** 9, tol=0., np=lam, seed=33)
+        g.initialize(getattr(hip.objectives, obj), lo, up, guess)
+        if not wide:
+            g.set_state("sample_wide_max", [0.])
+            g.set_state("dbg", [128.])
+        for _ in range(3):
+            g.iterate()
+        g.phase(_ffi.PHASE_SAMPLE_EVALUATE)
+        g.phase(_ffi.PHASE_RANK)
+        g.phase(_ffi.PHASE_UPDATE)
+        out.append({k: g.get_state(k).copy() for k in ("arx", "fitness", "fit_idx", "xmean", "sigma", "C", "ps")})
+    for k in out[0]:
+        np.testing.assert_array_equal(out[0][k], out[1][k], err_msg=k)
+
+
 def test_split_decomposition_runs_generation_after_generation(hip):
     """whole generations of ONE ActiveCMAES run at n = 128 (the single-run reading of BASELINE's
     configs) with the split decomposition against the same run with everything on one workgroup:
