@@ -57,6 +57,12 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     c.tol = params_.tol;
     c.seed = params_.seed;
     parts_ = std::max(1, std::min(256, c.np / 64));
+    {   // up to 16 refreshes of the swarm's best per generation, chunks of at least 64 particles
+        // (multiples of 16: whole workgroups); a swarm of up to 64 moves in one piece
+        const int nchunks = std::min(16, (c.np + 63) / 64);
+        chunk_ = ((c.np + nchunks - 1) / nchunks + 15) / 16 * 16;
+        if (nchunks <= 1) chunk_ = c.np;
+    }
 
     const size_t rows = (size_t) P * c.np, ld = c.ld;
     X_.alloc(rows * ld);
@@ -122,20 +128,23 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     BBO_HIP(hipStreamSynchronize(stream_));
 }
 
-void PsoEngine::host_evaluate_swarm()
+// the particles [i0, i1) of every population through the host objective (i1 < 0: the whole swarm)
+void PsoEngine::host_evaluate_swarm(int i0, int i1)
 {
     const PsoConst &c = c_;
+    if (i1 < 0) i1 = c.np;
+    const int cnt = i1 - i0;
     BBO_HIP(hipStreamSynchronize(stream_));
     std::vector<PsoScal> sc(c.npop);
     scal_.download(sc.data(), c.npop);
-    std::vector<double> xh((size_t) c.np * c.ld), fh(c.np);
+    std::vector<double> xh((size_t) cnt * c.ld), fh(cnt);
     for (int p = 0; p < c.npop; p++) {
         if (c.honor_stop && sc[p].stop) continue;
-        X_.download(xh.data(), xh.size(), (size_t) p * c.np * c.ld);
-        obj_.eval_host(xh.data(), c.np, c.n, c.ld, fh.data());
+        X_.download(xh.data(), xh.size(), ((size_t) p * c.np + i0) * c.ld);
+        obj_.eval_host(xh.data(), cnt, c.n, c.ld, fh.data());
         for (auto &v : fh)
             if (v != v) v = std::numeric_limits<double>::infinity();
-        f_.upload(fh.data(), c.np, (size_t) p * c.np);
+        f_.upload(fh.data(), cnt, (size_t) p * c.np + i0);
     }
 }
 
@@ -190,16 +199,24 @@ void PsoEngine::generation(bool honor_stop)
     hipLaunchKernelGGL(pso_control_b, dim3(P), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
+    // the swarm moves in chunks of chunk_ particles, the best refreshed between them: what the
+    // reference's in-loop refresh (apso.cpp:194-197) buys at large np (one chunk = the generation-
+    // synchronous form of rounds 1-4: every particle sees the best of the generation start)
     timer_.begin(stream_, K_UPDATE);
-    hipLaunchKernelGGL(pso_update, dim3((c.np + R - 1) / R, P), dim3(16 * R), ldsR, stream_, d_,
-            c_);
+    const int step = chunk_ > 0 && chunk_ < c.np ? chunk_ : c.np;
+    for (int i0 = 0; i0 < c.np; i0 += step) {
+        const int i1 = std::min(c.np, i0 + step);
+        hipLaunchKernelGGL(pso_update, dim3((i1 - i0 + R - 1) / R, P), dim3(16 * R), ldsR, stream_, d_,
+                c_, i0, i1);
+        if (!obj_.on_device()) {
+            host_evaluate_swarm(i0, i1);
+            hipLaunchKernelGGL(pso_pbest, dim3((i1 - i0 + 15) / 16, P), dim3(256), 0, stream_, d_, c_, i0,
+                    i1);
+        }
+        if (i1 < c.np) hipLaunchKernelGGL(pso_gbest, dim3(P), dim3(256), 0, stream_, d_, c_, i0, i1);
+    }
     timer_.end(stream_);
     BBO_HIP(hipGetLastError());
-    if (!obj_.on_device()) {
-        host_evaluate_swarm();
-        hipLaunchKernelGGL(pso_pbest, g16, dim3(256), 0, stream_, d_, c_);
-        BBO_HIP(hipGetLastError());
-    }
     timer_.begin(stream_, K_FINISH);
     hipLaunchKernelGGL(pso_finish, dim3(P), dim3(256), 0, stream_, d_, c_);
     timer_.end(stream_);
@@ -350,6 +367,7 @@ int PsoEngine::get(const std::string &k, int p, double *out, int cap)
     if (k == "maxit") return one(s.maxit);
     if (k == "fev") return one(s.fev);
     if (k == "np") return one(c.np);
+    if (k == "chunk") return one(chunk_);      // particles between two refreshes of the swarm's best
     if (k == "evof") return one(s.evof);
     if (k == "stop") return one(s.stop);
     if (k == "conv") return one(s.conv);
@@ -365,6 +383,10 @@ int PsoEngine::set(const std::string &k, int p, const double *in, int count)
     BBO_HIP(hipSetDevice(params_.device));
     BBO_HIP(hipStreamSynchronize(stream_));
     const PsoConst &c = c_;
+    if (k == "chunk") {        // 0 or >= np: the whole swarm sees the best of the generation start
+        chunk_ = (int) in[0] <= 0 ? c.np : (int) in[0];
+        return 1;
+    }
     if (k == "profile") {
         timer_.enable(in[0] != 0., K_COUNT);
         return 1;

@@ -71,7 +71,7 @@ public:
 
 private:
     void generation(bool honor_stop);
-    void host_evaluate_swarm();
+    void host_evaluate_swarm(int i0 = 0, int i1 = -1);
     void host_evaluate_elite();
     bool all_stopped();
 
@@ -82,6 +82,7 @@ private:
     hipStream_t stream_ = nullptr;
     bool inited_ = false;
     int parts_ = 1;
+    int chunk_ = 0;           // particles between two refreshes of the swarm's best inside a generation
     std::vector<double> aux_h_;
     DevBuf<double> colpart2_, rowpart2_, Xc_;
     DevBuf<double> X_, V_, XB_, f_, fb_, xbest_, ws_, mean_, nrm_, pvec_, radius_, colpart_,

@@ -640,19 +640,23 @@ __global__ __launch_bounds__(256) void pso_control_b(PsoDev d, PsoConst c)
 }
 
 // ---------------------------------------------------------------------------
-// fused particle update.  grid (ceil(np/16), P), 256 threads, LDS 16 * ld doubles
+// fused particle update of the particles [i0, i1).  grid (ceil((i1 - i0) / R), P), 16 R threads,
+// LDS R * ld doubles.  A generation is a handful of such launches with the swarm's best refreshed
+// in between (pso_gbest): the reference refreshes it inside its particle loop (apso.cpp:194-197),
+// and at np in the thousands a swarm that only sees the best of the generation START converges
+// measurably slower ("APSO: chunked refresh"; tests/test_pop_bands_gpu.py)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pso_update(PsoDev d, PsoConst c)
+__global__ __launch_bounds__(256) void pso_update(PsoDev d, PsoConst c, int i0, int i1)
 {
     const int p = blockIdx.y;
     const PsoScal *sc = d.scal + p;
     if (pso_frozen(c, sc)) return;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld, n = c.n;
-    const bool live = i < c.np;
+    const int i = i0 + blockIdx.x * (blockDim.x >> 4) + r, ld = c.ld, n = c.n;
+    const bool live = i < i1;
     double *row = lds + r * ld;
-    const size_t base = ((size_t) p * c.np + i) * ld;
+    const size_t base = ((size_t) p * c.np + (live ? i : i0)) * ld;
     const double *gb = d.xbest + (size_t) p * ld;
     const double w = sc->w, c1 = sc->c1, c2 = sc->c2;
     const int it = sc->it;
@@ -709,15 +713,15 @@ __global__ __launch_bounds__(256) void pso_update(PsoDev d, PsoConst c)
     }
 }
 
-// host-objective path: pbest update from the uploaded fitness
-__global__ __launch_bounds__(256) void pso_pbest(PsoDev d, PsoConst c)
+// host-objective path: pbest update of the particles [i0, i1) from the uploaded fitness
+__global__ __launch_bounds__(256) void pso_pbest(PsoDev d, PsoConst c, int i0, int i1)
 {
     const int p = blockIdx.y;
     const PsoScal *sc = d.scal + p;
     if (pso_frozen(c, sc)) return;
     const int tid = threadIdx.x, r = tid >> 4, g = tid & 15;
-    const int i = blockIdx.x * 16 + r;
-    if (i >= c.np) return;
+    const int i = i0 + blockIdx.x * 16 + r;
+    if (i >= i1) return;
     const size_t base = ((size_t) p * c.np + i) * c.ld;
     const double f = d.f[(size_t) p * c.np + i], fb = d.fb[(size_t) p * c.np + i];
     if (f < fb) {
@@ -726,6 +730,34 @@ __global__ __launch_bounds__(256) void pso_pbest(PsoDev d, PsoConst c)
                     *reinterpret_cast<const double2*>(&d.X[base + 2 * pj]);
         if (g == 0) d.fb[(size_t) p * c.np + i] = f;
     }
+}
+
+// the swarm's best after the particles [i0, i1) have moved: arg-min of their new fitness (lowest
+// index on ties, as the reference's loop meets them), taken over if it beats the best so far.
+// One workgroup of 256 per population.  (pso_finish repeats the scan over the whole swarm at the
+// end of the generation; after these refreshes it finds nothing new.)
+__global__ __launch_bounds__(256) void pso_gbest(PsoDev d, PsoConst c, int i0, int i1)
+{
+    const int p = blockIdx.x;
+    PsoScal *sc = d.scal + p;
+    if (pso_frozen(c, sc)) return;
+    __shared__ double sval[4];
+    __shared__ int sidx[4];
+    const int tid = threadIdx.x, np = c.np, ld = c.ld;
+    const double *f = d.f + (size_t) p * np;
+    double fv = PSO_INF;
+    int ib = 0x7fffffff;
+    for (int i = i0 + tid; i < i1; i += 256)
+        if (f[i] < fv) {
+            fv = f[i];
+            ib = i;
+        }
+    pso_block_arg<1>(fv, ib, sval, sidx);
+    const bool improved = ib != 0x7fffffff && fv < sc->fbest;
+    if (improved)
+        for (int j = tid; j < ld; j += 256)
+            d.xbest[(size_t) p * ld + j] = d.X[((size_t) p * np + ib) * ld + j];
+    if (improved && tid == 0) sc->fbest = fv;
 }
 
 // gbest arg-min over the new fitness, stop test, counters.  One workgroup of 256 per population

@@ -179,6 +179,9 @@ class _Lib:
                 f("zig_strip").argtypes = [C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
                 f("zig_strip").restype = C.c_int
+            if hasattr(L, p + "apso_set_chunk"):
+                f("apso_set_chunk").argtypes = [C.c_void_p, C.c_int]
+                f("apso_set_chunk").restype = None
             if hasattr(L, p + "pop_set_mode"):
                 f("pop_set_mode").argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
                 f("pop_set_mode").restype = None
@@ -275,6 +278,11 @@ class Handle:
         else:
             kind = {"apso": 1, "sansde": 2, "cso": 3, "ccpso": 4}.get(self.alg, 0)
             self.lib.f("pop_set_mode")(self.ptr, kind, 1 if sync else 0, rng_mode, seed)
+
+    def set_chunk(self, chunk):
+        """APSO, sync mode (oracle only): particles between two refreshes of the swarm's best inside
+        a generation -- what the device's `chunk` state key reports (0: the whole swarm)"""
+        self.lib.f("apso_set_chunk")(self.ptr, int(chunk))
 
     def rset(self, key, value):
         """restart drivers (oracle only): overwrite one bookkeeping field"""

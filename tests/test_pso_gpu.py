@@ -27,6 +27,7 @@ def _close(a, b, rtol, what):
     (33, 70, "sphere", True),         # odd n, np not a multiple of 16 or 64
     (16, 64, "ackley", False),
     (64, 130, "griewank", True),
+    (24, 1100, "rosenbrock", True),   # 16 refreshes of the swarm's best per generation (chunks of 80)
     # rows of more than 512 doubles: 8 / 4 particles per workgroup (rows_per_wg16)
     (513, 40, "sphere", True),
     (1024, 24, "rastrigin", True),
@@ -40,6 +41,10 @@ def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
     o.set_mode(True, po.RNG_PHILOX, seed)
     g.initialize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
     o.init(obj, lo, up, np.zeros(n))
+    # (the swarm moves in chunks with the best refreshed in between: the oracle is told the chunk)
+    chunk = int(g.get_state("chunk")[0])
+    assert chunk == np_ if np_ <= 64 else (chunk % 16 == 0 and np_ / 16 <= chunk < np_)
+    o.set_chunk(chunk)
     np.testing.assert_array_equal(g.get_state("x"), o.get("x"))   # same Philox words
     _close(g.get_state("f"), o.get("f"), 1e-12, "init f")
     _close(g.get_state("fbest"), o.get("fbest"), 1e-12, "init fbest")
@@ -60,7 +65,7 @@ def test_generations_match_sync_oracle(hip, oracle_lib, n, np_, obj, correct):
         _close(g.get_state("f"), o.get("f"), 1e-10, tag + " f")
         _close(g.get_state("xbest"), o.get("xbest"), 1e-11, tag + " gbest")
         _close(g.get_state("fbest"), o.get("fbest"), 1e-10, tag + " fbest")
-    if n <= 512:
+    if n <= 512 and np_ < 1000:
         assert len(set(states)) >= 2   # the fuzzy state machine actually moved
 
 
@@ -95,6 +100,43 @@ def test_mean_distance_matches_numpy(hip, n, np_):
     assert np.abs(ws[rows] - direct).max() <= 1e-11 * direct.max()
 
 
+def test_chunk_of_the_whole_swarm_is_the_synchronous_form(hip, oracle_lib):
+    """bbo_set "chunk" 0: every particle sees the best of the generation start (rounds 1-4); the
+    oracle's sync mode without a chunk is that form"""
+    n, np_, seed = 12, 200, 7
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    g = hip.APSO(mfev=10 ** 7, tol=1e-12, np=np_, seed=seed)
+    o = po.apso(oracle_lib, 10 ** 7, 1e-12, np_)
+    o.set_mode(True, po.RNG_PHILOX, seed)
+    g.initialize(hip.objectives.rosenbrock, lo, up, np.zeros(n))
+    g.set_state("chunk", [0.])
+    assert int(g.get_state("chunk")[0]) == np_
+    o.init("rosenbrock", lo, up, np.zeros(n))
+    for gen in range(10):
+        g.iterate()
+        o.iterate()
+        _close(g.get_state("x"), o.get("x"), 1e-11, "gen %d x" % gen)
+        _close(g.get_state("xbest"), o.get("xbest"), 1e-11, "gen %d gbest" % gen)
+
+
+def test_python_objective_sees_the_same_chunks(hip):
+    """a Python callable and the built-in objective of the same function: the same swarm after
+    every generation (the host path evaluates chunk by chunk, the best refreshed in between)"""
+    n, np_, seed = 6, 150, 3
+    lo, up = -5. * np.ones(n), 5. * np.ones(n)
+    a = hip.APSO(mfev=10 ** 7, tol=1e-12, np=np_, seed=seed)
+    b = hip.APSO(mfev=10 ** 7, tol=1e-12, np=np_, seed=seed)
+    a.initialize(hip.objectives.sphere, lo, up, np.zeros(n))
+    b.initialize(lambda x: float(np.sum(np.asarray(x) ** 2)), lo, up, np.zeros(n))
+    assert int(a.get_state("chunk")[0]) == int(b.get_state("chunk")[0]) == 64   # three chunks: 64, 64, 22
+    for gen in range(8):
+        a.iterate()
+        b.iterate()
+        _close(a.get_state("x"), b.get_state("x"), 1e-12, "gen %d x" % gen)
+        _close(a.get_state("xbest"), b.get_state("xbest"), 1e-12, "gen %d gbest" % gen)
+        assert int(a.get_state("fev")[0]) == int(b.get_state("fev")[0])
+
+
 def test_apso_solves_sphere(hip):
     n = 8
     alg = hip.APSO(mfev=200000, tol=1e-6, np=40, seed=3)
@@ -124,6 +166,7 @@ def test_whole_run_same_seed_matches_oracle(hip, oracle_lib, obj, seed):
     sol = g.optimize(getattr(hip.objectives, obj), lo, up, np.zeros(n))
     o = po.apso(oracle_lib, 60000, 1e-8, 30)
     o.set_mode(True, po.RNG_PHILOX, seed)
+    o.set_chunk(30)
     xo, fevo, convo = o.optimize(obj, lo, up, np.zeros(n))
     assert sol.n_evals == fevo and sol.converged == convo
     np.testing.assert_allclose(sol.x, xo, rtol=0, atol=1e-8)
