@@ -66,6 +66,28 @@ bbo::ObjectiveSpec to_spec(const bbo_objective *o)
 
 } // namespace
 
+#include <dlfcn.h>
+namespace bbo {
+const Roctx &Roctx::get()
+{
+    static const Roctx r = [] {
+        Roctx x;
+        for (const char *lib : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4",
+                "libroctx64.so" }) {
+            void *h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            x.push = reinterpret_cast<Roctx::push_fn>(dlsym(h, "roctxRangePushA"));
+            x.pop = reinterpret_cast<Roctx::pop_fn>(dlsym(h, "roctxRangePop"));
+            if (x.push && x.pop) break;
+            x.push = nullptr;
+            x.pop = nullptr;
+        }
+        return x;
+    }();
+    return r;
+}
+} // namespace bbo
+
 extern "C" {
 
 void bbo_params_default(bbo_params *p, int algo)

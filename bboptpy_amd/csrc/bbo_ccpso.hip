@@ -10,6 +10,7 @@ namespace bbo {
 
 namespace {
 enum { K_REGROUP = 0, K_EVAL, K_UPDATE, K_POSITION, K_FINISH, K_COUNT };
+static const char *const K_NAMES[K_COUNT] = { "bbo:ccp_regroup", "bbo:ccp_eval", "bbo:ccp_update", "bbo:ccp_position", "bbo:ccp_finish" };   // roctx ranges, bench.py's slot names
 }
 
 CcpsoEngine::CcpsoEngine(const bbo_params &p) :
@@ -637,7 +638,7 @@ int CcpsoEngine::set(const std::string &k, int p, const double *in, int count)
     if (!inited_) throw Error(BBO_ERR_STATE, "set() before initialize()");
     BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
     if (k == "profile") {
-        timer_.enable(in[0] != 0., K_COUNT);
+        timer_.enable(in[0] != 0., K_COUNT, K_NAMES);
         return 1;
     }
     // what a host-side local search (ccpso.cpp:371-435; the Python class drives it) hands back:

@@ -20,6 +20,7 @@ namespace {
 
 // kernel slots of the profile report (bbo_get "profile"), in launch order
 enum { K_SAMPLE = 0, K_RANK, K_WHITEN, K_GRAM, K_PATHS, K_COV, K_EIGEN, K_POST, K_STOP, K_COUNT };
+static const char *const K_NAMES[K_COUNT] = { "bbo:cma_sample_eval", "bbo:cma_rank", "bbo:cma_whiten", "bbo:cma_gram", "bbo:cma_paths", "bbo:cma_cov", "bbo:cma_eigen", "bbo:cma_post", "bbo:cma_history_stop" };   // roctx ranges, bench.py's slot names
 
 int pick_maxt(int ld)
 {
@@ -1281,7 +1282,7 @@ int CmaEngine::set(const std::string &k, int p, const double *in, int count)
         return r;
     }
     if (k == "profile") {
-        timer_.enable(in[0] != 0., K_COUNT);
+        timer_.enable(in[0] != 0., K_COUNT, K_NAMES);
         return 1;
     }
     if (k == "dbg") {

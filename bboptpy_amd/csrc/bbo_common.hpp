@@ -88,6 +88,19 @@ struct DevBuf {
 // Per-kernel device timing with HIP events on the engine's own stream (bench.py's
 // roofline leg): disabled by default; when enabled every launch is bracketed by an event
 // pair, collect() (after a stream sync) folds the elapsed times into per-kernel totals.
+// roctx ranges: with the `profile` switch on, every phase of a generation is also
+// a named range on the host thread -- rocprofv3 --marker-trace shows "bbo:cma_eigen" over the
+// launches it brackets.  The marker library is looked up at run time (libroctx64 / the
+// rocprofiler-sdk one, whichever the process finds): the product links against nothing it may
+// not find on a box, and without the library the ranges are simply not emitted.
+struct Roctx {
+    using push_fn = int (*)(const char*);
+    using pop_fn = int (*)();
+    push_fn push = nullptr;
+    pop_fn pop = nullptr;
+    static const Roctx &get();
+};
+
 class KernelTimer {
 public:
     ~KernelTimer()
@@ -97,9 +110,11 @@ public:
             (void) hipEventDestroy(e.b);
         }
     }
-    void enable(bool on, int nslots)
+    // names: one static string per slot ("bbo:<phase>") for the roctx ranges, or null
+    void enable(bool on, int nslots, const char *const *names = nullptr)
     {
         on_ = on;
+        names_ = names;
         ms_.assign(nslots, 0.);
         calls_.assign(nslots, 0);
         used_ = 0;
@@ -108,6 +123,10 @@ public:
     void begin(hipStream_t st, int slot)
     {
         if (!on_) return;
+        if (names_ && Roctx::get().push) {
+            Roctx::get().push(names_[slot]);
+            open_ = true;
+        }
         if (used_ == pool_.size()) {
             Pair p;
             BBO_HIP(hipEventCreate(&p.a));
@@ -122,6 +141,10 @@ public:
         if (!on_) return;
         BBO_HIP(hipEventRecord(pool_[used_].b, st));
         used_++;
+        if (open_) {
+            Roctx::get().pop();
+            open_ = false;
+        }
     }
     void collect()   // call after the stream has been synchronised
     {
@@ -150,6 +173,8 @@ private:
     std::vector<long> calls_;
     size_t used_ = 0;
     bool on_ = false;
+    bool open_ = false;
+    const char *const *names_ = nullptr;
 };
 
 // Raises a kernel's dynamic-LDS ceiling (hipFuncAttributeMaxDynamicSharedMemorySize), once

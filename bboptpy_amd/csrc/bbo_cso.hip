@@ -11,6 +11,7 @@ namespace bbo {
 
 namespace {
 enum { K_MEAN = 0, K_SHUFFLE, K_GROUPS, K_COMPETE, K_FINISH, K_COUNT };
+static const char *const K_NAMES[K_COUNT] = { "bbo:cso_mean", "bbo:cso_shuffle", "bbo:cso_groups", "bbo:cso_compete", "bbo:cso_finish" };   // roctx ranges, bench.py's slot names
 }
 
 CsoEngine::CsoEngine(const bbo_params &p) :
@@ -371,7 +372,7 @@ int CsoEngine::set(const std::string &k, int p, const double *in, int count)
     BBO_REQUIRE(p >= 0 && p < c_.npop, "population index out of range");
     (void) count;
     if (k == "profile") {
-        timer_.enable(in[0] != 0., K_COUNT);
+        timer_.enable(in[0] != 0., K_COUNT, K_NAMES);
         return 1;
     }
     throw Error(BBO_ERR_KEY, "unknown or read-only state key '" + k + "'");

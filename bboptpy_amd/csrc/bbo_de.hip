@@ -11,6 +11,7 @@ namespace bbo {
 
 namespace {
 enum { K_GEN = 0, K_BOOK, K_ARCH, K_RANK, K_FINISH, K_SELECT, K_COUNT };
+static const char *const K_NAMES[K_COUNT] = { "bbo:de_generation", "bbo:de_bookkeep", "bbo:de_archive_copy", "bbo:de_rank", "bbo:de_finish", "bbo:de_select" };   // roctx ranges, bench.py's slot names
 }
 
 DeEngine::DeEngine(const bbo_params &p) :
@@ -452,7 +453,7 @@ int DeEngine::set(const std::string &k, int p, const double *in, int count)
     scal_.download(&s, 1, p);
     const size_t pbase = (size_t) p * c.npinit;
     if (k == "profile") {
-        timer_.enable(in[0] != 0., K_COUNT);
+        timer_.enable(in[0] != 0., K_COUNT, K_NAMES);
         return 1;
     }
     if (k == "x") {   // rows in sorted order; follow with set("f") to re-rank

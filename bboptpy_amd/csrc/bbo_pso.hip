@@ -11,6 +11,7 @@ namespace bbo {
 
 namespace {
 enum { K_CENTER = 0, K_ESE, K_CTRL, K_UPDATE, K_FINISH, K_COUNT };
+static const char *const K_NAMES[K_COUNT] = { "bbo:pso_center", "bbo:pso_ese", "bbo:pso_control", "bbo:pso_update", "bbo:pso_finish" };   // roctx ranges, bench.py's slot names
 }
 
 PsoEngine::PsoEngine(const bbo_params &p) :
@@ -388,7 +389,7 @@ int PsoEngine::set(const std::string &k, int p, const double *in, int count)
         return 1;
     }
     if (k == "profile") {
-        timer_.enable(in[0] != 0., K_COUNT);
+        timer_.enable(in[0] != 0., K_COUNT, K_NAMES);
         return 1;
     }
     auto rows_in = [&](DevBuf<double> &b) {
