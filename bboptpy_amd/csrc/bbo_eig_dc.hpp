@@ -139,6 +139,27 @@ __device__ inline int dc_count_before(const double *v, int cnt, double key, bool
 }
 
 // rank of entry `self` (key) of the concatenation [list A: n_a entries | list B: n_b entries] at v
+#ifdef DC_OLD_TWO_BRANCH
+// (the form of rounds 2-3, kept for scripts/hiptests/rank_tie.hip and variant builds: two
+// data-dependent while loops under a divergent select -- see DESIGN.md section 4)
+__device__ inline int dc_count_before_while(const double *v, int cnt, double key, bool or_equal)
+{
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double d = dc_key(v[mid]);
+        const bool before = or_equal ? d <= key : d < key;
+        lo = before ? mid + 1 : lo;
+        hi = before ? hi : mid;
+    }
+    return lo;
+}
+__device__ inline int dc_rank_sorted2(const double *v, int n_a, int n_b, double key, int self, int trips)
+{
+    return self < n_a ? self + dc_count_before_while(v + n_a, n_b, key, false)
+                      : (self - n_a) + dc_count_before_while(v, n_a, key, true);
+}
+#else
 __device__ inline int dc_rank_sorted2(const double *v, int n_a, int n_b, double key, int self, int trips)
 {
     const bool first = self < n_a;
@@ -147,6 +168,7 @@ __device__ inline int dc_rank_sorted2(const double *v, int n_a, int n_b, double 
     const int own = first ? self : self - n_a;
     return own + dc_count_before(other, ocnt, key, !first, trips);
 }
+#endif
 
 // the team of wavefronts that works on one merge
 struct DcTeam {
