@@ -265,7 +265,9 @@ void CmaEngine::init(int n, const double *lower, const double *upper, const doub
         // cma_gram128 streams its slab: size the slabs for ~512 workgroups over all populations
         // (two resident per CU: one round; 1024 cost 1 % more in the Gram kernel and a quarter more
         // in cma_cov, which sums the slabs)
-        int want = std::max(1, std::min(32, (512 + P - 1) / P));
+        int cap = 32;
+        if (const char *e = std::getenv("BBO_GRAM_WANT")) cap = std::max(1, std::atoi(e));     // (tuning)
+        int want = std::max(1, std::min(cap, (512 + P - 1) / P));
         want = std::min(want, (c.lambda_pad + G128_CH - 1) / G128_CH);
         c.rps = ((c.lambda_pad + want - 1) / want + G128_CH - 1) / G128_CH * G128_CH;
     }

@@ -4,6 +4,7 @@
 #include "bbo_pso_kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 
@@ -60,7 +61,9 @@ void PsoEngine::init(int n, const double *lower, const double *upper, const doub
     parts_ = std::max(1, std::min(256, c.np / 64));
     {   // up to 16 refreshes of the swarm's best per generation, chunks of at least 64 particles
         // (multiples of 16: whole workgroups); a swarm of up to 64 moves in one piece
-        const int nchunks = std::min(16, (c.np + 63) / 64);
+        // (beyond 32768 particles eight: a launch over fewer than ~8000 particles is one round of
+        // workgroups and leaves HBM half idle -- C4's update ran at 0.37 of the roof in 16 chunks)
+        const int nchunks = c.np > 32768 ? 8 : std::min(16, (c.np + 63) / 64);
         chunk_ = ((c.np + nchunks - 1) / nchunks + 15) / 16 * 16;
         if (nchunks <= 1) chunk_ = c.np;
     }
@@ -203,20 +206,26 @@ void PsoEngine::generation(bool honor_stop)
     // the swarm moves in chunks of chunk_ particles, the best refreshed between them: what the
     // reference's in-loop refresh (apso.cpp:194-197) buys at large np (one chunk = the generation-
     // synchronous form of rounds 1-4: every particle sees the best of the generation start)
-    timer_.begin(stream_, K_UPDATE);
     const int step = chunk_ > 0 && chunk_ < c.np ? chunk_ : c.np;
+    // (the timer slots: pso_update brackets each update launch, pso_finish the refreshes of the best
+    // and the closing kernel)
     for (int i0 = 0; i0 < c.np; i0 += step) {
         const int i1 = std::min(c.np, i0 + step);
+        timer_.begin(stream_, K_UPDATE);
         hipLaunchKernelGGL(pso_update, dim3((i1 - i0 + R - 1) / R, P), dim3(16 * R), ldsR, stream_, d_,
                 c_, i0, i1);
+        timer_.end(stream_);
         if (!obj_.on_device()) {
             host_evaluate_swarm(i0, i1);
             hipLaunchKernelGGL(pso_pbest, dim3((i1 - i0 + 15) / 16, P), dim3(256), 0, stream_, d_, c_, i0,
                     i1);
         }
-        if (i1 < c.np) hipLaunchKernelGGL(pso_gbest, dim3(P), dim3(256), 0, stream_, d_, c_, i0, i1);
+        if (i1 < c.np) {
+            timer_.begin(stream_, K_FINISH);
+            hipLaunchKernelGGL(pso_gbest, dim3(P), dim3(256), 0, stream_, d_, c_, i0, i1);
+            timer_.end(stream_);
+        }
     }
-    timer_.end(stream_);
     BBO_HIP(hipGetLastError());
     timer_.begin(stream_, K_FINISH);
     hipLaunchKernelGGL(pso_finish, dim3(P), dim3(256), 0, stream_, d_, c_);

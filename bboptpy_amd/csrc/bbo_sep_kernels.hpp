@@ -18,6 +18,26 @@
 
 namespace bbo {
 
+// sum of `count` values `stride` apart in their order, eight loads in flight at a time (summed
+// straight off a loop every addition waits for its own round trip; the same additions in the same
+// order)
+__device__ inline double slab_sum(const double *v, int count, size_t stride)
+{
+    double sum = 0.;
+    int s = 0;
+    for (; s + 8 <= count; s += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = v[(size_t) (s + u) * stride];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += x[u];
+    }
+    for (; s < count; s++) sum += v[(size_t) s * stride];
+    return sum;
+}
+
+
 // ---------------------------------------------------------------------------
 // sample + evaluate: x = m + sigma d z (sep_cmaes.cpp:73), G lanes per candidate (G | 64, so a
 // row is drawn and evaluated by ONE wavefront: no workgroup barrier after the table is staged),
@@ -386,8 +406,7 @@ __global__ __launch_bounds__(256) void sep_paths(CmaDev d, CmaConst c)
     const double csc = sqrt(c.cs * (2. - c.cs) * c.mueff);
     double ssq = 0.;
     for (int j = tid; j < ld; j += 256) {
-        double sum = 0.;
-        for (int s = 0; s < c.splits; s++) sum += d.mean_part[((size_t) p * c.splits + s) * ld + j];
+        const double sum = slab_sum(d.mean_part + (size_t) p * c.splits * ld + j, c.splits, ld);
         const double xo = xmean[j];
         double xn = 0., v = 0.;
         if (j < c.n) {
@@ -413,9 +432,7 @@ __global__ __launch_bounds__(256) void sep_paths(CmaDev d, CmaConst c)
         if (j < c.n) {
             const double pcj = (1. - c.cc) * pc[j] + hsig * ccc * (xmean[j] - xold[j]) / sigma;
             pc[j] = pcj;
-            double m2 = 0.;
-            for (int s = 0; s < c.splits; s++)
-                m2 += d.gram_part[((size_t) p * c.splits + s) * ld + j];
+            const double m2 = slab_sum(d.gram_part + (size_t) p * c.splits * ld + j, c.splits, ld);
             const double cn = (1. - c.ccov) * cs_[j] + (c.ccov / c.mueff) * pcj * pcj
                     + c.ccov * (1. - 1. / c.mueff) * m2;
             cs_[j] = cn;

@@ -105,13 +105,20 @@ def de_kernel_costs(n, np_, P):
     }
 
 
+def pso_chunk(np_):
+    """particles between two refreshes of the swarm's best inside a generation (bbo_pso.hip: up to
+    16 chunks of at least 64 particles, multiples of 16; 8 beyond 32768 particles) -- one pso_update LAUNCH moves one chunk"""
+    nchunks = 8 if np_ > 32768 else min(16, (np_ + 63) // 64)
+    return np_ if nchunks <= 1 else ((np_ + nchunks - 1) // nchunks + 15) // 16 * 16
+
+
 def pso_kernel_costs(n, np_, P):
     return {
         "pso_center": ("hbm", P * np_ * 16 * n),
         "pso_ese": ("mfma", P * np_ * n * np_),          # d_ij = d_ji: half of the 2 n np^2 products
         "pso_control": ("hbm", P * np_ * 16),
-        "pso_update": ("hbm", P * np_ * (40 * n + 16)),
-        "pso_finish": ("hbm", P * np_ * 16),
+        "pso_update": ("hbm", P * pso_chunk(np_) * (40 * n + 16)),     # per launch: one chunk
+        "pso_finish": ("hbm", None),     # the refreshes of the best between chunks + the closing kernel: latency
     }
 
 
