@@ -782,18 +782,20 @@ def main():
         singles = None
         if world == 1 and not args.no_single:
             if P != 1:
-                s1 = max(10, args.steps // 2)
-                dt1, _, fev1, _ = measure(bb, wl, 1, s1, 5, 77, local_rank, profile=False)
-                single = {"value": fev1 / dt1, "ms_per_step": 1e3 * dt1 / s1,
+                # (a generation of ONE population is ~0.4 ms: 200 of them, so that the one host
+                # synchronisation at the end of the timed region is noise, not 1 % of it)
+                s1 = max(200, args.steps)
+                dt1, _, fev1, _ = measure(bb, wl, 1, s1, 10, 77, local_rank, profile=False)
+                single = {"value": fev1 / dt1, "ms_per_step": 1e3 * dt1 / s1, "steps": s1,
                           "unit": "candidate-evals/s"}
             if args.workload == "M":
                 # one optimisation run at a time (P = 1), the strict reading of each config
                 singles = {"M": single}
                 for key in ("C1", "C3"):
                     w1 = WORKLOADS[key]
-                    sk = 400 if key == "C1" else max(10, args.steps // 2)
+                    sk = 400 if key == "C1" else max(200, args.steps)
                     d1, _, f1, _ = measure(bb, w1, 1, sk, 10, 78, local_rank, profile=False)
-                    singles[key] = {"value": f1 / d1, "ms_per_step": 1e3 * d1 / sk,
+                    singles[key] = {"value": f1 / d1, "ms_per_step": 1e3 * d1 / sk, "steps": sk,
                                     "unit": "candidate-evals/s"}
         conv = ftar = None
         if (world == 1 and wl["algo"] == "ActiveCMAES" and not args.no_convergence
