@@ -145,7 +145,7 @@ private:
     static int next_mw_xcd();
     long sample_wide_max_tiles_ = 512;       // n = 128: at most this many 16-row tiles take cma_sample_eval<1, 8>
     long sample128_min_rows_ = 256 * 128;   // candidates in flight from which cma_sample_eval128 is used
-    int split_maxp_ = 16;              // 64 < n <= 128: at most this many populations take the split decomposition
+    int split_maxp_ = 32;              // 64 < n <= 128: at most this many populations take the split decomposition
     bool rank_wrote_norms_ = false;    // this generation's cma_rank_sort wrote S: no whiten launch
     int last_n_ = -1;
     std::vector<double> lower_h_, upper_h_, aux_h_;
