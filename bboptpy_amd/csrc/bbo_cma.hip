@@ -580,7 +580,7 @@ void CmaEngine::launch_update()
     const CmaConst &c = c_;
     if (c.variant == 2) {
         timer_.begin(stream_, K_GRAM);
-        hipLaunchKernelGGL(sep_moments, dim3(c.splits, (c.ld + 255) / 256, c.npop), dim3(256), 0,
+        hipLaunchKernelGGL(sep_moments, dim3(c.splits, (c.ld + 511) / 512, c.npop), dim3(256), 0,
                 stream_, d_, c_);
         timer_.end(stream_);
         timer_.begin(stream_, K_PATHS);
