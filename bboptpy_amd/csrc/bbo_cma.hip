@@ -564,7 +564,9 @@ void CmaEngine::launch_rank()
     } else {
         // few candidates in flight: 8 per workgroup, 32 slices each (a quarter of the 64-bit compares
         // per thread; diagnostic bit 128 keeps the 32-candidate form -- the same counts)
-        if ((long) c.npop * ((c.lambda + 31) / 32) <= 512 && c.lambda >= 512 && !(d_.dbg & 128))
+        if ((long) c.npop * ((c.lambda + 31) / 32) <= 256 && c.lambda >= 2048 && !(d_.dbg & (128 | 4096)))
+            hipLaunchKernelGGL(cma_rank64, dim3((c.lambda + 3) / 4, c.npop), dim3(256), 0, stream_, d_, c_);
+        else if ((long) c.npop * ((c.lambda + 31) / 32) <= 512 && c.lambda >= 512 && !(d_.dbg & 128))
             hipLaunchKernelGGL(cma_rank32, dim3((c.lambda + 7) / 8, c.npop), dim3(256), 0, stream_, d_, c_);
         else
             hipLaunchKernelGGL(cma_rank, dim3((c.lambda + 31) / 32, c.npop), dim3(256), 0, stream_, d_, c_);

@@ -627,6 +627,10 @@ __global__ __launch_bounds__(256) void cma_rank32(CmaDev d, CmaConst c)
 {
     cma_rank_body<32>(d, c);
 }
+__global__ __launch_bounds__(256) void cma_rank64(CmaDev d, CmaConst c)
+{
+    cma_rank_body<64>(d, c);
+}
 
 // the same ranking by one in-LDS sort per population (lambda <= SORT_LDS_MAX): merge sort by
 // merge path for 2048 / 4096 padded keys (`merge`: two buffers, 24 m bytes of dynamic LDS), the

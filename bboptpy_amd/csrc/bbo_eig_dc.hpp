@@ -1515,7 +1515,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         if (ext_top && nc == 2) {
             // the top merge of a matrix wider than 128 (512 threads): scalar part only
             if (top_part == 2) {
-                for (size_t q = tid; q < w_doubles; q += T) scratch[q] = Wimg[q];
+                // (eight loads in flight per thread: copied element by element every LDS store waited
+                // for its own round trip to L2 -- 6 us of this kernel at n = 128)
+                for (size_t q0 = tid; q0 < w_doubles; q0 += (size_t) 8 * T) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) x[u] = q0 + (size_t) u * T < w_doubles ? Wimg[q0 + (size_t) u * T] : 0.;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (q0 + (size_t) u * T < w_doubles) scratch[q0 + (size_t) u * T] = x[u];
+                }
                 __syncthreads();
                 if (tid == 0) maxnr_s = W.cnt[2];
                 __syncthreads();

@@ -412,11 +412,12 @@ def test_eigensolver_forms_for_64_to_128_agree(hip, n):
             assert np.abs(v - Ds[("one workgroup", 1)]).max() <= 1e-12 * sc, (name, key)
 
 
-@pytest.mark.parametrize("lam,obj", [(256, "rosenbrock"), (1024, "ellipsoid"), (200, "rastrigin")])
+@pytest.mark.parametrize("lam,obj", [(256, "rosenbrock"), (1024, "ellipsoid"), (200, "rastrigin"),
+                                     (2048, "rosenbrock")])     # (2048: a wavefront per candidate in the rank)
 def test_single_run_sampler_and_ranking_equal_the_batch_kernels(hip, lam, obj):
     """one population at a time (round 5) takes kernels of its own at n = 128: a 16-row tile per
     workgroup in the sampler (one column tile per wavefront) and 32 slices per candidate in the
-    counting rank, which also hands down the whitened norms.  Same normals, same products in the
+    counting rank (64 from lambda = 2048), which also hands down the whitened norms.  Same normals, same products in the
     same order, same counts: X, f, ||z||^2-derived S and the ranking equal the other kernels' bit
     for bit (tuning keys sample_wide_max = 0 and diagnostic bit 128 select those)."""
     from bboptpy_amd import _ffi
