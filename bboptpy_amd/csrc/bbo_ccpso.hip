@@ -357,7 +357,7 @@ void CcpsoEngine::require_unsharded(const char *what) const
 // caller's callable, or the built-in's formula on the host).  Each search starts `local` afresh
 // (B = C = I) under the seed base + search index -- the reference's CMA-ES objects start from the
 // previous search's matrices (cmaes.cpp:53-54), which corrupts the heap when the swarm count
-// grows; not reproduced (CCPSO2).
+// grows; not reproduced (HISTORY.md section 3, CCPSO2).
 void CcpsoEngine::set_local(Optimizer *local, int localfreq)
 {
     BBO_REQUIRE(c_.npop <= 1 && params_.populations <= 1,

@@ -151,7 +151,7 @@ __device__ inline void ccp_wave_sync()
 // swarm's 2 np candidates, which all replace the SAME coordinates -- a candidate costs the gather of its cp
 // values and one evaluation, not a copy of the n-vector (the form with one team per candidate
 // spent its time staging 8 KB per evaluation: 749 us per generation at n = 1000 against
-// the figure in DESIGN.md section 3).  The values in the row and the reduction are what they
+// the figure in HISTORY.md section 3).  The values in the row and the reduction are what they
 // were: f is bit-identical.  Teams sit inside one wavefront: syncs at wavefront scope.
 // grid (ceil(CCP_SPLIT nswarm_max / (256/G)), P), 256 threads, LDS (256/G) * ld doubles -- swarms past
 // nswarm, or outside this rank's shard [nswarm r / W, nswarm (r + 1) / W), return

@@ -299,7 +299,7 @@ __device__ __forceinline__ uint32_t normal_quads_fast(uint64_t seed, uint32_t c0
         const u32x4 w = wn;
 #ifdef BBO_DIAG_STRIP_NOCONFLICT
         // timing / counter diagnostic only (wrong normals): the 16 lanes of a b128 read group take
-        // 16 consecutive records, so the strip reads cannot conflict
+        // 16 consecutive records, so the strip reads cannot conflict (HISTORY.md section 6, round 4)
         const uint32_t dl = threadIdx.x & 15u;
         const double2 e0 = tab[((w.x & 1023u) & ~15u) | dl], e1 = tab[((w.y & 1023u) & ~15u) | dl],
                 e2 = tab[((w.z & 1023u) & ~15u) | dl], e3 = tab[((w.w & 1023u) & ~15u) | dl];

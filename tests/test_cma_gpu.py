@@ -467,7 +467,7 @@ def test_spread_reduction_runs_generation_after_generation(hip):
     grow from launch to launch, its buffers alternate between steps): 12 generations of two
     populations against the same run with the reduction on one workgroup -- same trajectory to
     rounding (lambda = 2 n: with fewer candidates than dimensions the first covariance matrices have
-    a repeated eigenvalue whose eigenvectors rounding decides), and no
+    a repeated eigenvalue whose eigenvectors rounding decides, HISTORY.md section 5), and no
     wavefront ever gave up waiting"""
     n, lam, P = 256, 512, 2
     lo, up = -5. * np.ones(n), 5. * np.ones(n)
