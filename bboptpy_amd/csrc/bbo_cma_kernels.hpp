@@ -942,6 +942,10 @@ __device__ __forceinline__ void gram_body(const CmaDev &d, const CmaConst &c, in
     const int *rank = d.rank + (size_t) p * c.lambda_pad;
     const double isig = 1. / sc->sigma;
     const int row0 = s * rps;
+    // (rows of this slab that exist at all: lambda_pad is a multiple of 16, so are the slab's live
+    // rows -- at lambda = 20 the slab of 64 is half empty, and staging and sweeping the empty half
+    // was a third of this kernel's time at n = 256)
+    const int rlive = min(rps, c.lambda_pad - row0);
 
     if (tid < rps) {
         const int row = row0 + tid;
@@ -959,7 +963,7 @@ __device__ __forceinline__ void gram_body(const CmaDev &d, const CmaConst &c, in
         double m0 = 0., m1 = 0., m2 = 0., m3 = 0.;
         const double2 xo01 = *reinterpret_cast<const double2*>(&xold[c4]);
         const double2 xo23 = *reinterpret_cast<const double2*>(&xold[c4 + 2]);
-        for (int r = r0; r < rps; r += rpp) {
+        for (int r = r0; r < rlive; r += rpp) {
             const int row = row0 + r;
             double2 a01 = make_double2(0., 0.), a23 = make_double2(0., 0.);
             if (row < c.lambda) {
@@ -1001,7 +1005,7 @@ __device__ __forceinline__ void gram_body(const CmaDev &d, const CmaConst &c, in
         if (q < LT) tri_tile(q, ti[t], tj[t]);
     }
     const int fr = lane & 15, fk = lane >> 4;
-    for (int ks = 0; ks < (rps >> 2); ks++) {
+    for (int ks = 0; ks < (rlive >> 2); ks++) {
         const int k = 4 * ks + fk;
         const double vk = V[k];
         const double *yk = Y + k * ldy;
