@@ -88,8 +88,10 @@ struct MwBudget {
     bool known[MAXDEV] = {};
     static MwBudget &get()
     {
-        static MwBudget b;
-        return b;
+        // (never destroyed: an engine that outlives the library's static objects -- a global in the
+        // caller's program -- still gives its share back through a live object)
+        static MwBudget *b = new MwBudget;
+        return *b;
     }
     long capacity(int dev)
     {
