@@ -676,7 +676,7 @@ void CmaEngine::launch_eigen()
     const bool split128 = pl_lds.use_lds && pl_lds.threads == 512 && pl_lds.dc && c.npop <= split_maxp_
             && !(d_.dbg & (2 | 4 | 8 | 1024 | 4194304));
     const EigPlan pl = split128 ? eig_plan_split(c.n, c.ld) : pl_lds;
-    bool wy4_packs = false;
+    bool wy4_packs = false, fcols_closed = false;
     allow_lds((const void*) cma_eigen, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_g, 160 * 1024 - 768);
     allow_lds((const void*) cma_eigen_b, 160 * 1024 - 768);
@@ -741,6 +741,15 @@ void CmaEngine::launch_eigen()
         if ((long) c.npop * 8 <= 256 && !(d_.dbg & 67108864)) {
             hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 1);
             hipLaunchKernelGGL(cma_eig_secular, dim3((c.n + 31) / 32, c.npop), dim3(512), 0, stream_, d_, c_);
+            // behind the secular equation: the Loewner vector and the columns of F on n / 32 workgroups
+            // each, the closing repair / root with them (even n: the T factors were built beside the
+            // halves; diagnostic bit 33554432: cma_eigen_g2 part 2, one workgroup, as in round 4)
+            fcols_closed = !(c.n & 1) && c.lazy_isc && (long) c.npop * ((c.n + 15) / 16) <= 256
+                    && !(d_.dbg & (33554432 | 134217728));
+            if (fcols_closed) {
+                hipLaunchKernelGGL(cma_eig_lowner, dim3((c.n + 31) / 32, c.npop), dim3(512), 0, stream_, d_, c_);
+                hipLaunchKernelGGL(cma_eig_fcols, dim3((c.n + 31) / 32, c.npop), dim3(512), 0, stream_, d_, c_);
+            } else
             hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 2);
         } else
         hipLaunchKernelGGL(cma_eigen_g2, dim3(c.npop), dim3(512), pl.lds_bytes, stream_, d_, c_, pl, 0);
@@ -799,7 +808,7 @@ void CmaEngine::launch_eigen()
                 // (under lazy_isc the packed operand B D leaves with B: no cma_post launch)
                 wy4_packs = c.lazy_isc != 0;
                 hipLaunchKernelGGL(cma_eig_wy4, dim3((c.n + 15) / 16, c.npop), dim3(256), 0, stream_, d_, c_,
-                        wy4_packs ? 1 : 0);
+                        wy4_packs ? (fcols_closed ? 2 : 1) : 0);
             } else
             hipLaunchKernelGGL(cma_eig_wy, dim3((c.n + 63) / 64, c.npop), dim3(256), 0, stream_, d_,
                     c_);

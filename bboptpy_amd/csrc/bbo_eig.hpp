@@ -1451,6 +1451,233 @@ __global__ __launch_bounds__(512) void cma_eig_secular(CmaDev d, CmaConst c)
     dc_secular<16>(W, k, rho, 512 * (int) blockIdx.x + (int) threadIdx.x, true, nullptr, false, n);
 }
 
+// ---------------------------------------------------------------------------
+// The rest of a split top merge on ceil(n / 32) workgroups each (round 5): on the one workgroup of
+// cma_eigen_g2 part 2 the Loewner vector and the eigenvector factor F -- two passes of k^2
+// reciprocals -- were 2 x 22 us at n = 256 (2 x 7 at 128), the CU's issue rate again, as the secular
+// equation was.  Two launches because each needs ALL of the one before: the Loewner product of a
+// pole runs over every root, the norm of a column over every pole's Loewner value.
+//   cma_eig_lowner: pole i = 32 bx + tid / 16 by 16 lanes: what[i] = sign(z_i) sqrt |prod_j
+//       ((d_orgj - d_i) + mu_j) / (d_j - d_i)| -> the work-area image in global memory.
+//   cma_eig_fcols: every workgroup ranks the m eigenvalues (roots and deflated poles: two sorted
+//       lists, or by counting when a deflation rotation or an escaped root may have disturbed them)
+//       into LDS -- output order, row map, column map, 1 us of redundant work --, then its 32
+//       output columns of F by 16 lanes each: the column's norm over all poles, its m entries
+//       (rows in ORIGINAL column order), the deflation rotations on its columns.  Workgroup 0 also
+//       does what cma_eigen_impl does behind the merge: eigenvalues in ascending order, the
+//       reference's repair (cmaes.cpp:250-266), D = sqrt, the counters.
+// Same expressions as dc_merge_level; the sums and products run over the lanes in another order,
+// so the bits differ from the one-workgroup form (forms-agree tests: eigenvalues to 1e-12, each
+// form's own residual and orthogonality).  Even n only (the T factors were built beside the halves).
+// ---------------------------------------------------------------------------
+__device__ inline double eig_row16_prod(double v)
+{
+    v *= eig_dpp<0x128>(v);   // row_ror:8
+    v *= eig_dpp<0x124>(v);   // row_ror:4
+    v *= eig_dpp<0x122>(v);   // row_ror:2
+    v *= eig_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+
+__global__ __launch_bounds__(512) void cma_eig_lowner(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    const CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (sc->eig_stage != 1) return;
+    const int n = c.n;
+    double *tri = d.eig_work + (size_t) (4 * p + 3) * eig_slab(c.ld);
+    const DcWork W = dc_work_layout(tri + 4 * n + 8, n + 2, nullptr);
+    const int k = W.cnt[0];
+    const int i = 32 * (int) blockIdx.x + ((int) threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (k == 1) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            W.what[0] = 1.;
+            W.ninv[0] = 1.;
+        }
+        return;
+    }
+    double prod = 1.;
+    if (i < k) {
+        // lam_jj - d_i = (d_org - d_i) + mu, paired with a denominator d_jj - d_i (the origin poles
+        // were left in W.lam by cma_eig_secular); four roots at a time, all loads first
+        const double di2 = W.dl[i];
+        double p4[4] = { 1., 1., 1., 1. };
+        const int npl = (k + 15) >> 4;
+        for (int t0 = 0; t0 < npl; t0 += 4) {
+            double lo_[4], mu_[4], dj_[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jc = min(sub + (t0 + u) * 16, k - 1);
+                lo_[u] = W.lam[jc];
+                mu_[u] = W.mu[jc];
+                dj_[u] = W.dl[jc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = sub + (t0 + u) * 16;
+                const double num = (lo_[u] - di2) + mu_[u];
+                const double f = num * dc_rcp(jj == i ? 1. : dj_[u] - di2);
+                p4[u] *= jj < k ? f : 1.;
+            }
+        }
+        prod = (p4[0] * p4[1]) * (p4[2] * p4[3]);
+    }
+    prod = eig_row16_prod(prod);
+    if (i < k && sub == 0) {
+        const double v = sqrt(fabs(prod));
+        W.what[i] = W.ws[i] >= 0. ? v : -v;
+    }
+}
+
+__global__ __launch_bounds__(512) void cma_eig_fcols(CmaDev d, CmaConst c)
+{
+    const int p = blockIdx.y;
+    CmaScal *sc = d.scal + p;
+    if (c.honor_stop && sc->stop != 0) return;
+    if (sc->eig_stage != 1) return;
+    constexpr int MMAX = 256 + 2;
+    __shared__ double lamS[MMAX], gvs[MMAX];
+    __shared__ int outposS[MMAX], rowmapS[MMAX], colrootS[MMAX];
+    const int n = c.n, ld = c.ld, tid = threadIdx.x, T = 512;
+    const size_t slab = eig_slab(ld);
+    double *base = d.eig_work + (size_t) 4 * p * slab;
+    double *tri = base + 3 * slab;
+    const DcWork W = dc_work_layout(tri + 4 * n + 8, n + 2, nullptr);
+    const int m = n, a = 0;
+    const int k = W.cnt[0], nd = W.cnt[1], nr = W.cnt[2];
+    // ---- all eigenvalues, their output order, the row / column maps of F (dc_merge_level) ----------
+    if (tid < k) lamS[tid] = W.dl[W.org[tid]] + W.mu[tid];
+    if (tid < nd) lamS[k + tid] = W.dS[W.dp[tid]];
+    __syncthreads();
+    if (tid < m) {
+        const double key = dc_key(lamS[tid]);
+        const int trips = 32 - __builtin_clz(max(m, 1));
+        outposS[tid] = (nr > 0 || W.cnt[3] != 0) ? dc_rank_of(lamS, m, key, tid)
+                : dc_rank_sorted2(lamS, k, nd, key, tid, trips);
+    }
+    __syncthreads();
+    if (tid < k) {
+        rowmapS[W.srcS[W.kp[tid]] - a] = tid;
+        colrootS[outposS[tid]] = tid;
+    }
+    if (tid < nd) {
+        rowmapS[W.srcS[W.dp[tid]] - a] = -(1 + outposS[k + tid]);
+        colrootS[outposS[k + tid]] = -1;
+    }
+    __syncthreads();
+    // ---- this workgroup's 32 output columns of F, 16 lanes each ---------------------------------------
+    double *Fg = base + slab + (size_t) n * n;            // F: m x m, rows in ORIGINAL column order
+    const int cidx = 32 * (int) blockIdx.x + (tid >> 4), sub = tid & 15;
+    const int j = cidx < m ? colrootS[cidx] : -1;
+    const double dorgj = j >= 0 ? W.dl[W.org[j]] : 0.;
+    const double muj = j >= 0 ? W.mu[j] : 0.;
+    double ss = 0.;
+    if (j >= 0 && k > 1) {
+        const int npl = (k + 15) >> 4;
+        for (int t0 = 0; t0 < npl; t0 += 4) {
+            double wh[4], dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ic = min(sub + (t0 + u) * 16, k - 1);
+                wh[u] = W.what[ic];
+                dd[u] = W.dl[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ii = sub + (t0 + u) * 16;
+                const double sv = wh[u] * dc_rcp((dd[u] - dorgj) - muj);
+                ss += ii < k ? sv * sv : 0.;
+            }
+        }
+    }
+    ss = dc_quad_sum<16>(ss);
+    const double nj = (j >= 0 && k > 1) ? 1. / sqrt(ss) : 1.;
+    if (cidx < m) {
+        for (int r0 = sub; r0 < m; r0 += 64) {
+            int iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) iv[u] = rowmapS[min(r0 + 16 * u, m - 1)];
+            double wh[4], dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ic = iv[u] >= 0 ? iv[u] : 0;
+                wh[u] = W.what[ic];
+                dd[u] = W.dl[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = r0 + 16 * u;
+                const int i = iv[u];
+                const double root = k == 1 ? 1. : wh[u] * dc_rcp((dd[u] - dorgj) - muj) * nj;
+                const double v = i >= 0 ? (j >= 0 ? root : 0.) : (-(1 + i) == cidx ? 1. : 0.);
+                if (r < m) Fg[(size_t) r * m + cidx] = v;
+            }
+        }
+    }
+    // deflation rotations, in reverse, on this workgroup's columns: Q G with G = [[c, -s], [s, c]] on
+    // sorted columns (p, j); a column's 16 lanes wrote its rows, so the lanes of the column meet first
+    if (nr > 0) {
+        __threadfence_block();
+        __syncthreads();
+        if (cidx < m && sub == 0)
+            for (int r = nr - 1; r >= 0; r--) {
+                const int rp = W.srcS[W.rotp[r]] - a, rj = W.srcS[W.rotj[r]] - a;
+                const double cth = W.rotc[r], s = W.rots[r];
+                const double x = Fg[(size_t) rp * m + cidx], y = Fg[(size_t) rj * m + cidx];
+                Fg[(size_t) rp * m + cidx] = cth * x - s * y;
+                Fg[(size_t) rj * m + cidx] = s * x + cth * y;
+            }
+    }
+    if (blockIdx.x != 0) return;
+    // ---- workgroup 0: what follows the merge in cma_eigen_impl ---------------------------------------
+    // the scale of eig_dc_phase (a power of two from the largest |d|, |e| of the torn problem), undone
+    double am = 0.;
+    for (int i = tid; i < n; i += T) am = fmax(am, fmax(fabs(tri[3 * n + i]), fabs(tri[n + i])));
+    am = dc_wave_max(am);
+    __shared__ double reds[8];
+    if ((tid & 63) == 0) reds[tid >> 6] = am;
+    __syncthreads();
+    am = reds[0];
+#pragma unroll
+    for (int w = 1; w < 8; w++) am = fmax(am, reds[w]);
+    int ex = 0;
+    if (am > 0.) frexp(am, &ex);
+    const double inv = 1. / (am > 0. ? ldexp(1., 1 - ex) : 1.);
+    if (tid < m) gvs[outposS[tid]] = lamS[tid] * inv;         // ascending
+    __syncthreads();
+    // repair (cmaes.cpp:250-266) and sqrt (:269-271)
+    double *C = d.C + (size_t) p * ld * ld;
+    const double lo = gvs[0], hi = gvs[n - 1];
+    __syncthreads();
+    if (lo <= 0.) {
+        const double shift = fmax(hi, 0.) / 1e14;
+        for (int i = tid; i < n; i += T) {
+            gvs[i] = fmax(gvs[i], 0.) + shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+        __syncthreads();
+    }
+    const double lo2 = gvs[0], hi2 = gvs[n - 1];
+    __syncthreads();
+    if (hi2 > 1e14 * lo2) {
+        const double shift = hi2 / 1e14 - lo2;
+        for (int i = tid; i < n; i += T) {
+            gvs[i] += shift;
+            C[(size_t) i * ld + i] += shift;
+        }
+        __syncthreads();
+    }
+    double *Dp = d.D + (size_t) p * ld;
+    for (int i = tid; i < ld; i += T) Dp[i] = i < n ? sqrt(gvs[i]) : 1.;
+    if (tid == 0) {
+        sc->eigenlastev = sc->fev;
+        sc->eigen_done = 1;
+        // (eig_stage stays 1 for the workgroups of this launch that have not started yet: the last
+        // kernel of the chain, cma_eig_wy4, clears it)
+    }
+}
+
 // grid (2, P), 512 threads, dynamic LDS of the n = 128 plan (plh); lda_work: row stride of the
 // global work matrix the blocks go to
 __global__ __launch_bounds__(512) void cma_eig_halves(CmaDev d, CmaConst c, EigPlan plh, int lda_work)
@@ -1842,7 +2069,10 @@ __device__ __forceinline__ void eig_wy4_body(const CmaDev &d, const CmaConst &c,
                             q[j][r] * dcol;
             }
         }
-    if (pack && tid == 0 && blockIdx.x == 0) d.scal[p].basis_ok = 1;
+    if (pack && tid == 0 && blockIdx.x == 0) {
+        d.scal[p].basis_ok = 1;
+        if (pack == 2) d.scal[p].eig_stage = 0;      // (behind cma_eig_fcols, which left it to the chain's end)
+    }
 }
 
 __global__ __launch_bounds__(256) void cma_eig_wy4(CmaDev d, CmaConst c, int pack)

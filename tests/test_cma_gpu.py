@@ -344,7 +344,8 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
     forms = {"one workgroup": 4194304, "split": 16777216, "default": 0, "all steps spread": 536870912,
-             "split, as for many matrices": 16777216 | 67108864 | 134217728}
+             "split, as for many matrices": 16777216 | 67108864 | 134217728,
+             "Loewner / F on one workgroup (round 4)": 33554432}
     for name, Cm in _spd_cases(n, rng):
         Cm = 0.5 * (Cm + Cm.T)
         lam = np.linalg.eigvalsh(Cm)
@@ -365,7 +366,8 @@ def test_eigensolver_forms_for_128_to_256_agree(hip, n):
             assert np.linalg.norm(B.T @ B - np.eye(n)) <= 1e-12 * n, (name, form)
             assert np.linalg.norm(B @ np.diag(D * D) @ B.T - Cm) <= 1e-11 * np.linalg.norm(Cm), (name, form)
             Ds[form] = D * D
-        for form in ("split", "default", "all steps spread", "split, as for many matrices"):
+        for form in ("split", "default", "all steps spread", "split, as for many matrices",
+                     "Loewner / F on one workgroup (round 4)"):
             assert np.abs(Ds[form] - Ds["one workgroup"]).max() <= 1e-12 * sc, (name, form)
 
 
@@ -381,7 +383,7 @@ def test_eigensolver_forms_for_64_to_128_agree(hip, n):
     bit (the split form packs it in the reflector kernel, the other in the eigensolver)."""
     from bboptpy_amd import _ffi
     rng = np.random.default_rng(n)
-    forms = {"one workgroup": 4194304, "split": 0}
+    forms = {"one workgroup": 4194304, "split": 0, "split, Loewner / F on one workgroup": 33554432}
     for name, Cm in _spd_cases(n, rng):
         Cm = 0.5 * (Cm + Cm.T)
         sc = np.abs(np.linalg.eigvalsh(Cm)).max()
