@@ -201,7 +201,11 @@ int bbo_run(bbo_handle h, int max_generations, int *generations_done);
  * Named read/write access to the optimizer state, the counterpart of the reference's
  * protected members (base_cmaes.h:52-63, cmaes.h:42-46, shade.h:44-51, apso.h:46-66).
  * bbo_get returns the element count (>= 0) or a negative bbo_status; call with cap 0
- * to size a buffer.  Keys are listed in DESIGN.md. */
+ * to size a buffer.  Keys are listed in HISTORY.md (last section) and DESIGN.md section 9.
+ * One key changes semantics the reference's user can see: APSO "chunk" -- the number of particles
+ * that move between two refreshes of the swarm's best inside a generation (the reference refreshes
+ * after every particle, apso.cpp:194-197; the default here is np / 16 in whole workgroups, at least
+ * 64; 0 = the whole swarm sees the best of the generation start). */
 int bbo_get(bbo_handle h, const char *key, int population, double *out, int cap);
 int bbo_set(bbo_handle h, const char *key, int population, const double *in, int count);
 
