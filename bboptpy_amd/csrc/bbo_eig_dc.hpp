@@ -1485,11 +1485,17 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
         const int nm = nc >> 1;                       // merges at this level
         int teams = 1;
         while (teams < nm) teams <<= 1;               // 1, 2, 4, 8
-        const int wpt = NW / teams > 0 ? NW / teams : 1;   // wavefronts per team
+        int wpt = NW / teams > 0 ? NW / teams : 1;   // wavefronts per team
         // lanes per secular root: as many as every team of this level can give its poles
         // (chosen from the WIDEST merge so that all teams run the same code path)
         int m = 0;
         for (int i = 0; i < nm; i++) m = max(m, edge(2 * i + 2, L) - edge(2 * i, L));
+        // (round 5) a merge of at most 16 poles never needs more than ONE wavefront (four lanes per
+        // root, one column tile): where the workgroup has wavefronts to spare -- the halves of a
+        // split decomposition: four merges, eight wavefronts -- a second one per team only turns the
+        // team's ~25 phase boundaries from wavefront fences into workgroup barriers
+        // (diagnostic bit 65536*64 = 4194304 is taken; bit 8388608 forces barriers anyway)
+        if (m <= 16 && !BIG) wpt = 1;
         // a level has at most NW teams at a time: 16 merges (32 leaves, n > 256) take two passes
         const int tcount = min(teams, NW);
         for (int pass = 0; pass * tcount < nm && (BIG || pass == 0); pass++) {
