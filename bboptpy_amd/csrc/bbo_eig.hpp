@@ -1177,10 +1177,10 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             if (i >= 1) tri[n + i - 1] = ev[i];
             tri[2 * n + i] = hvec[i];
         }
-        for (int q = tid; q < 128 * n; q += T) {
-            const int r = q / n, cidx = q - r * n;
-            Vout[q] = cidx < r ? Ast(r, cidx) : 0.;
-        }
+        // (a row per wavefront at a time: indexed by q / n this copy was an integer division per
+        // element, 4 us of the kernel)
+        for (int r = wave; r < 128; r += T / 64)
+            for (int cidx = lane; cidx < n; cidx += 64) Vout[(size_t) r * n + cidx] = cidx < r ? Ast(r, cidx) : 0.;
         if (tid == 0) sc->eig_stage = 1;
         return;
     }
@@ -1233,10 +1233,8 @@ __device__ __forceinline__ void cma_eigen_impl(const CmaDev &d, const CmaConst &
             // (64 < n <= 128, few matrices: the reflectors leave the LDS stash -- row i = u_i, zero
             // from column i on -- for the place cma_eig_halves' third workgroup and cma_eig_wy4 read)
             double *Vout = d.eig_work + (size_t) (4 * p + 1) * eig_slab(ld);
-            for (int q = tid; q < n * n; q += T) {
-                const int r = q / n, cidx = q - r * n;
-                Vout[q] = A(r, cidx);
-            }
+            for (int r = wave; r < n; r += T / 64)
+                for (int cidx = lane; cidx < n; cidx += 64) Vout[(size_t) r * n + cidx] = A(r, cidx);
         }
         if (tid == 0) {
             tri[4 * n] = 0.;               // (T factors: not built yet, cma_eig_halves' third workgroup)
@@ -1744,10 +1742,8 @@ __global__ __launch_bounds__(512) void cma_eig_halves(CmaDev d, CmaConst c, EigP
             true, nullptr, 1);
     // the rest of this half's rows of the work matrix: the other half's columns are zero
     const int c0 = h ? 0 : mid, cw = h ? mid : n - mid;
-    for (int q = tid; q < m * cw; q += T) {
-        const int r = q / cw, cc = q - r * cw;
-        base[(size_t) (off + r) * lda_work + c0 + cc] = 0.;
-    }
+    for (int r = tid >> 6; r < m; r += T / 64)
+        for (int cc = tid & 63; cc < cw; cc += 64) base[(size_t) (off + r) * lda_work + c0 + cc] = 0.;
     for (int i = tid; i < m; i += T) tri[3 * n + off + i] = dv[i];
 }
 

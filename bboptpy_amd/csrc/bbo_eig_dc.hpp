@@ -1580,10 +1580,8 @@ __device__ __forceinline__ void eig_dc_phase(const DcMat &Q, int n, double *dv, 
 
     DC_STAMP(22);
     if (mode == 1) {
-        for (int q = tid; q < n * n; q += T) {
-            const int r = q / n, cc = q - r * n;
-            Bout[(size_t) r * ldb + (single ? W.outpos[cc] : cc)] = Q(r, cc);
-        }
+        for (int r = wave; r < n; r += NW)
+            for (int cc = lane; cc < n; cc += 64) Bout[(size_t) r * ldb + (single ? W.outpos[cc] : cc)] = Q(r, cc);
         __syncthreads();
         return;
     }
