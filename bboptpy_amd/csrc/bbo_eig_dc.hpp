@@ -318,8 +318,25 @@ __device__ __forceinline__ void dc_secular(const DcWork &W, int k, double rho, i
     double fm = 0.;
     {
         const double midp = 0.5 * (dj + dn);
-        if (act)
-            for (int i = sub; i < k; i += LPR) fm += W.w2[i] * dc_rcp(W.dl[i] - midp);
+        if (act) {
+            // (four entries requested together, from clamped addresses, and added in the list's order:
+            // entry by entry this loop is one dependent round trip per entry when the work area is
+            // the global image of cma_eig_secular -- 8 to 16 of them in front of the solve)
+            const int npl0 = (k + LPR - 1) / LPR;
+            for (int t0 = 0; t0 < npl0; t0 += 4) {
+                double ww[4], dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ic = min(sub + (t0 + u) * LPR, k - 1);
+                    ww[u] = W.w2[ic];
+                    dd[u] = W.dl[ic];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (sub + (t0 + u) * LPR < k) fm += ww[u] * dc_rcp(dd[u] - midp);
+            }
+        }
         fm = 1. + rho * dc_quad_sum<LPR>(fm);
     }
     const bool left = fm > 0. || last;
