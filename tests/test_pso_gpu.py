@@ -119,6 +119,17 @@ def test_chunk_of_the_whole_swarm_is_the_synchronous_form(hip, oracle_lib):
         _close(g.get_state("xbest"), o.get("xbest"), 1e-11, "gen %d gbest" % gen)
 
 
+@pytest.mark.parametrize("np_", [30, 64, 65, 200, 1024, 5000, 40000])
+def test_bench_prices_a_launch_with_the_engines_chunk(hip, np_):
+    """bench.py prices ONE pso_update launch with the chunk of particles it moves: its rule and
+    the engine's must be the same"""
+    import bench
+    n = 4
+    g = hip.APSO(mfev=10 ** 7, tol=1e-12, np=np_, seed=1)
+    g.initialize(hip.objectives.sphere, -np.ones(n), np.ones(n), np.zeros(n))
+    assert int(g.get_state("chunk")[0]) == bench.pso_chunk(np_)
+
+
 def test_python_objective_sees_the_same_chunks(hip):
     """a Python callable and the built-in objective of the same function: the same swarm after
     every generation (the host path evaluates chunk by chunk, the best refreshed in between)"""
